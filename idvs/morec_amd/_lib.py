@@ -1,0 +1,90 @@
+"""ctypes binding of ``libmorec_hip.so`` (the C-ABI declared in ``include/morec_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call returns non-zero, this module raises.
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C idvs/morec_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmorec_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+class MorecError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int), ("dact", C.c_int),
+                ("accumulate", C.c_int), ("split_k", C.c_int), ("alpha", C.c_float)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("n_seq", C.c_int), ("T", C.c_int), ("n_heads", C.c_int), ("dh", C.c_int), ("causal", C.c_int),
+                ("scale", C.c_float), ("mask_value", C.c_float), ("dtype", C.c_int)]
+
+
+class CeDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("S", C.c_int), ("D", C.c_int), ("Nc", C.c_int), ("col_offset", C.c_int),
+                ("dtype", C.c_int)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    "morec_strerror": (C.c_char_p, [C.c_int]),
+    "morec_version": (C.c_int, []),
+    "morec_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "morec_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
+                                      C.c_int, _P]),
+    "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),
+    "morec_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "morec_bert_embed_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _P]),
+    "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_scatter_add_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_strided_rows_copy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_inbatch_ce_workspace_bytes": (C.c_size_t, [C.POINTER(CeDesc)]),
+    "morec_inbatch_ce_fwd": (C.c_int, [C.POINTER(CeDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "morec_inbatch_ce_bwd": (C.c_int, [C.POINTER(CeDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P,
+                                       _P]),
+    "morec_adamw": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                              C.c_int, C.c_float, _P]),
+    "morec_eval_rank": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_probe": (C.c_int, [_P, _P]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises ``MorecError`` if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MorecError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C idvs/morec_amd/csrc` -- there is no CPU/PyTorch fallback path")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().morec_strerror(rc)
+        raise MorecError(f"{what} failed: rc={rc} ({msg.decode() if msg else '?'})")

@@ -1,0 +1,308 @@
+// attention.hip -- small-tile multi-head attention, forward and backward, one wavefront per
+// (sequence, head).  The sequences on this path are tiny and fixed (user history S = 20 / 10, titles
+// T = 30): the problem is "many independent 32 x 32 score tiles", not long context, so the design is
+//   * Q / K / V (and dO) d-chunks staged in LDS as fp32 (chunking makes any head width work:
+//     BERT dh = 64, SASRec d_k = 256 ... 2048),
+//   * each lane owns a 4 x 4 block of the 32 x 32 score tile in registers (8 x 8 lanes),
+//   * softmax row statistics by wave64 shuffles across the 8 lanes that share a row,
+//   * P (and dS) parked in LDS for the second product.
+// HBM traffic is exactly one read of qkv (+ dctx) and one write of ctx (dqkv): the kernel is
+// HBM/latency-bound; FLOPs are < 1 % of the encoder's.
+// Reference arithmetic: SASRec T/model/encoders.py:24-27 + T/model/modules.py:27-31 (mask built from
+// log_mask inside the kernel: key kept iff log_mask[b, j] != 0 and j <= i, additive -1e9);
+// BERT: HF BertSelfAttention eager path (additive finfo.min on padded keys).
+#include "common.hpp"
+
+namespace {
+constexpr int TP = 32;   // padded tile edge
+constexpr int PP = 36;   // pitch (floats) of the 32 x 32 probability tiles
+
+struct AttnArgs {
+    const void* qkv;
+    const float* key_keep;
+    void* ctx;         // fwd: output; bwd: dctx input
+    void* dqkv;        // bwd only
+    int n_seq, T, n_heads, dh;
+    int causal;
+    float scale, mask_value;
+};
+
+// stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to 32 rows
+template <typename T, int DC>
+__device__ __forceinline__ void stage_chunk(const T* __restrict__ src, size_t row0, int pitch, int col0, int d0, int dh,
+                                            int Tlen, float* __restrict__ dst) {
+    constexpr int P = DC + 4;
+    constexpr int VEC = TP * DC / 4;  // float4 slots
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < VEC / 64; ++i) {
+        const int v = lane + i * 64;
+        const int r = v / (DC / 4), c = (v % (DC / 4)) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < Tlen && d0 + c < dh) io<T>::load4(src + (row0 + r) * (size_t)pitch + col0 + d0 + c, o);
+        *reinterpret_cast<float4*>(dst + r * P + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// s[r][c] += sum_d X[i0 + r][d] * Y[j0 + c][d] over one staged chunk
+template <int DC>
+__device__ __forceinline__ void block_dot(const float* __restrict__ X, const float* __restrict__ Y, int i0, int j0,
+                                          float (&s)[4][4]) {
+    constexpr int P = DC + 4;
+#pragma unroll 4
+    for (int d = 0; d < DC; d += 4) {
+        float4 x[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(X + (i0 + r) * P + d);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const float4*>(Y + (j0 + c) * P + d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                s[r][c] += x[r].x * y[c].x + x[r].y * y[c].y + x[r].z * y[c].z + x[r].w * y[c].w;
+    }
+}
+
+// masked, scaled softmax of the lane's 4 x 4 block; rows are shared by the 8 lanes with equal (lane >> 3)
+__device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, int Tlen, int causal, float scale,
+                                              float mask_value, const float* __restrict__ keep_row) {
+    float keep[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) keep[c] = (j0 + c < Tlen) ? keep_row[j0 + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + r;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = j0 + c;
+            const bool kept = (keep[c] != 0.f) && (!causal || j <= i);
+            // reference arithmetic: score * scale + additive mask (the large-magnitude mask absorbs the score)
+            const float v = s[r][c] * scale + (kept ? 0.f : mask_value);
+            s[r][c] = (j < Tlen) ? v : -INFINITY;
+            m = fmaxf(m, s[r][c]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float e = (j0 + c < Tlen) ? expf(s[r][c] - m) : 0.f;
+            s[r][c] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sum += __shfl_xor(sum, 4, 64);
+        const float inv = (i < Tlen) ? 1.0f / sum : 0.f;   // padded query rows contribute nothing downstream
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[r][c] *= inv;
+    }
+}
+
+// o[r][0..CW-1] = sum_k W[k][w0 + r] * V[k][c0 .. c0+CW-1]   (W stored [k][32 + pad]: "weights by row k");
+// CW = DC / 8 columns per lane so that the 8 x 8 lane grid covers a [32 x DC] output chunk exactly.
+template <int DC>
+__device__ __forceinline__ void block_pv(const float* __restrict__ W, const float* __restrict__ V, int w0, int c0,
+                                         int klen, float (&o)[4][DC / 8]) {
+    constexpr int P = DC + 4, CW = DC / 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) o[r][c] = 0.f;
+    for (int k = 0; k < klen; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(W + k * PP + w0);
+        const float wr[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < CW / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(V + k * P + c0 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r][4 * q + 0] += wr[r] * v.x; o[r][4 * q + 1] += wr[r] * v.y;
+                o[r][4 * q + 2] += wr[r] * v.z; o[r][4 * q + 3] += wr[r] * v.w;
+            }
+        }
+    }
+}
+
+template <typename T, int CW>
+__device__ __forceinline__ void store_rows(T* __restrict__ dst, size_t row0, int pitch, int col, int r0, int Tlen,
+                                           int dcol, int dh, const float (&o)[4][CW]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r0 + r < Tlen) {
+            T* p = dst + (row0 + r0 + r) * (size_t)pitch + col;
+#pragma unroll
+            for (int q = 0; q < CW / 4; ++q) {
+                const float v[4] = {o[r][4 * q], o[r][4 * q + 1], o[r][4 * q + 2], o[r][4 * q + 3]};
+                if (dcol + 4 * q < dh) io<T>::store4(p + 4 * q, v);
+            }
+        }
+    }
+}
+
+template <typename T, int DC>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int P = DC + 4;
+    __shared__ __attribute__((aligned(16))) float sA[TP * P];
+    __shared__ __attribute__((aligned(16))) float sB[TP * P];
+    __shared__ __attribute__((aligned(16))) float sPt[TP * PP];   // P transposed: [key j][query i]
+    const int lane = threadIdx.x;
+    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const size_t row0 = (size_t)seq * a.T;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+
+    float s[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[r][c] = 0.f;
+    for (int d0 = 0; d0 < a.dh; d0 += DC) {
+        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sA);
+        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sB);
+        __syncthreads();
+        block_dot<DC>(sA, sB, i0, j0, s);
+        __syncthreads();
+    }
+    block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<float4*>(sPt + (j0 + c) * PP + i0) = make_float4(s[0][c], s[1][c], s[2][c], s[3][c]);
+    __syncthreads();
+    T* ctx = reinterpret_cast<T*>(a.ctx);
+    constexpr int CW = DC / 8;
+    const int c0 = (lane & 7) * CW;
+    for (int d0 = 0; d0 < a.dh; d0 += DC) {
+        stage_chunk<T, DC>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sA);
+        __syncthreads();
+        float o[4][CW];
+        block_pv<DC>(sPt, sA, i0, c0, a.T, o);
+        store_rows<T, CW>(ctx, row0, H, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        __syncthreads();
+    }
+}
+
+// Backward: recomputes P from Q, K (no forward state kept), then
+//   dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(P o dP)) * scale, dQ = dS K, dK = dS^T Q.
+template <typename T, int DC>
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
+    constexpr int P = DC + 4;
+    __shared__ __attribute__((aligned(16))) float sQ[TP * P];
+    __shared__ __attribute__((aligned(16))) float sK[TP * P];
+    __shared__ __attribute__((aligned(16))) float sV[TP * P];
+    __shared__ __attribute__((aligned(16))) float sO[TP * P];
+    __shared__ __attribute__((aligned(16))) float sP[TP * PP];    // P   [query i][key j]
+    __shared__ __attribute__((aligned(16))) float sS[TP * PP];    // dS  [query i][key j]
+    __shared__ __attribute__((aligned(16))) float sSt[TP * PP];   // dS^T [key j][query i]
+    const int lane = threadIdx.x;
+    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const size_t row0 = (size_t)seq * a.T;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* dctx = reinterpret_cast<const T*>(a.ctx);
+    T* dqkv = reinterpret_cast<T*>(a.dqkv);
+    const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+
+    float s[4][4], dp[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[r][c] = 0.f; dp[r][c] = 0.f; }
+    for (int d0 = 0; d0 < a.dh; d0 += DC) {
+        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
+        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
+        stage_chunk<T, DC>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sV);
+        stage_chunk<T, DC>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
+        __syncthreads();
+        block_dot<DC>(sQ, sK, i0, j0, s);
+        block_dot<DC>(sO, sV, i0, j0, dp);
+        __syncthreads();
+    }
+    block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float delta = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) delta += s[r][c] * dp[r][c];
+        delta += __shfl_xor(delta, 1, 64);
+        delta += __shfl_xor(delta, 2, 64);
+        delta += __shfl_xor(delta, 4, 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dp[r][c] = s[r][c] * (dp[r][c] - delta) * a.scale;   // dp now holds dS
+        *reinterpret_cast<float4*>(sP + (i0 + r) * PP + j0) = make_float4(s[r][0], s[r][1], s[r][2], s[r][3]);
+        *reinterpret_cast<float4*>(sS + (i0 + r) * PP + j0) = make_float4(dp[r][0], dp[r][1], dp[r][2], dp[r][3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<float4*>(sSt + (j0 + c) * PP + i0) = make_float4(dp[0][c], dp[1][c], dp[2][c], dp[3][c]);
+    __syncthreads();
+    constexpr int CW = DC / 8;
+    const int c0 = (lane & 7) * CW;
+    for (int d0 = 0; d0 < a.dh; d0 += DC) {
+        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
+        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
+        stage_chunk<T, DC>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
+        __syncthreads();
+        float o[4][CW];
+        // dQ[i0..][cols] = sum_j dS^T[j][i0..] * K[j][cols]
+        block_pv<DC>(sSt, sK, i0, c0, a.T, o);
+        store_rows<T, CW>(dqkv, row0, pitch, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        // dK[j..][cols] = sum_i dS[i][j..] * Q[i][cols]   (the lane's row block i0 doubles as its key block)
+        block_pv<DC>(sS, sQ, i0, c0, a.T, o);
+        store_rows<T, CW>(dqkv, row0, pitch, H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        // dV[j..][cols] = sum_i P[i][j..] * dO[i][cols]
+        block_pv<DC>(sP, sO, i0, c0, a.T, o);
+        store_rows<T, CW>(dqkv, row0, pitch, 2 * H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        __syncthreads();
+    }
+}
+
+int check_desc(const morec_attn_desc* d) {
+    if (!d) return MOREC_E_ARG;
+    if (d->n_seq <= 0 || d->T <= 0 || d->n_heads <= 0 || d->dh <= 0) return MOREC_E_ARG;
+    if (d->T > TP) return MOREC_E_UNSUPPORTED;
+    if (d->dh % 8) return MOREC_E_ALIGN;
+    return MOREC_OK;
+}
+}  // namespace
+
+extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx,
+                              void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!qkv || !key_keep || !ctx) return MOREC_E_ARG;
+    AttnArgs a{qkv, key_keep, ctx, nullptr, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value};
+    dim3 grid(d->n_seq * d->n_heads), block(64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MOREC_F32)
+        hipLaunchKernelGGL((attn_fwd_kernel<float, 64>), grid, block, 0, s, a);
+    else if (d->dtype == MOREC_BF16)
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16, 64>), grid, block, 0, s, a);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx,
+                              void* dqkv, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!qkv || !key_keep || !dctx || !dqkv) return MOREC_E_ARG;
+    AttnArgs a{qkv, key_keep, const_cast<void*>(dctx), dqkv, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale,
+               d->mask_value};
+    dim3 grid(d->n_seq * d->n_heads), block(64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MOREC_F32)
+        hipLaunchKernelGGL((attn_bwd_kernel<float, 32>), grid, block, 0, s, a);
+    else if (d->dtype == MOREC_BF16)
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 32>), grid, block, 0, s, a);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

@@ -1,0 +1,65 @@
+// capi.hip -- library-level entry points: error strings, version, hardware probe.
+#include "common.hpp"
+
+extern "C" const char* morec_strerror(int code) {
+    switch (code) {
+        case MOREC_OK: return "ok";
+        case MOREC_E_ARG: return "MOREC_E_ARG: null pointer or non-positive size";
+        case MOREC_E_ALIGN: return "MOREC_E_ALIGN: pointer/pitch not 16-byte aligned or size not a vector multiple";
+        case MOREC_E_UNSUPPORTED: return "MOREC_E_UNSUPPORTED: shape outside kernel limits";
+        case MOREC_E_DTYPE: return "MOREC_E_DTYPE: unsupported dtype combination";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+    return "unknown morec error";
+}
+
+extern "C" int morec_version(void) { return 100; }
+
+// Probe: (a) MFMA fragment/accumulator layouts with recognisable integer data, (b) what each lane of
+// ds_read_b64_tr_b16 receives when lane l supplies address base + 8*l over an LDS image lds16[x] = x.
+// out[0..255]     : 16x16x32 bf16: D = A.B with A[i][k] = (k == i) ? 1 : 0 for i<16 (k<16), B[k][j] = 16*k + j
+//                   (assumed layouts: lane l gives row/col l&15, k = 8*(l>>4)+e) -> out[l*4+r] should be
+//                   D[(l>>4)*4+r][l&15] = 16*((l>>4)*4+r) + (l&15)
+// out[256..511]   : 16x16x4 f32 with the same test (k < 4 only -> rows 0..3 nonzero)
+// out[512..767]   : tr_b16 values, 4 per lane
+__global__ void probe_kernel(int32_t* out) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds16[1024];
+    const int l = threadIdx.x;
+    for (int i = l; i < 1024; i += 64) lds16[i] = (unsigned short)i;
+    __syncthreads();
+    {
+        bf16x8_t a, b;
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * (l >> 4) + e;
+            const float av = (k == (l & 15)) ? 1.f : 0.f;                    // A[i = l&15][k]
+            const float bv = (k < 16) ? (float)(16 * k + (l & 15)) : 0.f;    // B[k][j = l&15]
+            a[e] = (__bf16)av;
+            b[e] = (__bf16)bv;
+        }
+        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) out[l * 4 + r] = (int32_t)c[r];
+    }
+    {
+        const int k = l >> 4;
+        const float av = (k == (l & 15)) ? 1.f : 0.f;
+        const float bv = (float)(16 * k + (l & 15));
+        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) out[256 + l * 4 + r] = (int32_t)c[r];
+    }
+    {
+        uint64_t v;
+        const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned short*)lds16 + 8u * l;
+        asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        for (int r = 0; r < 4; ++r) out[512 + l * 4 + r] = (int32_t)((v >> (16 * r)) & 0xffffu);
+    }
+}
+
+extern "C" int morec_probe(int32_t* out, void* stream) {
+    if (!out) return MOREC_E_ARG;
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), out);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

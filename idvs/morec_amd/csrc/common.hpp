@@ -1,0 +1,92 @@
+// common.hpp -- shared device helpers for the gfx950 (MI355X) kernels of libmorec_hip.so.
+// wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "morec_hip.h"
+
+#define MOREC_WAVE 64
+
+struct bf16 {
+    unsigned short v;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16 x) { return __uint_as_float(((uint32_t)x.v) << 16); }
+__device__ __forceinline__ float bfbits2f(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+__device__ __forceinline__ unsigned short f2bf_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // round-nearest-even
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ bf16 f2bf(float f) { return bf16{f2bf_bits(f)}; }
+
+// ---- typed 4-element vector IO (16 B for f32, 8 B for bf16) --------------------------------------
+template <typename T>
+struct io;
+template <>
+struct io<float> {
+    static constexpr int dtype = MOREC_F32;
+    __device__ __forceinline__ static void load4(const float* p, float (&o)[4]) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    __device__ __forceinline__ static void store4(float* p, const float (&o)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __device__ __forceinline__ static float load1(const float* p) { return *p; }
+    __device__ __forceinline__ static void store1(float* p, float v) { *p = v; }
+    // what a value becomes when written to memory as T and read back
+    __device__ __forceinline__ static float round(float v) { return v; }
+};
+template <>
+struct io<bf16> {
+    static constexpr int dtype = MOREC_BF16;
+    __device__ __forceinline__ static void load4(const bf16* p, float (&o)[4]) {
+        uint2 v = *reinterpret_cast<const uint2*>(p);
+        o[0] = bfbits2f(v.x & 0xffffu); o[1] = bfbits2f(v.x >> 16);
+        o[2] = bfbits2f(v.y & 0xffffu); o[3] = bfbits2f(v.y >> 16);
+    }
+    __device__ __forceinline__ static void store4(bf16* p, const float (&o)[4]) {
+        uint2 v;
+        v.x = (uint32_t)f2bf_bits(o[0]) | ((uint32_t)f2bf_bits(o[1]) << 16);
+        v.y = (uint32_t)f2bf_bits(o[2]) | ((uint32_t)f2bf_bits(o[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = v;
+    }
+    __device__ __forceinline__ static float load1(const bf16* p) { return bf2f(*p); }
+    __device__ __forceinline__ static void store1(bf16* p, float v) { *p = f2bf(v); }
+    __device__ __forceinline__ static float round(float v) { return bf2f(f2bf(v)); }
+};
+
+// ---- wave-level reductions (64 lanes) ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf GELU and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- host-side argument checks -------------------------------------------------------------------------
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int elt_size(int dtype) { return dtype == MOREC_BF16 ? 2 : 4; }
+#define MOREC_CHECK_LAUNCH()                        \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)

@@ -1,0 +1,253 @@
+// embed.hip -- embedding gathers / scatters (HBM-bound integer-indexed row traffic).
+//   BERT embeddings (HF BertEmbeddings): word[ids] + position[t] + token_type[0] -> LayerNorm, fused;
+//   backward scatter-add into the three tables (word row pad_id skipped: nn.Embedding padding_idx);
+//   ID tower (T/model/model.py:27-28,37): row gather / scatter-add with padding_idx = 0;
+//   strided row copies for hidden[:, 0] (T/model/encoders.py:69).
+#include "common.hpp"
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __restrict__ ids,
+                                                             const float* __restrict__ word,
+                                                             const float* __restrict__ pos,
+                                                             const float* __restrict__ type0,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             T* __restrict__ z_out, T* __restrict__ y,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             int M, int Tlen, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const size_t base = (size_t)row * H;
+    const float* w = word + (size_t)ids[row] * H;
+    const float* p = pos + (size_t)(row % Tlen) * H;
+    float v[VPL][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) {
+            const float4 a = *reinterpret_cast<const float4*>(w + c);
+            const float4 b = *reinterpret_cast<const float4*>(p + c);
+            const float4 t = *reinterpret_cast<const float4*>(type0 + c);
+            // HF order: (inputs_embeds + token_type_embeddings) + position_embeddings
+            v[i][0] = (a.x + t.x) + b.x; v[i][1] = (a.y + t.y) + b.y;
+            v[i][2] = (a.z + t.z) + b.z; v[i][3] = (a.w + t.w) + b.w;
+            if (z_out) {
+                io<T>::store4(z_out + base + c, v[i]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = io<T>::round(v[i][k]);
+            }
+            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[i][k] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)H + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+            float o[4];
+            o[0] = (v[i][0] - mean) * rstd * g.x + b.x;
+            o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
+            o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
+            o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+            io<T>::store4(y + base + c, o);
+        }
+    }
+}
+
+extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
+                                    const float* gamma, const float* beta, float eps, void* z_out, void* y,
+                                    float* mean, float* rstd, int M, int T, int H, int dtype, void* stream) {
+    if (!ids || !word || !pos || !type0 || !gamma || !beta || !y || M <= 0 || T <= 0 || H <= 0) return MOREC_E_ARG;
+    if (H % 4) return MOREC_E_ALIGN;
+    const int vpl = (H + 255) / 256;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define EMB(TT, V)                                                                                                  \
+    hipLaunchKernelGGL((bert_embed_fwd_kernel<TT, V>), grid, block, 0, s, ids, word, pos, type0, gamma, beta, eps, \
+                       (TT*)z_out, (TT*)y, mean, rstd, M, T, H)
+#define EMB_DISPATCH(TT)                      \
+    do {                                      \
+        if (vpl <= 1) EMB(TT, 1);             \
+        else if (vpl <= 2) EMB(TT, 2);        \
+        else if (vpl <= 3) EMB(TT, 3);        \
+        else if (vpl <= 4) EMB(TT, 4);        \
+        else if (vpl <= 8) EMB(TT, 8);        \
+        else return MOREC_E_UNSUPPORTED;      \
+    } while (0)
+    if (dtype == MOREC_F32) EMB_DISPATCH(float);
+    else if (dtype == MOREC_BF16) EMB_DISPATCH(bf16);
+    else return MOREC_E_DTYPE;
+#undef EMB
+#undef EMB_DISPATCH
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+// word-table scatter: one wave per token row, fp32 atomics (duplicate tokens collide in L2)
+template <typename T>
+__global__ __launch_bounds__(256) void word_scatter_kernel(const int32_t* __restrict__ ids, const T* __restrict__ dz,
+                                                           float* __restrict__ dword, int pad_id, int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int id = ids[row];
+    if (id == pad_id) return;
+    float* dst = dword + (size_t)id * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        io<T>::load4(dz + (size_t)row * H + c, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dst + c + k, v[k]);
+    }
+}
+
+// dpos[t] = sum over sequences of dz[seq*T + t]; dtype0 = sum over all rows: block (t, chunk of sequences)
+template <typename T>
+__global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
+                                                            float* __restrict__ dtype0, int nseq, int Tlen, int H,
+                                                            int seq_per_block) {
+    const int t = blockIdx.x;
+    const int s0 = blockIdx.y * seq_per_block, s1 = min(nseq, s0 + seq_per_block);
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float acc = 0.f;
+        for (int sq = s0; sq < s1; ++sq) acc += io<T>::load1(dz + ((size_t)sq * Tlen + t) * H + c);
+        atomicAdd(dpos + (size_t)t * H + c, acc);
+        if (dtype0) atomicAdd(dtype0 + c, acc);
+    }
+}
+
+extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0,
+                                    int pad_id, int M, int T, int H, int dtype, void* stream) {
+    if (!ids || !dz || !dword || !dpos || M <= 0 || T <= 0 || H <= 0 || M % T) return MOREC_E_ARG;
+    if (H % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int spb = 64;
+    dim3 g1((M + 3) / 4), g2(T, (M / T + spb - 1) / spb);
+    if (dtype == MOREC_F32) {
+        hipLaunchKernelGGL((word_scatter_kernel<float>), g1, dim3(256), 0, s, ids, (const float*)dz, dword, pad_id, M, H);
+        hipLaunchKernelGGL((pos_type_grad_kernel<float>), g2, dim3(256), 0, s, (const float*)dz, dpos, dtype0, M / T, T, H, spb);
+    } else if (dtype == MOREC_BF16) {
+        hipLaunchKernelGGL((word_scatter_kernel<bf16>), g1, dim3(256), 0, s, ids, (const bf16*)dz, dword, pad_id, M, H);
+        hipLaunchKernelGGL((pos_type_grad_kernel<bf16>), g2, dim3(256), 0, s, (const bf16*)dz, dpos, dtype0, M / T, T, H, spb);
+    } else {
+        return MOREC_E_DTYPE;
+    }
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
+                                                          T* __restrict__ out, int R, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* src = table + (size_t)idx[row] * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        const float o[4] = {v.x, v.y, v.z, v.w};
+        io<T>::store4(out + (size_t)row * D + c, o);
+    }
+}
+
+extern "C" int morec_gather_rows(const float* table, const int32_t* idx, void* out, int R, int D, int dtype,
+                                 void* stream) {
+    if (!table || !idx || !out || R <= 0 || D <= 0) return MOREC_E_ARG;
+    if (D % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((R + 3) / 4);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((gather_rows_kernel<float>), grid, dim3(256), 0, s, table, idx, (float*)out, R, D);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, dim3(256), 0, s, table, idx, (bf16*)out, R, D);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restrict__ d, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ dtable, int R, int D, int pad_id) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int id = idx[row];
+    if (id == pad_id) return;
+    float* dst = dtable + (size_t)id * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float v[4];
+        io<T>::load4(d + (size_t)row * D + c, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dst + c + k, v[k]);
+    }
+}
+
+extern "C" int morec_scatter_add_rows(const void* d, const int32_t* idx, float* dtable, int R, int D, int pad_id,
+                                      int dtype, void* stream) {
+    if (!d || !idx || !dtable || R <= 0 || D <= 0) return MOREC_E_ARG;
+    if (D % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((R + 3) / 4);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)d, idx, dtable, R, D, pad_id);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((scatter_add_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)d, idx, dtable, R, D, pad_id);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void strided_rows_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int D,
+                                                           int in_stride, int out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    for (int c = lane * 4; c < D; c += 256) {
+        float v[4];
+        io<T>::load4(in + (size_t)row * in_stride * D + c, v);
+        io<T>::store4(out + (size_t)row * out_stride * D + c, v);
+    }
+}
+
+extern "C" int morec_strided_rows_copy(const void* in, void* out, int R, int D, int in_row_stride, int out_row_stride,
+                                       int dtype, void* stream) {
+    if (!in || !out || R <= 0 || D <= 0 || in_row_stride <= 0 || out_row_stride <= 0) return MOREC_E_ARG;
+    if (D % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((R + 3) / 4);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((strided_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, R, D, in_row_stride, out_row_stride);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((strided_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, R, D, in_row_stride, out_row_stride);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

@@ -1,0 +1,237 @@
+// gemm.hip -- NT GEMM with fused epilogues (bias, GELU/ReLU, activation-derivative, split-K atomics),
+// plus the layout helpers the backward pass needs (transpose with conversion, cast, column sums).
+// Reference arithmetic replaced: see include/morec_hip.h (morec_gemm_nt).
+#include "gemm_core.hpp"
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;
+    void* aux_out;
+    const void* dact_in;
+    int M, N, K, lda, ldb, ldc;
+    int act, dact, accumulate;
+    int kchunk;
+    int tiles_m, tiles_n;
+    float alpha;
+};
+
+template <typename TI, typename TO, int KSUB>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+    using G = GemmTile<TI, KSUB>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
+    const int m0 = tm * G::TM, n0 = tn * G::TN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    gemm_mainloop<TI, KSUB>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb,
+                            m0, n0, kbeg, kend, smem, acc);
+
+    TO* C = reinterpret_cast<TO*>(p.C);
+    TO* aux = reinterpret_cast<TO*>(p.aux_out);
+    const TO* din = reinterpret_cast<const TO*>(p.dact_in);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = acc_row(m0, mi);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = acc_col(n0, ni);
+            if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            const size_t off = (size_t)m * p.ldc + n;
+            if (aux) io<TO>::store4(aux + off, v);
+            if (p.act == MOREC_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            } else if (p.act == MOREC_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (p.dact != MOREC_ACT_NONE) {
+                float u[4];
+                io<TO>::load4(din + off, u);
+                if (p.dact == MOREC_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
+                }
+            }
+            if (p.accumulate == 0) {
+                io<TO>::store4(C + off, v);
+            } else if (p.accumulate == 1) {
+                float c[4];
+                io<TO>::load4(C + off, c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += c[r];
+                io<TO>::store4(C + off, v);
+            } else {
+                if constexpr (sizeof(TO) == 4) {
+                    float* cf = reinterpret_cast<float*>(C) + off;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(cf + r, v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO, int KSUB>
+static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+    using G = GemmTile<TI, KSUB>;
+    const int split = d->split_k < 1 ? 1 : d->split_k;
+    int kchunk = (d->K + split - 1) / split;
+    kchunk = ((kchunk + G::KE - 1) / G::KE) * G::KE;
+    a.kchunk = kchunk;
+    const int zs = (d->K + kchunk - 1) / kchunk;
+    a.tiles_m = (d->M + G::TM - 1) / G::TM;
+    a.tiles_n = (d->N + G::TN - 1) / G::TN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<TI, TO, KSUB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, zs);
+    hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, KSUB>), grid, dim3(256), G::LDS_BYTES, s, a);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                             void* aux_out, const void* dact_in, void* stream) {
+    if (!d || !A || !B || !C) return MOREC_E_ARG;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return MOREC_E_ARG;
+    const int es = elt_size(d->in_dtype), os = elt_size(d->out_dtype);
+    if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias))) return MOREC_E_ALIGN;
+    if ((d->lda * es) % 16 || (d->ldb * es) % 16 || (d->K * es) % 16) return MOREC_E_ALIGN;
+    if (d->N % 4 || (d->ldc * os) % (4 * os) || d->ldc % 4) return MOREC_E_ALIGN;
+    if (d->split_k > 1 && d->accumulate != 2) return MOREC_E_ARG;
+    if (d->accumulate == 2 && d->out_dtype != MOREC_F32) return MOREC_E_DTYPE;
+    if (d->dact != MOREC_ACT_NONE && !dact_in) return MOREC_E_ARG;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
+    a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float, 2>(d, a, s);
+    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16, 2>(d, a, s);
+    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_F32) return launch_gemm<bf16, float, 2>(d, a, s);
+    return MOREC_E_DTYPE;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transpose (+ conversion): 64 x 64 tiles through LDS, coalesced on both sides
+// ---------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C,
+                                                        int ld_in, int ld_out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + i * 4, c = c0 + tx;
+        tile[ty + i * 4][tx] = (r < R && c < C) ? io<TI>::load1(in + (size_t)r * ld_in + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + i * 4, r = r0 + tx;
+        if (c < C && r < R) io<TO>::store1(out + (size_t)c * ld_out + r, tile[tx][ty + i * 4]);
+    }
+}
+
+extern "C" int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype,
+                               int out_dtype, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0) return MOREC_E_ARG;
+    dim3 grid((C + 63) / 64, (R + 63) / 64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (in_dtype == MOREC_F32 && out_dtype == MOREC_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ld_in, ld_out);
+    else if (in_dtype == MOREC_F32 && out_dtype == MOREC_BF16)
+        hipLaunchKernelGGL((transpose_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)in, (bf16*)out, R, C, ld_in, ld_out);
+    else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, R, C, ld_in, ld_out);
+    else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_F32)
+        hipLaunchKernelGGL((transpose_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)in, (float*)out, R, C, ld_in, ld_out);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float v[4];
+        io<TI>::load4(in + i * 4, v);
+        io<TO>::store4(out + i * 4, v);
+    }
+}
+
+extern "C" int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream) {
+    if (!in || !out) return MOREC_E_ARG;
+    if (n == 0) return MOREC_OK;
+    if (n % 4 || !aligned16(in) || (reinterpret_cast<uintptr_t>(out) & 7u)) return MOREC_E_ALIGN;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (in_dtype == MOREC_F32 && out_dtype == MOREC_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(blocks), dim3(256), 0, s, (const float*)in, (bf16*)out, n4);
+    else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(blocks), dim3(256), 0, s, (const bf16*)in, (float*)out, n4);
+    else if (in_dtype == MOREC_F32 && out_dtype == MOREC_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, s, (const float*)in, (float*)out, n4);
+    else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, (const bf16*)in, (bf16*)out, n4);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+// column sums: each block reduces a [rows_per_block x 256-column] slab, one atomicAdd per column per block
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int M, int N,
+                                                     int ld, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += io<T>::load1(in + (size_t)r * ld + n);
+    atomicAdd(out + n, s);
+}
+
+extern "C" int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream) {
+    if (!in || !out || M <= 0 || N <= 0) return MOREC_E_ARG;
+    const int rpb = 128;
+    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)in, out, M, N, ld, rpb);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, out, M, N, ld, rpb);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

@@ -1,0 +1,331 @@
+// inbatch_ce.hip -- fused in-batch debiased sampled-softmax cross-entropy (the "scoring kernel").
+//
+// Reference (T/model/model.py:32-33,45-67): logits = P.E^T - log(pop[ids]) are materialised as an
+// [B*S, B*(S+1)] fp32 matrix, masked by a Python double loop over users (one boolean compare of size
+// (S+1) x S*Nc per user), then fed to nn.CrossEntropyLoss.  Here each 128 x 128 logit tile lives only in
+// MFMA accumulators: the tile is produced by the shared GEMM main loop, the column-validity mask, the
+// popularity correction and the per-user id-membership reject mask (positive restored) are applied in
+// registers, and only per-(row, 64-column) softmax partials (max, sum-exp) leave the workgroup.
+//
+// Masking rules, bit-exact with the reference's bookkeeping:
+//   column c invalid (padding slot)                          -> -1e4          (model.py:51-52)
+//   ids[c] in {ids of user u's S+1 slots} and c != label(r)  -> -1e4          (model.py:54-63)
+//   label(r = u*S + j) = col_offset + u*(S+1) + j + 1                         (model.py:45-48)
+// Masked cells keep the VALUE -1e4 inside the softmax (exactly as the reference) and get zero gradient.
+#include "gemm_core.hpp"
+
+namespace {
+constexpr float MASKED_LOGIT = -1e4f;
+constexpr int MAX_TILE_USERS = 130;  // users overlapped by a 128-row tile when S >= 1
+
+struct CeArgs {
+    const void* P;
+    const void* E;
+    const int32_t* row_ids;
+    const int32_t* col_ids;
+    const float* col_logpop;
+    const uint8_t* col_valid;
+    const uint8_t* row_valid;
+    float* pmax;      // fwd: [Nr][K2] partial maxima         bwd: unused
+    float* psum;      // fwd: [Nr][K2] partial sum-exp
+    float* pos;       // fwd: [Nr] positive logit
+    const float* row_lse;   // bwd
+    void* dl;         // bwd: [Nr][ld_dl] dlogits (dtype T)
+    const float* gscale_dev;
+    float gscale;
+    int B, S, D, Nr, Nc, col_offset, K2, ld_dl, ldp, lde;
+    int tiles_m, tiles_n;
+};
+
+// Turns the accumulator tile into masked logits in place.  Uses LDS (free after the main loop) for the
+// tile's user id lists, column ids and the [user][column] membership bytes.
+// Returns through `lab[mi]` the label column of each of the lane's 4 rows (or -1 when the row is out of range).
+template <typename T>
+__device__ __forceinline__ void masked_logits(const CeArgs& p, int m0, int n0, char* smem, f32x4_t (&acc)[4][4],
+                                              int (&lab)[4]) {
+    int32_t* s_uid = reinterpret_cast<int32_t*>(smem);                       // [nu][S+1]
+    const int S1 = p.S + 1;
+    const int u_lo = m0 / p.S;
+    const int u_hi = min(p.B - 1, (min(m0 + 127, p.Nr - 1)) / p.S);
+    const int nu = u_hi - u_lo + 1;
+    int32_t* s_cid = s_uid + ((nu * S1 + 3) & ~3);                           // [128]
+    uint8_t* s_mem = reinterpret_cast<uint8_t*>(s_cid + 128);               // [nu][128]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nu * S1; i += 256) s_uid[i] = p.row_ids[u_lo * S1 + i];
+    if (tid < 128) s_cid[tid] = (n0 + tid < p.Nc) ? p.col_ids[n0 + tid] : -1;
+    __syncthreads();
+    for (int i = tid; i < nu * 128; i += 256) {
+        const int u = i >> 7, c = i & 127;
+        const int32_t id = s_cid[c];
+        bool hit = false;
+        for (int k = 0; k < S1; ++k) hit |= (s_uid[u * S1 + k] == id);
+        s_mem[i] = (hit && n0 + c < p.Nc) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = acc_row(m0, mi);
+        lab[mi] = -1;
+        if (m >= p.Nr) continue;
+        const int u = m / p.S, j = m - u * p.S;
+        lab[mi] = p.col_offset + u * S1 + j + 1;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = acc_col(n0, ni);
+            const uint32_t mem4 = *reinterpret_cast<const uint32_t*>(s_mem + (u - u_lo) * 128 + (n - n0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = n + r;
+                float v = -INFINITY;   // columns past the pool do not exist
+                if (c < p.Nc) {
+                    const bool rejected = ((mem4 >> (8 * r)) & 1u) && (c != lab[mi]);
+                    v = (p.col_valid[c] == 0 || rejected) ? MASKED_LOGIT : acc[mi][ni][r] - p.col_logpop[c];
+                }
+                acc[mi][ni][r] = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(CeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (wg / p.tiles_n) * 128, n0 = (wg % p.tiles_n) * 128;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    gemm_mainloop<T, 2>(reinterpret_cast<const T*>(p.P), reinterpret_cast<const T*>(p.E), p.Nr, p.Nc, p.ldp, p.lde, m0,
+                        n0, 0, p.D, smem, acc);
+    int lab[4];
+    masked_logits<T>(p, m0, n0, smem, acc, lab);
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+    const int half = (wg % p.tiles_n) * 2 + wn;   // which 64-column slice of the pool this wave covered
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = acc_row(m0, mi);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[mi][ni][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = acc_col(n0, ni);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[mi][ni][r];
+                if (mx > -INFINITY) sm += expf(v - mx);   // v == -inf (no such column) contributes 0
+                if (m < p.Nr && n + r == lab[mi]) p.pos[m] = v;
+            }
+        }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (m < p.Nr && (lane >> 4) == 0) {
+            p.pmax[(size_t)m * p.K2 + half] = mx;
+            p.psum[(size_t)m * p.K2 + half] = sm;
+        }
+    }
+}
+
+// one wave per row: merge the K2 partials -> lse, loss; block-sum the valid rows' losses into loss_sum
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                         const float* __restrict__ pos,
+                                                         const uint8_t* __restrict__ row_valid,
+                                                         float* __restrict__ row_lse, float* __restrict__ row_loss,
+                                                         float* __restrict__ loss_sum, int Nr, int K2) {
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    float loss = 0.f;
+    if (row < Nr) {
+        float mx = -INFINITY;
+        for (int k = lane; k < K2; k += 64) mx = fmaxf(mx, pmax[(size_t)row * K2 + k]);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int k = lane; k < K2; k += 64) {
+            const float pm = pmax[(size_t)row * K2 + k];
+            if (pm > -INFINITY) sm += psum[(size_t)row * K2 + k] * expf(pm - mx);
+        }
+        sm = wave_sum(sm);
+        const float lse = mx + logf(sm);
+        loss = row_valid[row] ? (lse - pos[row]) : 0.f;
+        if (lane == 0) {
+            row_lse[row] = lse;
+            row_loss[row] = loss;
+        }
+    }
+    if (lane == 0) s_part[wave] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
+// backward, stage 1: recompute the logit tile and emit dlogits = g * (softmax - onehot) for the unmasked
+// cells of valid rows (0 elsewhere), written once as dtype T; the two products dP = dl.E and dE = dl^T.P
+// then run on the shared GEMM kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_dl_kernel(CeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (wg / p.tiles_n) * 128, n0 = (wg % p.tiles_n) * 128;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    gemm_mainloop<T, 2>(reinterpret_cast<const T*>(p.P), reinterpret_cast<const T*>(p.E), p.Nr, p.Nc, p.ldp, p.lde, m0,
+                        n0, 0, p.D, smem, acc);
+    int lab[4];
+    masked_logits<T>(p, m0, n0, smem, acc, lab);
+    const float g = p.gscale * (p.gscale_dev ? *p.gscale_dev : 1.0f);
+    T* dl = reinterpret_cast<T*>(p.dl);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = acc_row(m0, mi);
+        if (m >= p.Nr) continue;
+        const float w = p.row_valid[m] ? g : 0.f;
+        const float lse = p.row_lse[m];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = acc_col(n0, ni);
+            if (n >= p.ld_dl) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[mi][ni][r];
+                float d = 0.f;
+                // cells overwritten with -1e4 receive no gradient (index_put semantics); their softmax mass is
+                // exp(-1e4 - lse) == 0 in fp32 whenever the row has a finite positive
+                if (n + r < p.Nc && v != MASKED_LOGIT) d = expf(v - lse) - ((n + r == lab[mi]) ? 1.f : 0.f);
+                o[r] = w * d;
+            }
+            io<T>::store4(dl + (size_t)m * p.ld_dl + n, o);
+        }
+    }
+}
+
+inline int pad8(int x) { return (x + 7) & ~7; }
+}  // namespace
+
+// workspace layout (floats unless noted):
+//   fwd:  pmax [Nr*K2] | psum [Nr*K2] | pos [Nr]
+//   bwd:  dl T[Nr*ldc] | dlt T[Nc*ldr] | Pt T[D*ldr] | Et T[D*ldc]     (ldc = pad8(Nc), ldr = pad8(Nr))
+extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
+    if (!d) return 0;
+    const size_t Nr = (size_t)d->B * d->S, Nc = d->Nc, D = d->D;
+    const size_t K2 = 2 * ((Nc + 127) / 128);
+    const size_t fwd = (2 * Nr * K2 + Nr) * sizeof(float);
+    const size_t es = elt_size(d->dtype);
+    const size_t ldc = pad8((int)Nc), ldr = pad8((int)Nr);
+    const size_t bwd = (Nr * ldc + Nc * ldr + D * ldr + D * ldc) * es + 256;
+    return (fwd > bwd ? fwd : bwd) + 256;
+}
+
+static int ce_fill(const morec_ce_desc* d, CeArgs& a) {
+    if (!d || d->B <= 0 || d->S <= 0 || d->D <= 0 || d->Nc <= 0) return MOREC_E_ARG;
+    if ((d->D * elt_size(d->dtype)) % 16) return MOREC_E_ALIGN;
+    if (d->dtype != MOREC_F32 && d->dtype != MOREC_BF16) return MOREC_E_DTYPE;
+    if (d->col_offset < 0 || d->col_offset + d->B * (d->S + 1) > d->Nc) return MOREC_E_ARG;
+    a.B = d->B; a.S = d->S; a.D = d->D; a.Nr = d->B * d->S; a.Nc = d->Nc; a.col_offset = d->col_offset;
+    a.tiles_m = (a.Nr + 127) / 128; a.tiles_n = (a.Nc + 127) / 128; a.K2 = 2 * a.tiles_n;
+    a.ldp = d->D; a.lde = d->D;
+    return MOREC_OK;
+}
+
+extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids,
+                                    const int32_t* col_ids, const float* col_logpop, const uint8_t* col_valid,
+                                    const uint8_t* row_valid, float* row_lse, float* row_loss, float* loss_sum,
+                                    void* workspace, void* stream) {
+    CeArgs a{};
+    int rc = ce_fill(d, a);
+    if (rc) return rc;
+    if (!P || !E || !row_ids || !col_ids || !col_logpop || !col_valid || !row_valid || !row_lse || !row_loss ||
+        !loss_sum || !workspace)
+        return MOREC_E_ARG;
+    if (!aligned16(P) || !aligned16(E) || !aligned16(workspace)) return MOREC_E_ALIGN;
+    a.P = P; a.E = E; a.row_ids = row_ids; a.col_ids = col_ids; a.col_logpop = col_logpop; a.col_valid = col_valid;
+    a.row_valid = row_valid;
+    float* ws = reinterpret_cast<float*>(workspace);
+    a.pmax = ws; a.psum = ws + (size_t)a.Nr * a.K2; a.pos = ws + 2 * (size_t)a.Nr * a.K2;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (d->dtype == MOREC_F32) {
+        using G = GemmTile<float, 2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, dim3(256), G::LDS_BYTES, s, a);
+    } else {
+        using G = GemmTile<bf16, 2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<bf16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
+    }
+    MOREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_combine_kernel, dim3((a.Nr + 3) / 4), dim3(256), 0, s, a.pmax, a.psum, a.pos, row_valid,
+                       row_lse, row_loss, loss_sum, a.Nr, a.K2);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids,
+                                    const int32_t* col_ids, const float* col_logpop, const uint8_t* col_valid,
+                                    const uint8_t* row_valid, const float* row_lse, const float* gscale_dev,
+                                    float gscale, void* dP, void* dE, void* workspace, void* stream) {
+    CeArgs a{};
+    int rc = ce_fill(d, a);
+    if (rc) return rc;
+    if (!P || !E || !row_ids || !col_ids || !col_logpop || !col_valid || !row_valid || !row_lse || !dP || !dE ||
+        !workspace)
+        return MOREC_E_ARG;
+    if (!aligned16(P) || !aligned16(E) || !aligned16(workspace) || !aligned16(dP) || !aligned16(dE))
+        return MOREC_E_ALIGN;
+    a.P = P; a.E = E; a.row_ids = row_ids; a.col_ids = col_ids; a.col_logpop = col_logpop; a.col_valid = col_valid;
+    a.row_valid = row_valid; a.row_lse = row_lse; a.gscale_dev = gscale_dev; a.gscale = gscale;
+    const int es = elt_size(d->dtype);
+    const int ldc = pad8(a.Nc), ldr = pad8(a.Nr);
+    char* ws = reinterpret_cast<char*>(workspace);
+    char* dl = ws;
+    char* dlt = dl + (((size_t)a.Nr * ldc * es + 15) & ~(size_t)15);
+    char* Pt = dlt + (((size_t)a.Nc * ldr * es + 15) & ~(size_t)15);
+    char* Et = Pt + (((size_t)a.D * ldr * es + 15) & ~(size_t)15);
+    a.dl = dl; a.ld_dl = ldc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ldr != a.Nr) {  // zero the pad columns the transposes do not touch
+        (void)hipMemsetAsync(dlt, 0, (size_t)a.Nc * ldr * es, s);
+        (void)hipMemsetAsync(Pt, 0, (size_t)a.D * ldr * es, s);
+    }
+    if (ldc != a.Nc) (void)hipMemsetAsync(Et, 0, (size_t)a.D * ldc * es, s);
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (d->dtype == MOREC_F32) {
+        using G = GemmTile<float, 2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_bwd_dl_kernel<float>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipLaunchKernelGGL((ce_bwd_dl_kernel<float>), grid, dim3(256), G::LDS_BYTES, s, a);
+    } else {
+        using G = GemmTile<bf16, 2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_bwd_dl_kernel<bf16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipLaunchKernelGGL((ce_bwd_dl_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
+    }
+    MOREC_CHECK_LAUNCH();
+    rc = morec_transpose(dl, dlt, a.Nr, a.Nc, ldc, ldr, d->dtype, d->dtype, stream);
+    if (rc) return rc;
+    rc = morec_transpose(P, Pt, a.Nr, a.D, a.D, ldr, d->dtype, d->dtype, stream);
+    if (rc) return rc;
+    rc = morec_transpose(E, Et, a.Nc, a.D, a.D, ldc, d->dtype, d->dtype, stream);
+    if (rc) return rc;
+    morec_gemm_desc g{};
+    g.in_dtype = d->dtype; g.out_dtype = d->dtype; g.alpha = 1.0f; g.split_k = 1;
+    // dP[Nr, D] = dl[Nr, Nc] . Et[D, Nc]^T
+    g.M = a.Nr; g.N = a.D; g.K = ldc; g.lda = ldc; g.ldb = ldc; g.ldc = a.D;
+    rc = morec_gemm_nt(&g, dl, Et, dP, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    // dE[Nc, D] = dlt[Nc, Nr] . Pt[D, Nr]^T
+    g.M = a.Nc; g.N = a.D; g.K = ldr; g.lda = ldr; g.ldb = ldr; g.ldc = a.D;
+    return morec_gemm_nt(&g, dlt, Pt, dE, nullptr, nullptr, nullptr, stream);
+}

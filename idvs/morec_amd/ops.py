@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C-ABI (``include/morec_hip.h``): they marshal ``torch`` device tensors
+into raw pointers + sizes and launch on torch's current HIP stream.  PyTorch is plumbing here (memory,
+streams); all arithmetic happens in ``libmorec_hip.so``.  Every wrapper raises on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, AttnDesc, CeDesc, GemmDesc, check
+
+FLT_MIN_MASK = -3.4028234663852886e38  # torch.finfo(torch.float32).min: HF eager additive key mask
+
+
+def code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise _lib.MorecError(f"unsupported dtype {dt}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.MorecError("libmorec_hip needs device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise _lib.MorecError("tensor must be contiguous")
+    return t
+
+
+def pad8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+# ---------------------------------------------------------------------------------------------------------
+def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=None, dact=ACT_NONE, dact_in=None,
+            accumulate=0, split_k=1, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    """out[M,N] (+)= alpha * a[M,K] @ b[N,K]^T with the fused epilogues of ``morec_gemm_nt``."""
+    _dev(a), _dev(b)
+    M = a.shape[0] if M is None else M
+    K = a.shape[1] if K is None else K
+    N = b.shape[0] if N is None else N
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
+    ldc = out.stride(0) if ldc is None else ldc
+    d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha)
+    check(_lib.lib().morec_gemm_nt(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux_out), _p(dact_in), _stream()),
+          "morec_gemm_nt")
+    return out
+
+
+def transpose(x, out=None, out_dtype=None, ld_out=None):
+    """[R, C] -> [C, ld_out>=R] (pad columns, if any, are zero)."""
+    _dev(x)
+    R, Cc = x.shape
+    ld_out = pad8(R) if ld_out is None else ld_out
+    if out is None:
+        alloc = torch.zeros if ld_out != R else torch.empty
+        out = alloc((Cc, ld_out), device=x.device, dtype=out_dtype or x.dtype)
+    check(_lib.lib().morec_transpose(_p(x), _p(out), R, Cc, x.stride(0), out.stride(0), code(x.dtype), code(out.dtype),
+                                     _stream()), "morec_transpose")
+    return out
+
+
+def cast(x, out_dtype, out=None):
+    _dev(x)
+    if out is None:
+        out = torch.empty_like(x, dtype=out_dtype)
+    check(_lib.lib().morec_cast(_p(x), _p(out), x.numel(), code(x.dtype), code(out.dtype), _stream()), "morec_cast")
+    return out
+
+
+def colsum_(x, out, M=None, N=None, ld=None):
+    """out[N] += column sums of x[M, N] (fp32 atomics)."""
+    _dev(x)
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    ld = x.stride(0) if ld is None else ld
+    check(_lib.lib().morec_colsum(_p(x), _p(out), M, N, ld, code(x.dtype), _stream()), "morec_colsum")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, save_z=True, z_inplace=False):
+    _dev(x)
+    M, N = x.shape
+    y = torch.empty_like(x)
+    need_z = save_z and (bias is not None or res is not None or pos is not None)
+    z = (x if z_inplace else torch.empty_like(x)) if need_z else None
+    mean = torch.empty(M, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(_lib.lib().morec_layernorm_fwd(_p(x), _p(bias), _p(res), _p(pos), pos_period, _p(gamma), _p(beta), eps, _p(z),
+                                         _p(y), _p(mean), _p(rstd), M, N, code(x.dtype), _stream()), "morec_layernorm_fwd")
+    return y, (z if need_z else x), mean, rstd
+
+
+def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta):
+    _dev(dy_a)
+    M, N = z.shape
+    dz = torch.empty_like(z)
+    check(_lib.lib().morec_layernorm_bwd(_p(dy_a), _p(dy_b), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dgamma),
+                                         _p(dbeta), M, N, code(z.dtype), _stream()), "morec_layernorm_bwd")
+    return dz
+
+
+def pos_grad_(dz, dpos, period):
+    M, N = dz.shape
+    check(_lib.lib().morec_pos_grad(_p(dz), _p(dpos), M, N, period, code(dz.dtype), _stream()), "morec_pos_grad")
+
+
+def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype):
+    return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype))
+
+
+def attn_fwd(desc, qkv, key_keep):
+    _dev(qkv), _dev(key_keep)
+    ctx = torch.empty((qkv.shape[0], qkv.shape[1] // 3), device=qkv.device, dtype=qkv.dtype)
+    check(_lib.lib().morec_attn_fwd(C.byref(desc), _p(qkv), _p(key_keep), _p(ctx), _stream()), "morec_attn_fwd")
+    return ctx
+
+
+def attn_bwd(desc, qkv, key_keep, dctx):
+    _dev(dctx)
+    dqkv = torch.empty_like(qkv)
+    check(_lib.lib().morec_attn_bwd(C.byref(desc), _p(qkv), _p(key_keep), _p(dctx), _p(dqkv), _stream()), "morec_attn_bwd")
+    return dqkv
+
+
+def bert_embed_fwd(ids32, word, pos, type0, gamma, beta, eps, T, dtype):
+    M = ids32.numel()
+    H = word.shape[1]
+    z = torch.empty((M, H), device=word.device, dtype=dtype)
+    y = torch.empty_like(z)
+    mean = torch.empty(M, device=word.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=word.device, dtype=torch.float32)
+    check(_lib.lib().morec_bert_embed_fwd(_p(ids32), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), eps, _p(z),
+                                          _p(y), _p(mean), _p(rstd), M, T, H, code(dtype), _stream()), "morec_bert_embed_fwd")
+    return y, z, mean, rstd
+
+
+def bert_embed_bwd_(ids32, dz, dword, dpos, dtype0, pad_id, T):
+    M, H = dz.shape
+    check(_lib.lib().morec_bert_embed_bwd(_p(ids32), _p(dz), _p(dword), _p(dpos), _p(dtype0), pad_id, M, T, H,
+                                          code(dz.dtype), _stream()), "morec_bert_embed_bwd")
+
+
+def gather_rows(table, idx32, dtype):
+    R, D = idx32.numel(), table.shape[1]
+    out = torch.empty((R, D), device=table.device, dtype=dtype)
+    check(_lib.lib().morec_gather_rows(_p(table), _p(idx32), _p(out), R, D, code(dtype), _stream()), "morec_gather_rows")
+    return out
+
+
+def scatter_add_rows_(d, idx32, dtable, pad_id):
+    R, D = d.shape
+    check(_lib.lib().morec_scatter_add_rows(_p(_dev(d)), _p(idx32), _p(dtable), R, D, pad_id, code(d.dtype), _stream()),
+          "morec_scatter_add_rows")
+
+
+def strided_rows_copy(src, out, R, D, in_stride, out_stride):
+    check(_lib.lib().morec_strided_rows_copy(_p(src), _p(out), R, D, in_stride, out_stride, code(src.dtype), _stream()),
+          "morec_strided_rows_copy")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+def ce_desc(B, S, D, Nc, col_offset, dtype):
+    return CeDesc(B, S, D, Nc, col_offset, code(dtype))
+
+
+def ce_workspace(desc, device):
+    n = _lib.lib().morec_inbatch_ce_workspace_bytes(C.byref(desc))
+    return torch.empty(n, device=device, dtype=torch.uint8)
+
+
+def inbatch_ce_fwd(desc, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, ws):
+    Nr = desc.B * desc.S
+    lse = torch.empty(Nr, device=P.device, dtype=torch.float32)
+    row_loss = torch.empty(Nr, device=P.device, dtype=torch.float32)
+    loss_sum = torch.zeros(1, device=P.device, dtype=torch.float32)
+    check(_lib.lib().morec_inbatch_ce_fwd(C.byref(desc), _p(_dev(P)), _p(_dev(E)), _p(row_ids), _p(col_ids), _p(col_logpop),
+                                          _p(col_valid), _p(row_valid), _p(lse), _p(row_loss), _p(loss_sum), _p(ws),
+                                          _stream()), "morec_inbatch_ce_fwd")
+    return loss_sum, lse, row_loss
+
+
+def inbatch_ce_bwd(desc, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, lse, gscale_dev, gscale, ws):
+    dP = torch.empty_like(P)
+    dE = torch.empty_like(E)
+    check(_lib.lib().morec_inbatch_ce_bwd(C.byref(desc), _p(P), _p(E), _p(row_ids), _p(col_ids), _p(col_logpop),
+                                          _p(col_valid), _p(row_valid), _p(lse), _p(gscale_dev), gscale, _p(dP), _p(dE),
+                                          _p(ws), _stream()), "morec_inbatch_ce_bwd")
+    return dP, dE
+
+
+def adamw_(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    check(_lib.lib().morec_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(), lr, beta1,
+                                 beta2, eps, wd, step, grad_scale, _stream()), "morec_adamw")
+
+
+def eval_rank(prec, item_emb, hist32, target32):
+    U, D = prec.shape
+    rank = torch.empty(U, device=prec.device, dtype=torch.int32)
+    ts = torch.empty(U, device=prec.device, dtype=torch.float32)
+    check(_lib.lib().morec_eval_rank(_p(_dev(prec)), _p(_dev(item_emb)), _p(_dev(hist32)), hist32.shape[1], _p(target32),
+                                     _p(rank), _p(ts), U, item_emb.shape[0], D, _stream()), "morec_eval_rank")
+    return rank
+
+
+def probe(device="cuda"):
+    out = torch.zeros(4096, device=device, dtype=torch.int32)
+    check(_lib.lib().morec_probe(_p(out), _stream()), "morec_probe")
+    return out

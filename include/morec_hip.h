@@ -1,0 +1,191 @@
+/*
+ * morec_hip.h -- C-ABI of libmorec_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * end-to-end MoRec in-batch training step (westlake-repl/IDvs.MoRec, inbatch_sasrec_e2e_text).
+ *
+ * The reference is pure Python over PyTorch/HuggingFace and has NO FFI of its own:
+ * every entry point below therefore cites the reference Python call site whose arithmetic it
+ * replaces (paths relative to /root/reference, T/ = inbatch_sasrec_e2e_text/), and INTEGRATION.md
+ * shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named h_*;
+ *   - the caller owns every buffer (PyTorch caching allocator); the library allocates nothing and
+ *     keeps no global state; every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative MOREC_E_* for bad arguments, a positive value = hipError_t;
+ *   - dtype codes: MOREC_F32 = 0 (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32), MOREC_BF16 = 1
+ *     (bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16);
+ *   - row-major matrices with explicit leading dimensions in ELEMENTS; every base pointer and
+ *     every row pitch must be 16-byte aligned (MOREC_E_ALIGN otherwise);
+ *   - item ids are int32 on the device (the host narrows the int64 ids PyTorch provides).
+ */
+#ifndef MOREC_HIP_H
+#define MOREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOREC_F32 0
+#define MOREC_BF16 1
+
+#define MOREC_OK 0
+#define MOREC_E_ARG (-1)         /* null pointer / non-positive size */
+#define MOREC_E_ALIGN (-2)       /* pointer or pitch not 16-byte aligned / size not a multiple of the vector width */
+#define MOREC_E_UNSUPPORTED (-3) /* shape outside what the kernel was written for */
+#define MOREC_E_DTYPE (-4)
+
+#define MOREC_ACT_NONE 0
+#define MOREC_ACT_GELU 1 /* exact erf GELU (HF BertIntermediate; T/model/encoders.py:59 nn.GELU) */
+#define MOREC_ACT_RELU 2 /* T/model/modules.py:12 */
+
+const char* morec_strerror(int code);
+int morec_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T  (both operands K-contiguous, "NT")
+ * Replaces every nn.Linear / torch.matmul on the path (T/model/modules.py:14,56-61;
+ * HF modeling_bert.py BertSelfAttention/BertSelfOutput/BertIntermediate/BertOutput;
+ * T/model/encoders.py:69; T/model/model.py:49) and, fed with transposed operands, their
+ * autograd backward (dX = dY.W, dW = dY^T.X).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    int lda, ldb, ldc;
+    int in_dtype;      /* dtype of A and B */
+    int out_dtype;     /* dtype of C (and aux_out / dact_in) */
+    int act;           /* MOREC_ACT_*: C = act(acc + bias); aux_out (optional) receives acc + bias */
+    int dact;          /* MOREC_ACT_*: C = (acc) * act'(dact_in[m,n]) -- backward through an activation */
+    int accumulate;    /* 0: C = v   1: C += v (non-atomic)   2: atomicAdd (fp32 C only; used with split_k) */
+    int split_k;       /* >= 1: K is cut into split_k chunks over blockIdx.z (requires accumulate == 2 when > 1) */
+    float alpha;
+} morec_gemm_desc;
+
+int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                  void* aux_out, const void* dact_in, void* stream);
+
+/* out[c, r] = in[r, c]; in is [R, C] with pitch ld_in, out is [C, R] with pitch ld_out.
+ * in_dtype/out_dtype select a fused conversion (f32 -> bf16 weight shadows). */
+int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype, int out_dtype,
+                    void* stream);
+/* elementwise convert n elements */
+int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream);
+/* out[n] = sum_m in[m, n]  (bias gradients), atomically accumulated into fp32 out */
+int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm with fused pre-add:  z = x (+ bias[n]) (+ res[m,n]) (+ pos[m % pos_period, n]);
+ * y = (z - mean) * rstd * gamma + beta.   (T/model/modules.py:17,63,93; HF BertSelfOutput /
+ * BertOutput / BertEmbeddings LayerNorm).  z_out may be NULL (not needed) or alias x.
+ * ------------------------------------------------------------------------------------------ */
+int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
+                        const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
+                        float* rstd, int M, int N, int dtype, void* stream);
+/* dz = LN'(dy_a + dy_b; z).  dgamma/dbeta are atomically accumulated (fp32, [N]).  dy_b may be NULL. */
+int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
+                        const float* gamma, void* dz, float* dgamma, float* dbeta, int M, int N, int dtype,
+                        void* stream);
+/* dpos[m % period, n] += dz[m, n]  (position-embedding gradient, fp32 atomics) */
+int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-tile multi-head attention on packed projections qkv[M, 3*H] = [Q | K | V], M = n_seq*T,
+ * H = n_heads*dh, T <= 32.  scores = (q.k) * scale + (key masked ? mask_value : 0), causal option,
+ * softmax, ctx = P.V.   SASRec: T/model/encoders.py:24-27 + T/model/modules.py:27-31 (causal,
+ * mask_value -1e9, scale 1/sqrt(d_k)).  BERT: HF BertSelfAttention eager (mask_value finfo.min).
+ * key_keep: float [n_seq, T], nonzero = attend.  One wavefront per (sequence, head).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int n_seq, T, n_heads, dh;
+    int causal;
+    float scale, mask_value;
+    int dtype;
+} morec_attn_desc;
+
+int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx, void* stream);
+int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx, void* dqkv,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embeddings
+ * ------------------------------------------------------------------------------------------ */
+/* BERT embeddings: z = word[ids[m]] + pos[m % T] + type0;  y = LN(z)  (HF BertEmbeddings). */
+int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
+                         const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
+                         float* rstd, int M, int T, int H, int dtype, void* stream);
+/* scatter dz into dword[ids[m]] (skipping pad_id: nn.Embedding padding_idx), dpos[m % T], dtype0 */
+int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0, int pad_id,
+                         int M, int T, int H, int dtype, void* stream);
+/* out[r, :] = table[idx[r], :]  (fp32 table -> dtype out).  T/model/model.py:37 nn.Embedding lookup. */
+int morec_gather_rows(const float* table, const int32_t* idx, void* out, int R, int D, int dtype, void* stream);
+/* dtable[idx[r], :] += d[r, :] unless idx[r] == pad_id (padding_idx=0, T/model/model.py:27) */
+int morec_scatter_add_rows(const void* d, const int32_t* idx, float* dtable, int R, int D, int pad_id, int dtype,
+                           void* stream);
+/* strided row copy: out[r, :] = in[r*stride_rows, :]  (hidden[:, 0], T/model/encoders.py:69) and its
+ * backward (scatter into a zero-filled [R*stride_rows, D]) */
+int morec_strided_rows_copy(const void* in, void* out, int R, int D, int in_row_stride, int out_row_stride,
+                            int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * In-batch debiased sampled-softmax cross-entropy (T/model/model.py:32-33,45-67), fused:
+ * logits never reach HBM.  P [Nr, D] user states (Nr = B*S rows), E [Nc, D] item vectors of the
+ * column pool (local: Nc = B*(S+1); pooled over ranks: SURVEY.md §8e), both `dtype`.
+ *   row_ids   int32 [B*(S+1)]  ids of this rank's users (reject sets)
+ *   col_ids   int32 [Nc]       ids of the pool columns
+ *   col_logpop float [Nc]      log(pop_prob[col_ids])
+ *   col_valid uint8 [Nc]       slot is not padding (cat(log_mask, 1) != 0)
+ *   row_valid uint8 [Nr]       log_mask != 0
+ *   col_offset                 column of this rank's slot 0 in the pool
+ * fwd: per-(row, 64-column slice) partial (max, sumexp) + positive logit -> row_lse[Nr], row_loss[Nr]
+ *      and loss_sum (fp32 scalar accumulated atomically; caller zeroes it).
+ * bwd: dP[Nr, D] and dE[Nc, D] (dtype, overwritten):
+ *      dlogit = gscale * (*gscale_dev if given) * (softmax - onehot) on unmasked cells of valid rows,
+ *      0 elsewhere; dP = dlogit . E, dE = dlogit^T . P.
+ * workspace (both): morec_inbatch_ce_workspace_bytes().
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, S, D;
+    int Nc;
+    int col_offset;
+    int dtype;
+} morec_ce_desc;
+
+size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d);
+int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids,
+                         const int32_t* col_ids, const float* col_logpop, const uint8_t* col_valid,
+                         const uint8_t* row_valid, float* row_lse, float* row_loss, float* loss_sum,
+                         void* workspace, void* stream);
+int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids,
+                         const int32_t* col_ids, const float* col_logpop, const uint8_t* col_valid,
+                         const uint8_t* row_valid, const float* row_lse, const float* gscale_dev, float gscale,
+                         void* dP, void* dE, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter arena (torch.optim.AdamW semantics, T/run.py:159-162,246).
+ * One launch per hyper-parameter group (contiguous range).  Optionally refreshes the bf16 shadow.
+ * step = 1-based step count after increment.
+ * ------------------------------------------------------------------------------------------ */
+int morec_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, size_t n,
+                float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation (T/data_utils/metrics.py:96-102,49-57): rank of the target among all items after
+ * masking the history -- count-greater instead of a full argsort.
+ * scores = prec[U, D] . item_emb[item_num+1, D]^T are formed tile by tile; rank[u] = 1 + #{items i>=1,
+ * i not in history(u), score[u,i] > score[u,target[u]]}.
+ * hist: int32 [U, Hmax] padded with -1.
+ * ------------------------------------------------------------------------------------------ */
+int morec_eval_rank(const float* prec, const float* item_emb, const int32_t* hist, int Hmax, const int32_t* target,
+                    int32_t* rank, float* tscore_ws /* float[U] scratch */, int U, int n_items_plus1, int D,
+                    void* stream);
+
+/* diagnostics: dumps MFMA fragment layouts and ds_read_b64_tr_b16 semantics into out (int32[4096]) */
+int morec_probe(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOREC_HIP_H */

@@ -1,0 +1,351 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp64/fp32
+reference of the same op (and the CPU oracle for the loss / ranks).  Tolerances: exact-fp32 MFMA path
+1e-5-class; bf16 path 2e-2 relative to the tensor's max-abs (stated per test)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from idvs.morec_amd import ops  # noqa: E402
+from idvs.morec_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU  # noqa: E402
+
+DEV = "cuda"
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return 2e-5 if dt == torch.float32 else 2.5e-2
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rnd(*shape, dt=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dt)
+
+
+def test_probe_mfma_layouts():
+    out = ops.probe().cpu().numpy()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/probe.txt", "w") as f:
+        f.write("bf16 16x16x32:\n%s\nf32 16x16x4:\n%s\ntr_b16 (lane: 4 values):\n%s\n" % (
+            out[:256].reshape(64, 4), out[256:512].reshape(64, 4), out[512:768].reshape(64, 4)))
+    lanes = np.arange(64)
+    exp_bf = np.stack([16 * ((lanes >> 4) * 4 + r) + (lanes & 15) for r in range(4)], 1)
+    assert np.array_equal(out[:256].reshape(64, 4), exp_bf)
+    exp_f = np.where(((lanes >> 4) * 4 + np.arange(4)[:, None]) < 4,
+                     16 * ((lanes >> 4) * 4 + np.arange(4)[:, None]) + (lanes & 15), 0).T
+    assert np.array_equal(out[256:512].reshape(64, 4), exp_f)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(128, 128, 64), (300, 260, 136), (77, 512, 768), (2560, 2688, 512), (4096, 768, 3072)])
+def test_gemm_plain(dt, shape):
+    M, N, K = shape
+    a, b = rnd(M, K, dt=dt), rnd(N, K, dt=dt, seed=1)
+    c = ops.gemm_nt(a, b)
+    ref = a.double() @ b.double().t()
+    assert rel(c, ref) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_epilogues(dt):
+    M, N, K = 260, 384, 256
+    a, b = rnd(M, K, dt=dt, scale=0.2), rnd(N, K, dt=dt, scale=0.2, seed=1)
+    bias = rnd(N, seed=2)
+    aux = torch.empty(M, N, device=DEV, dtype=dt)
+    c = ops.gemm_nt(a, b, bias=bias, act=ACT_GELU, aux_out=aux)
+    pre = a.double() @ b.double().t() + bias.double()
+    assert rel(aux, pre) < tol(dt)
+    assert rel(c, torch.nn.functional.gelu(pre)) < tol(dt)
+    c = ops.gemm_nt(a, b, bias=bias, act=ACT_RELU)
+    assert rel(c, torch.relu(pre)) < tol(dt)
+    # derivative epilogues
+    u = rnd(M, N, dt=dt, seed=3)
+    c = ops.gemm_nt(a, b, dact=ACT_GELU, dact_in=u)
+    ud = u.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    assert rel(c, (a.double() @ b.double().t()) * ud.grad) < tol(dt)
+    c = ops.gemm_nt(a, b, dact=ACT_RELU, dact_in=u)
+    assert rel(c, (a.double() @ b.double().t()) * (u.double() > 0)) < tol(dt)
+    # accumulate and alpha
+    c0 = rnd(M, N, dt=dt, seed=4)
+    c = ops.gemm_nt(a, b, out=c0.clone(), accumulate=1, alpha=0.5)
+    assert rel(c, c0.double() + 0.5 * (a.double() @ b.double().t())) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_splitk_atomic(dt):
+    M, N, K = 768, 768, 20160
+    a, b = rnd(M, K, dt=dt, scale=0.1), rnd(N, K, dt=dt, scale=0.1, seed=1)
+    out = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_nt(a, b, out=out, accumulate=2, split_k=8)
+    assert rel(out, a.double() @ b.double().t()) < tol(dt)
+    # odd K tail + pitch larger than K
+    K2 = 1000
+    out.zero_()
+    ops.gemm_nt(a, b, out=out, accumulate=2, split_k=3, K=K2)
+    assert rel(out, a[:, :K2].double() @ b[:, :K2].double().t()) < tol(dt)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_transpose_cast_colsum(dt):
+    x = rnd(300, 170, dt=dt)
+    xt = ops.transpose(x)
+    assert xt.shape == (170, 304) and torch.equal(xt[:, :300], x.t()) and (xt[:, 300:] == 0).all()
+    w = rnd(96, 200)
+    wt = ops.transpose(w, out_dtype=torch.bfloat16)
+    assert torch.equal(wt[:, :96], w.t().to(torch.bfloat16))
+    assert torch.equal(ops.cast(w, torch.bfloat16), w.to(torch.bfloat16))
+    out = torch.zeros(170, device=DEV)
+    ops.colsum_(x, out)
+    assert rel(out, x.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("N", [64, 512, 768, 2048])
+def test_layernorm(dt, N):
+    M, S = 203 * 4 + 1, 7
+    M = (M // S) * S
+    x, res = rnd(M, N, dt=dt), rnd(M, N, dt=dt, seed=1)
+    bias, pos = rnd(N, seed=2), rnd(S, N, seed=3)
+    gamma, beta = 1 + 0.1 * rnd(N, seed=4), 0.1 * rnd(N, seed=5)
+    y, z, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6, bias=bias, res=res, pos=pos, pos_period=S)
+    zr = x.double() + bias.double() + res.double() + pos.double().repeat(M // S, 1)
+    assert rel(z, zr) < tol(dt)
+    zs = z.double().requires_grad_(True)  # the kernel normalises the stored (rounded) z
+    yr = torch.nn.functional.layer_norm(zs, (N,), gamma.double(), beta.double(), 1e-6)
+    assert rel(y, yr) < tol(dt)
+    dy_a, dy_b = rnd(M, N, dt=dt, seed=6), rnd(M, N, dt=dt, seed=7)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(zs, (N,), gd, bd, 1e-6)
+    (yr * (dy_a.double() + dy_b.double())).sum().backward()
+    dgamma, dbeta = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dz = ops.layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta)
+    assert rel(dz, zs.grad) < tol(dt)
+    assert rel(dgamma, gd.grad) < 1e-4 and rel(dbeta, bd.grad) < 1e-4
+    dpos = torch.zeros(S, N, device=DEV)
+    ops.pos_grad_(dz, dpos, S)
+    assert rel(dpos, dz.double().view(M // S, S, N).sum(0)) < 1e-5
+    # no pre-add: z aliases x
+    y2, z2, _, _ = ops.layernorm_fwd(x, gamma, beta, 1e-12)
+    assert z2 is x
+    assert rel(y2, torch.nn.functional.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-12)) < tol(dt)
+
+
+def attn_ref(qkv, keep, n_heads, causal, scale, mask_value):
+    M, H3 = qkv.shape
+    n_seq, T = keep.shape
+    H = H3 // 3
+    dh = H // n_heads
+    q, k, v = (qkv[:, i * H:(i + 1) * H].reshape(n_seq, T, n_heads, dh).transpose(1, 2) for i in range(3))
+    kept = (keep != 0)[:, None, None, :].expand(n_seq, 1, T, T)
+    if causal:
+        kept = torch.tril(kept)
+    # same fp32 absorb semantics as the reference, evaluated in float32 on purpose
+    att = (q.float() @ k.float().transpose(-1, -2)) * scale + torch.where(kept, 0.0, mask_value).float()
+    p = torch.softmax(att.double(), -1)
+    return (p @ v.double()).transpose(1, 2).reshape(M, H)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [(5, 30, 12, 64, False, ops.FLT_MIN_MASK), (4, 20, 2, 256, True, -1e9),
+                                 (3, 7, 2, 32, True, -1e9), (6, 32, 2, 64, False, -10000.0), (2, 10, 2, 1024, True, -1e9)])
+def test_attention(dt, cfg):
+    n_seq, T, nh, dh, causal, mv = cfg
+    H = nh * dh
+    qkv = rnd(n_seq * T, 3 * H, dt=dt, scale=0.7)
+    keep = torch.ones(n_seq, T, device=DEV)
+    for s in range(n_seq):
+        n_pad = (s * 5) % T
+        if causal:
+            keep[s, :n_pad] = 0        # left padding (log_mask)
+        else:
+            keep[s, T - n_pad:] = 0    # right padding (attention_mask)
+    if not causal:
+        keep[n_seq - 1, :] = 0         # all-PAD title: fully masked rows
+    scale = 1.0 / math.sqrt(dh)
+    desc = ops.attn_desc(n_seq, T, nh, dh, causal, scale, mv, dt)
+    ctx = ops.attn_fwd(desc, qkv, keep)
+    qd = qkv.double().requires_grad_(True)
+    ref = attn_ref(qd, keep, nh, causal, scale, mv)
+    assert rel(ctx, ref) < tol(dt)
+    dctx = rnd(n_seq * T, H, dt=dt, seed=9)
+    (ref * dctx.double()).sum().backward()
+    dqkv = ops.attn_bwd(desc, qkv, keep, dctx)
+    assert rel(dqkv, qd.grad) < (1e-4 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_bert_embed(dt):
+    n_seq, T, H, V = 37, 30, 768, 1000
+    ids = torch.randint(0, V, (n_seq * T,), device=DEV, dtype=torch.int32)
+    ids[::7] = 0
+    word, pos, typ = rnd(V, H, scale=0.05), rnd(64, H, scale=0.05, seed=1), rnd(2, H, scale=0.05, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    y, z, mean, rstd = ops.bert_embed_fwd(ids, word, pos, typ[0].contiguous(), gamma, beta, 1e-12, T, dt)
+    zr = word.double()[ids.long()] + pos.double()[:T].repeat(n_seq, 1) + typ.double()[0]
+    assert rel(z, zr) < tol(dt)
+    assert rel(y, torch.nn.functional.layer_norm(z.double(), (H,), gamma.double(), beta.double(), 1e-12)) < tol(dt)
+    dz = rnd(n_seq * T, H, dt=dt, seed=5)
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros(H, device=DEV)
+    ops.bert_embed_bwd_(ids, dz, dword, dpos, dtyp, 0, T)
+    ref = torch.zeros_like(word, dtype=torch.float64)
+    ref.index_add_(0, ids.long(), dz.double())
+    ref[0] = 0
+    assert rel(dword, ref) < 1e-5
+    assert rel(dpos[:T], dz.double().view(n_seq, T, H).sum(0)) < 1e-5 and (dpos[T:] == 0).all()
+    assert rel(dtyp, dz.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gather_scatter(dt):
+    V, D, R = 500, 512, 333
+    table = rnd(V, D)
+    idx = torch.randint(0, V, (R,), device=DEV, dtype=torch.int32)
+    idx[::5] = 0
+    out = ops.gather_rows(table, idx, dt)
+    assert torch.equal(out, table[idx.long()].to(dt))
+    d = rnd(R, D, dt=dt, seed=1)
+    dt_ = torch.zeros_like(table)
+    ops.scatter_add_rows_(d, idx, dt_, 0)
+    ref = torch.zeros_like(table, dtype=torch.float64)
+    ref.index_add_(0, idx.long(), d.double())
+    ref[0] = 0
+    assert rel(dt_, ref) < 1e-5
+    hid = rnd(40 * 30, 768, dt=dt, seed=2)
+    cls = torch.empty(40, 768, device=DEV, dtype=dt)
+    ops.strided_rows_copy(hid, cls, 40, 768, 30, 1)
+    assert torch.equal(cls, hid.view(40, 30, 768)[:, 0])
+    back = torch.zeros_like(hid)
+    ops.strided_rows_copy(cls, back, 40, 768, 1, 30)
+    assert torch.equal(back.view(40, 30, 768)[:, 0], cls) and (back.view(40, 30, 768)[:, 1:] == 0).all()
+
+
+def _ce_case(B, S, D, item_num, seed, n_ranks=1, rank=0):
+    rng = np.random.default_rng(seed)
+    Bt = B * n_ranks
+    ids = np.zeros((Bt, S + 1), dtype=np.int64)
+    lm = np.zeros((Bt, S), dtype=np.float32)
+    for b in range(Bt):
+        L = int(rng.integers(2, S + 2))
+        seq = rng.integers(1, item_num + 1, L)
+        if L > 3:
+            seq[-2] = seq[0]
+        ids[b, S + 1 - L:] = seq
+        lm[b, S + 1 - L:] = 1
+    pop = rng.random(item_num + 1) + 0.01
+    pop[1:] /= pop[1:].sum()
+    pop[0] = 1.0
+    return ids, lm, pop
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [(6, 5, 64, 30, 1, 0), (16, 20, 512, 200, 1, 0), (128, 20, 512, 5000, 1, 0),
+                                 (8, 20, 128, 100, 4, 2), (5, 10, 2048, 60, 2, 1)])
+def test_inbatch_ce(dt, cfg):
+    import morec_oracle as orc
+    from morec_oracle import bookkeeping as bk
+    B, S, D, item_num, n_ranks, rank = cfg
+    ids_all, lm_all, pop = _ce_case(B, S, D, item_num, seed=B + S, n_ranks=n_ranks)
+    Nc = ids_all.size
+    ids, lm = ids_all[rank * B:(rank + 1) * B], lm_all[rank * B:(rank + 1) * B]
+    E = rnd(Nc, D, dt=dt, scale=0.5)
+    P = rnd(B * S, D, dt=dt, scale=0.5, seed=1)
+    off = rank * B * (S + 1)
+    n_valid = int((lm_all != 0).sum())
+    # oracle (CPU, fp64 on the same rounded inputs)
+    Pc, Ec = P.double().cpu().requires_grad_(True), E.double().cpu().requires_grad_(True)
+    loss_ref = orc.inbatch_ce_loss(Pc, Ec, ids, lm, pop, S, pool_ids=ids_all, pool_log_mask=lm_all, col_offset=off,
+                                   n_valid_total=n_valid)
+    loss_ref.backward()
+    desc = ops.ce_desc(B, S, D, Nc, off, dt)
+    ws = ops.ce_workspace(desc, DEV)
+    t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(d)
+    row_ids, col_ids = t(ids.reshape(-1), torch.int32), t(ids_all.reshape(-1), torch.int32)
+    logpop = t(bk.log_pop(pop, ids_all), torch.float32)
+    col_valid = t(bk.column_valid(lm_all), torch.uint8)
+    row_valid = t(lm.reshape(-1) != 0, torch.uint8)
+    loss_sum, lse, row_loss = ops.inbatch_ce_fwd(desc, P, E, row_ids, col_ids, logpop, col_valid, row_valid, ws)
+    loss = loss_sum.item() / n_valid
+    assert abs(loss - loss_ref.item()) < (2e-5 if dt == torch.float32 else 2e-2) * max(1.0, abs(loss_ref.item()))
+    dP, dE = ops.inbatch_ce_bwd(desc, P, E, row_ids, col_ids, logpop, col_valid, row_valid, lse, None, 1.0 / n_valid, ws)
+    assert rel(dP.cpu(), Pc.grad) < (1e-4 if dt == torch.float32 else 3e-2)
+    assert rel(dE.cpu(), Ec.grad) < (1e-4 if dt == torch.float32 else 3e-2)
+
+
+def test_inbatch_ce_golden(golden_dir):
+    """ID-tower goldens captured from the reference: bookkeeping through the HIP kernel (exact-fp32 path)."""
+    from morec_oracle import bookkeeping as bk
+    g = np.load(os.path.join(golden_dir, "g1_g4_id_tower.npz"))
+    for case in ["a", "b", "c", "d", "e"]:
+        B, S = int(g[f"{case}.B"]), int(g[f"{case}.S"])
+        ids, lm, pop = g[f"{case}.ids"], g[f"{case}.log_mask"], g[f"{case}.pop"]
+        rows = bk.valid_rows(lm)
+        # feed P = one-hot-ish so logits are recoverable?  Instead check the loss with logits reproduced from the
+        # golden's masked logits: use E = I-like embedding is not available; the full-model golden test covers values.
+        # Here: masked-cell pattern via gradient support -- dlogit == 0 exactly on masked cells.
+        D = 128
+        Nc = ids.size
+        E = rnd(Nc, D, scale=0.3)
+        P = rnd(B * S, D, scale=0.3, seed=1)
+        desc = ops.ce_desc(B, S, D, Nc, 0, torch.float32)
+        ws = ops.ce_workspace(desc, DEV)
+        t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(d)
+        args = (t(ids.reshape(-1), torch.int32), t(ids.reshape(-1), torch.int32), t(bk.log_pop(pop, ids), torch.float32),
+                t(bk.column_valid(lm), torch.uint8), t(lm.reshape(-1) != 0, torch.uint8))
+        loss_sum, lse, row_loss = ops.inbatch_ce_fwd(desc, P, E, *args, ws)
+        ops.inbatch_ce_bwd(desc, P, E, *args, lse, None, 1.0, ws)
+        torch.cuda.synchronize()
+        ldc = ops.pad8(Nc)
+        dl = ws[: B * S * ldc * 4].view(torch.float32).view(B * S, ldc)[:, :Nc].cpu().numpy()
+        masked = g[f"{case}.masked_valid"]
+        assert np.array_equal((dl[rows] == 0.0), masked), case   # zero gradient exactly on the reference's -1e4 cells
+        lab = g[f"{case}.labels_valid"]
+        assert (dl[rows, lab] < 0).all()
+        inv = np.setdiff1d(np.arange(B * S), rows)
+        assert (dl[inv] == 0).all()
+
+
+def test_adamw():
+    import morec_oracle as orc
+    n = 4096 * 3 + 8
+    p, g = rnd(n), rnd(n, seed=1, scale=1e-2)
+    m, v = rnd(n, seed=2, scale=1e-3), rnd(n, seed=3, scale=1e-3).abs()
+    pc, gc, mc, vc = (x.cpu().clone() for x in (p, g, m, v))
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    ops.adamw_(p, g, m, v, shadow, 1e-4, 0.9, 0.999, 1e-8, 0.01, 3)
+    orc.adamw_step(pc, gc, mc, vc, 3, 1e-4, 0.01)
+    assert (p.cpu() - pc).abs().max() < 1e-7 and rel(m.cpu(), mc) < 1e-6 and rel(v.cpu(), vc) < 1e-6
+    assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+def test_eval_rank():
+    import morec_oracle as orc
+    U, I, D, Hmax = 300, 1000, 64, 12
+    prec, emb = rnd(U, D), rnd(I + 1, D, seed=1)
+    rng = np.random.default_rng(0)
+    hist = np.full((U, Hmax), -1, dtype=np.int32)
+    histories, targets = [], np.zeros(U, dtype=np.int64)
+    for u in range(U):
+        L = int(rng.integers(1, Hmax + 1))
+        h = rng.integers(1, I + 1, L)
+        if L > 2:
+            h[1] = h[0]
+        hist[u, :L] = h
+        histories.append(h)
+        targets[u] = int(rng.integers(1, I + 1)) if u % 17 else int(h[0])  # some targets sit in the history
+    rank = ops.eval_rank(prec, emb, torch.from_numpy(hist).to(DEV), torch.from_numpy(targets.astype(np.int32)).to(DEV))
+    scores = (prec.double() @ emb.double().t()).float().cpu().numpy()
+    ref = orc.eval_ranks(scores, histories, targets)
+    ok = targets != np.array([h[0] for h in histories])
+    assert np.array_equal(rank.cpu().numpy()[ok], ref[ok])
+    assert (rank.cpu().numpy()[~ok] > 10).all()
