@@ -42,6 +42,7 @@ _SIGS = {
     "morec_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P]),
     "morec_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
                                       C.c_int, _P]),

@@ -235,3 +235,36 @@ extern "C" int morec_colsum(const void* in, float* out, int M, int N, int ld, in
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
+
+// out = dy * act'(pre)  (backward through the GELU of Text_Encoder, T/model/encoders.py:70, where the
+// activation follows the LAST projection and its derivative cannot ride on a GEMM epilogue)
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, size_t n4,
+                               int act) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float d[4], u[4];
+        io<T>::load4(dy + i * 4, d);
+        io<T>::load4(pre + i * 4, u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (act == MOREC_ACT_GELU) ? d[k] * dgelu_f(u[k]) : (u[k] > 0.f ? d[k] : 0.f);
+        io<T>::store4(out + i * 4, d);
+    }
+}
+
+extern "C" int morec_act_bwd(const void* dy, const void* pre, void* out, size_t n, int act, int dtype, void* stream) {
+    if (!dy || !pre || !out) return MOREC_E_ARG;
+    if (n == 0) return MOREC_OK;
+    if (n % 4) return MOREC_E_ALIGN;
+    if (act != MOREC_ACT_GELU && act != MOREC_ACT_RELU) return MOREC_E_ARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)dy, (const float*)pre, (float*)out, n4, act);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16*)dy, (const bf16*)pre, (bf16*)out, n4, act);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

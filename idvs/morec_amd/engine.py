@@ -1,0 +1,295 @@
+"""Host-side orchestration of the HIP kernels: explicit forward AND hand-derived backward for the three
+stages of ``Model.forward`` (``T/model/model.py:31-69``) -- item encoder, SASRec user encoder, in-batch CE.
+
+Nothing here does arithmetic in PyTorch: tensors are device buffers handed to ``ops`` (C-ABI launchers).
+Both the ``torch.autograd.Function`` wrappers in ``functional.py`` (drop-in ``Model``) and the fused
+``TrainStep`` driver call these functions.
+
+Layout: activations are row-major ``[tokens, features]`` in the compute dtype (fp32 = exact-fp32 MFMA
+parity mode, bf16 = fast mode); parameters are fp32 masters; every Linear weight is "prepared" once per
+step into the compute dtype in both orientations (``W`` for ``Y = X W^T`` and ``W^T`` for ``dX = dY W``).
+Weight gradients ``dW = dY^T X`` run as split-K NT GEMMs over transposed activations with fp32 atomics.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+
+
+@dataclass
+class LayerCfg:
+    """One post-LN transformer layer (``T/model/modules.py:66-75`` / HF ``BertLayer``)."""
+    H: int
+    heads: int
+    T: int               # tokens per sequence (S for SASRec, num_words_title for BERT)
+    act: int             # ACT_RELU (SASRec FFN) | ACT_GELU (BERT)
+    eps: float
+    causal: bool
+    mask_value: float    # additive value on masked keys: -1e9 (T/model/encoders.py:27) | finfo.min (HF eager)
+
+
+@dataclass
+class PreparedLinear:
+    w: torch.Tensor      # [out, in]  compute dtype
+    wt: torch.Tensor     # [in, pad8(out)] compute dtype (zero padded)
+
+
+def prepare_linear(weight: torch.Tensor, dtype: torch.dtype) -> PreparedLinear:
+    w = weight if weight.dtype == dtype else ops.cast(weight.contiguous(), dtype)
+    wt = ops.transpose(weight.contiguous(), out_dtype=dtype)
+    return PreparedLinear(w.contiguous(), wt)
+
+
+def _splitk(tiles: int, K: int) -> int:
+    return max(1, min(64, (1024 + tiles - 1) // tiles, K // 512 if K >= 1024 else 1))
+
+
+def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
+    """dw[N, K] += dy[M, N]^T @ x[M, K]  (fp32 atomics, split over M)."""
+    dyt = ops.transpose(dy) if dyt is None else dyt
+    xt = ops.transpose(x) if xt is None else xt
+    N, K, Mp = dyt.shape[0], xt.shape[0], dyt.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    ops.gemm_nt(dyt, xt, out=dw, accumulate=2, split_k=_splitk(tiles, Mp))
+    return dyt, xt
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one transformer layer
+# ---------------------------------------------------------------------------------------------------------
+def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool):
+    """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b."""
+    dh = cfg.H // cfg.heads
+    desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype)
+    qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
+    ctx = ops.attn_fwd(desc, qkv, key_keep)
+    a = ops.gemm_nt(ctx, w["o"].w)
+    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True)
+    u = torch.empty((x0.shape[0], w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
+    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u)
+    f = ops.gemm_nt(g, w["f2"].w)
+    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True)
+    saved = (desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep) if need_grad else None
+    return x2, saved
+
+
+def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
+    """g: fp32 gradient buffers (accumulated into): qkv [3H,H], bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b
+    (bias entries may be None).  Returns (da, db) with dx0 = da + db."""
+    desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep = saved
+    dz2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"])
+    if g.get("b2") is not None:
+        ops.colsum_(dz2, g["b2"])
+    linear_wgrad_(dz2, gact, g["f2"])
+    du = ops.gemm_nt(dz2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dz2.shape[1], N=u.shape[1])
+    if g.get("b1") is not None:
+        ops.colsum_(du, g["b1"])
+    linear_wgrad_(du, x1, g["f1"])
+    dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=x1.shape[1])
+    dz1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"])
+    if g.get("bo") is not None:
+        ops.colsum_(dz1, g["bo"])
+    linear_wgrad_(dz1, ctx, g["o"])
+    dctx = ops.gemm_nt(dz1, w["o"].wt, K=dz1.shape[1], N=ctx.shape[1])
+    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
+    if g.get("bqkv") is not None:
+        ops.colsum_(dqkv, g["bqkv"])
+    linear_wgrad_(dqkv, x0, g["qkv"])
+    dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=x0.shape[1])
+    return dx0, dz1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# SASRec user encoder (T/model/encoders.py:7-28, T/model/modules.py:78-96)
+# ---------------------------------------------------------------------------------------------------------
+UE = "user_encoder.transformer_encoder."
+
+
+def sasrec_layer_names(l: int, prefix: str = UE):
+    a = prefix + f"transformer_blocks.{l}.multi_head_attention."
+    f = prefix + f"transformer_blocks.{l}.feed_forward."
+    return a, f
+
+
+def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE):
+    layers = []
+    for l in range(n_layers):
+        a, f = sasrec_layer_names(l, prefix)
+        wqkv = torch.cat([p[a + "w_Q.weight"], p[a + "w_K.weight"], p[a + "w_V.weight"]], 0)
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype), bqkv=None, o=prepare_linear(p[a + "fc.weight"], dtype), bo=None,
+                           ln1_g=p[a + "layer_norm.weight"], ln1_b=p[a + "layer_norm.bias"],
+                           f1=prepare_linear(p[f + "w_1.weight"], dtype), b1=p[f + "w_1.bias"],
+                           f2=prepare_linear(p[f + "w_2.weight"], dtype), b2=p[f + "w_2.bias"],
+                           ln2_g=p[f + "layer_norm.weight"], ln2_b=p[f + "layer_norm.bias"]))
+    return layers
+
+
+def sasrec_forward(p: dict, prep, x_in: torch.Tensor, log_mask: torch.Tensor, heads: int, need_grad: bool,
+                   prefix: str = UE):
+    """x_in [B, S, D] compute dtype (contiguous), log_mask float [B, S] -> [B*S, D]."""
+    B, S, D = x_in.shape
+    cfg = LayerCfg(H=D, heads=heads, T=S, act=ACT_RELU, eps=1e-6, causal=True, mask_value=-1e9)
+    keep = log_mask.to(torch.float32).contiguous()
+    x, z0, mean0, rstd0 = ops.layernorm_fwd(x_in.view(B * S, D), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"],
+                                            1e-6, pos=p[prefix + "position_embedding.weight"], pos_period=S)
+    saved_layers = []
+    for w in prep:
+        x, sv = layer_forward(cfg, w, x, keep, B, need_grad)
+        saved_layers.append(sv)
+    saved = (cfg, z0, mean0, rstd0, saved_layers, S) if need_grad else None
+    return x, saved
+
+
+def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefix: str = UE):
+    """grads: name -> fp32 buffer (accumulated).  Returns d(x_in) [B*S, D]."""
+    cfg, z0, mean0, rstd0, saved_layers, S = saved
+    da, db = dout, None
+    for l in reversed(range(len(prep))):
+        a, f = sasrec_layer_names(l, prefix)
+        D = cfg.H
+        dqkv = grads.get(a + "qkv_fused")   # an arena may provide the fused [3D, D] block that w_Q/w_K/w_V alias
+        fused = dqkv is not None
+        if not fused:
+            dqkv = torch.zeros((3 * D, D), device=dout.device, dtype=torch.float32)
+        g = dict(qkv=dqkv, bqkv=None, o=grads[a + "fc.weight"], bo=None, ln1_g=grads[a + "layer_norm.weight"],
+                 ln1_b=grads[a + "layer_norm.bias"], f1=grads[f + "w_1.weight"], b1=grads[f + "w_1.bias"],
+                 f2=grads[f + "w_2.weight"], b2=grads[f + "w_2.bias"], ln2_g=grads[f + "layer_norm.weight"],
+                 ln2_b=grads[f + "layer_norm.bias"])
+        da, db = layer_backward(cfg, prep[l], saved_layers[l], da, db, g)
+        if not fused:   # hand the three row blocks out as the parameters' gradients (views, no arithmetic)
+            grads[a + "w_Q.weight"], grads[a + "w_K.weight"], grads[a + "w_V.weight"] = dqkv[:D], dqkv[D:2 * D], dqkv[2 * D:]
+    dz0 = ops.layernorm_bwd(da, db, z0, mean0, rstd0, p[prefix + "layer_norm.weight"], grads[prefix + "layer_norm.weight"],
+                            grads[prefix + "layer_norm.bias"])
+    ops.pos_grad_(dz0, grads[prefix + "position_embedding.weight"], S)
+    return dz0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BERT text encoder (T/model/encoders.py:53-70 + HF BertModel)
+# ---------------------------------------------------------------------------------------------------------
+TE = "bert_encoder.text_encoders.title."
+
+
+def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE):
+    bm = prefix + "bert_model."
+    layers = []
+    for l in range(n_layers):
+        L = bm + f"encoder.layer.{l}."
+        wqkv = torch.cat([p[L + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
+        bqkv = torch.cat([p[L + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype), bqkv=bqkv,
+                           o=prepare_linear(p[L + "attention.output.dense.weight"], dtype), bo=p[L + "attention.output.dense.bias"],
+                           ln1_g=p[L + "attention.output.LayerNorm.weight"], ln1_b=p[L + "attention.output.LayerNorm.bias"],
+                           f1=prepare_linear(p[L + "intermediate.dense.weight"], dtype), b1=p[L + "intermediate.dense.bias"],
+                           f2=prepare_linear(p[L + "output.dense.weight"], dtype), b2=p[L + "output.dense.bias"],
+                           ln2_g=p[L + "output.LayerNorm.weight"], ln2_b=p[L + "output.LayerNorm.bias"]))
+    return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype))
+
+
+def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
+                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE):
+    """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D]."""
+    bm = prefix + "bert_model."
+    Nc, T2 = text.shape
+    T = T2 // 2
+    ids32 = text[:, :T].to(torch.int32).contiguous().view(-1)
+    keep = text[:, T:].to(torch.float32).contiguous()
+    H = p[bm + "embeddings.word_embeddings.weight"].shape[1]
+    cfg = LayerCfg(H=H, heads=heads, T=T, act=ACT_GELU, eps=eps, causal=False, mask_value=mask_value)
+    type0 = p[bm + "embeddings.token_type_embeddings.weight"][0].contiguous()
+    x, z_e, mean_e, rstd_e = ops.bert_embed_fwd(ids32, p[bm + "embeddings.word_embeddings.weight"],
+                                                p[bm + "embeddings.position_embeddings.weight"], type0,
+                                                p[bm + "embeddings.LayerNorm.weight"], p[bm + "embeddings.LayerNorm.bias"],
+                                                eps, T, dtype)
+    saved_layers = []
+    for w in prep["layers"]:
+        x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad)
+        saved_layers.append(sv)
+    cls = torch.empty((Nc, H), device=x.device, dtype=dtype)
+    ops.strided_rows_copy(x, cls, Nc, H, T, 1)
+    D = prep["fc"].w.shape[0]
+    pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
+    item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H) if need_grad else None
+    return item, saved
+
+
+def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = TE, pad_id: int = 0):
+    bm = prefix + "bert_model."
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H = saved
+    dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
+    ops.colsum_(dv, grads[prefix + "fc.bias"])
+    linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
+    dcls = ops.gemm_nt(dv, prep["fc"].wt, K=dv.shape[1], N=H)
+    da = torch.zeros((Nc * T, H), device=dcls.device, dtype=dcls.dtype)
+    ops.strided_rows_copy(dcls, da, Nc, H, 1, T)
+    db = None
+    for l in reversed(range(len(prep["layers"]))):
+        L = bm + f"encoder.layer.{l}."
+        dqkv, dbqkv = grads.get(L + "qkv_fused.weight"), grads.get(L + "qkv_fused.bias")
+        fused = dqkv is not None
+        if not fused:
+            dqkv = torch.zeros((3 * H, H), device=da.device, dtype=torch.float32)
+            dbqkv = torch.zeros(3 * H, device=da.device, dtype=torch.float32)
+        g = dict(qkv=dqkv, bqkv=dbqkv, o=grads[L + "attention.output.dense.weight"], bo=grads[L + "attention.output.dense.bias"],
+                 ln1_g=grads[L + "attention.output.LayerNorm.weight"], ln1_b=grads[L + "attention.output.LayerNorm.bias"],
+                 f1=grads[L + "intermediate.dense.weight"], b1=grads[L + "intermediate.dense.bias"],
+                 f2=grads[L + "output.dense.weight"], b2=grads[L + "output.dense.bias"],
+                 ln2_g=grads[L + "output.LayerNorm.weight"], ln2_b=grads[L + "output.LayerNorm.bias"])
+        da, db = layer_backward(cfg, prep["layers"][l], saved_layers[l], da, db, g)
+        if not fused:
+            for i, n in enumerate(("query", "key", "value")):
+                grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
+                grads[L + f"attention.self.{n}.bias"] = dbqkv[i * H:(i + 1) * H]
+    dz_e = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
+                             grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"])
+    ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],
+                        grads[bm + "embeddings.position_embeddings.weight"],
+                        grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# in-batch debiased CE (T/model/model.py:32-33,45-67)
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class CeInputs:
+    row_ids: torch.Tensor      # int32 [B*(S+1)]  this rank's slot ids
+    col_ids: torch.Tensor      # int32 [Nc]       pool slot ids
+    col_logpop: torch.Tensor   # f32   [Nc]
+    col_valid: torch.Tensor    # u8    [Nc]
+    row_valid: torch.Tensor    # u8    [B*S]
+    B: int
+    S: int
+    col_offset: int
+
+
+def ce_inputs_local(sample_items_id: torch.Tensor, log_mask: torch.Tensor, log_pop_table: torch.Tensor) -> CeInputs:
+    """Index bookkeeping for one rank, all on device (no Python loops): column validity
+    ``cat(log_mask, 1)`` (model.py:51-52), row validity (model.py:65), log-pop gather (model.py:33)."""
+    B, S = log_mask.shape
+    ids = sample_items_id.view(-1)
+    ids32 = ids.to(torch.int32).contiguous()
+    ones = torch.ones((B, 1), device=log_mask.device, dtype=log_mask.dtype)
+    col_valid = (torch.cat((log_mask, ones), 1).view(-1) != 0).to(torch.uint8).contiguous()
+    row_valid = (log_mask.reshape(-1) != 0).to(torch.uint8).contiguous()
+    logpop = log_pop_table[ids].contiguous()
+    return CeInputs(ids32, ids32, logpop, col_valid, row_valid, B, S, 0)
+
+
+def ce_forward(ci: CeInputs, P: torch.Tensor, E: torch.Tensor):
+    """P [B*S, D], E [Nc, D] (compute dtype).  Returns (loss_sum fp32[1] on device, saved)."""
+    desc = ops.ce_desc(ci.B, ci.S, P.shape[1], E.shape[0], ci.col_offset, P.dtype)
+    ws = ops.ce_workspace(desc, P.device)
+    loss_sum, lse, _ = ops.inbatch_ce_fwd(desc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, ws)
+    return loss_sum, (desc, ws, lse)
+
+
+def ce_backward(ci: CeInputs, P, E, saved, gscale_dev, gscale: float):
+    desc, ws, lse = saved
+    return ops.inbatch_ce_bwd(desc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, lse,
+                              gscale_dev, gscale, ws)

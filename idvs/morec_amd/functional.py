@@ -1,0 +1,141 @@
+"""``torch.autograd.Function`` shells around ``engine``: they make the HIP forward/backward a node of
+PyTorch's autograd graph so that the reference driver's ``scaler.scale(loss).backward()``, ``DDP`` gradient
+hooks and ``optim.AdamW`` (``T/run.py:243-247``) keep working unchanged on the drop-in ``Model``.
+Gradients are computed by the hand-written backward kernels, never by autograd tracing of torch ops.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+
+
+def _zeros_like_params(names, params, skip=()):
+    return {n: torch.zeros_like(p, dtype=torch.float32) for n, p in zip(names, params) if n not in skip}
+
+
+class SasrecFn(torch.autograd.Function):
+    """``User_Encoder.forward`` (``T/model/encoders.py:23-28``)."""
+
+    @staticmethod
+    def forward(ctx, x_in, log_mask, cfg, *params):
+        names, heads, n_layers, dtype, prefix = cfg
+        p = dict(zip(names, params))
+        need = any(ctx.needs_input_grad)
+        x = x_in.contiguous()
+        if x.dtype != dtype:
+            x = ops.cast(x, dtype)
+        prep = engine.sasrec_prepare(p, n_layers, dtype, prefix)
+        out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix)
+        ctx.stuff = (p, prep, saved, names, prefix, x_in.dtype, tuple(x_in.shape))
+        return out.view(x_in.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, prep, saved, names, prefix, in_dtype, in_shape = ctx.stuff
+        ctx.stuff = None
+        qkv = {prefix + f"transformer_blocks.{l}.multi_head_attention.{w}.weight" for l in range(len(prep))
+               for w in ("w_Q", "w_K", "w_V")}
+        grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
+        d = dout.contiguous().view(-1, in_shape[-1])
+        dx = engine.sasrec_backward(p, prep, saved, d, grads, prefix)
+        if dx.dtype != in_dtype:
+            dx = ops.cast(dx, in_dtype)
+        return (dx.view(in_shape), None, None) + tuple(grads[n] for n in names)
+
+
+class BertEncoderFn(torch.autograd.Function):
+    """``Text_Encoder.forward`` (``T/model/encoders.py:63-70``) over HF ``BertModel`` arithmetic."""
+
+    @staticmethod
+    def forward(ctx, text, cfg, *params):
+        names, heads, n_layers, dtype, prefix, eps, mask_value = cfg
+        p = dict(zip(names, params))
+        need = any(ctx.needs_input_grad)
+        prep = engine.bert_prepare(p, n_layers, dtype, prefix)
+        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix)
+        ctx.stuff = (p, prep, saved, names, prefix)
+        ctx.needs = ctx.needs_input_grad
+        return item
+
+    @staticmethod
+    def backward(ctx, d_item):
+        p, prep, saved, names, prefix = ctx.stuff
+        ctx.stuff = None
+        bm = prefix + "bert_model."
+        qkv = {bm + f"encoder.layer.{l}.attention.self.{n}.{k}" for l in range(len(prep["layers"]))
+               for n in ("query", "key", "value") for k in ("weight", "bias")}
+        grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
+        engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+        needs = ctx.needs[2:]
+        return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
+
+
+class IdEmbeddingFn(torch.autograd.Function):
+    """``nn.Embedding(item_num + 1, D, padding_idx=0)`` lookup (``T/model/model.py:27,37``)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, dtype):
+        idx = ids.reshape(-1).to(torch.int32).contiguous()
+        out = ops.gather_rows(weight, idx, dtype)
+        ctx.save_for_backward(idx)
+        ctx.shape = weight.shape
+        return out.view(tuple(ids.shape) + (weight.shape[1],))
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, device=dout.device, dtype=torch.float32)
+        ops.scatter_add_rows_(dout.contiguous().view(-1, ctx.shape[1]), idx, dw, 0)
+        return None, dw, None
+
+
+def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def _reduce_scatter_sum(t: torch.Tensor, world: int, rank: int) -> torch.Tensor:
+    n = t.shape[0] // world
+    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all-reduce and keep our shard (CPU tests only)
+        dist.all_reduce(t)
+        return t[rank * n:(rank + 1) * n].contiguous()
+    out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    dist.reduce_scatter_tensor(out, t.contiguous())
+    return out
+
+
+class InBatchCEFn(torch.autograd.Function):
+    """In-batch debiased CE (``T/model/model.py:32-33,45-67``).  With ``pool=True`` under an initialised
+    process group the negatives are pooled over ranks: all-gather of the encoded item
+    vectors + slot ids + log-pop + validity forward, reduce-scatter(sum) of dE backward, valid-row count
+    all-reduced so that N ranks x B equals the single-process loss at batch N*B.  ``loss_mult`` rescales the
+    local share (``world_size`` when a gradient-AVERAGING wrapper such as DDP follows, 1 for sum-reduce)."""
+
+    @staticmethod
+    def forward(ctx, P, E, ci, pool, loss_mult, backend):
+        P, E = P.contiguous(), E.contiguous()
+        world = dist.get_world_size() if (pool and dist.is_available() and dist.is_initialized()) else 1
+        n_valid = ci.row_valid.sum(dtype=torch.float32)
+        if world > 1:
+            rank = dist.get_rank()
+            Epool = _all_gather_cat(E, world)
+            ci = engine.CeInputs(ci.row_ids, _all_gather_cat(ci.col_ids, world), _all_gather_cat(ci.col_logpop, world),
+                                 _all_gather_cat(ci.col_valid, world), ci.row_valid, ci.B, ci.S, rank * E.shape[0])
+            dist.all_reduce(n_valid)
+        else:
+            rank, Epool = 0, E
+        loss_sum, saved = backend.ce_forward(ci, P, Epool)
+        ctx.stuff = (ci, P, Epool, saved, world, rank, n_valid, loss_mult, backend)
+        return (loss_sum[0] * loss_mult / n_valid).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ci, P, Epool, saved, world, rank, n_valid, loss_mult, backend = ctx.stuff
+        ctx.stuff = None
+        g = (dloss.to(torch.float32) * loss_mult / n_valid).reshape(1).contiguous()
+        dP, dEpool = backend.ce_backward(ci, P, Epool, saved, g, 1.0)
+        dE = _reduce_scatter_sum(dEpool, world, rank) if world > 1 else dEpool
+        return dP, dE, None, None, None, None

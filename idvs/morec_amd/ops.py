@@ -82,6 +82,13 @@ def cast(x, out_dtype, out=None):
     return out
 
 
+def act_bwd(dy, pre, act):
+    out = torch.empty_like(dy)
+    check(_lib.lib().morec_act_bwd(_p(_dev(dy)), _p(_dev(pre)), _p(out), dy.numel(), act, code(dy.dtype), _stream()),
+          "morec_act_bwd")
+    return out
+
+
 def colsum_(x, out, M=None, N=None, ld=None):
     """out[N] += column sums of x[M, N] (fp32 atomics)."""
     _dev(x)

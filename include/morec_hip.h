@@ -72,6 +72,8 @@ int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_o
                     void* stream);
 /* elementwise convert n elements */
 int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream);
+/* out = dy * act'(pre), elementwise (act = MOREC_ACT_GELU | MOREC_ACT_RELU); T/model/encoders.py:70 backward */
+int morec_act_bwd(const void* dy, const void* pre, void* out, size_t n, int act, int dtype, void* stream);
 /* out[n] = sum_m in[m, n]  (bias gradients), atomically accumulated into fp32 out */
 int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream);
 

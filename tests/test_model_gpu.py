@@ -1,0 +1,217 @@
+"""Model-level parity on a real MI355X: the drop-in ``Model`` (HIP kernels through the C-ABI) against the
+golden vectors captured from the imported reference and against the CPU oracle on seeded inputs.
+Tolerances: exact-fp32 path -- loss within 1e-3 (north_star), in practice < 5e-5; gradients relative 2e-4.
+bf16 path -- loss within 3e-2 relative, gradients 8e-2 relative to max-abs (reported, looser)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from idvs.morec_amd.model import BertShape, HipBertModel, Model, User_Encoder  # noqa: E402
+from idvs.morec_amd.utils.detgen import det_normal, det_param  # noqa: E402
+
+DEV = "cuda"
+
+
+def make_args(**kw):
+    d = dict(max_seq_len=20, embedding_dim=64, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+             num_words_title=30, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+             bert_model_load="bert_micro", word_embedding_dim=64, compute_dtype="fp32")
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def load_det(module):
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            v.copy_(torch.from_numpy(det_param(k, tuple(v.shape))))
+    return module
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_g3_sasrec_golden(golden_dir, case, dtype):
+    gd = g(golden_dir, "g3_sasrec.npz")
+    B, S, D, heads, blocks = (int(v) for v in gd[f"{case}.cfg"])
+    cd = torch.float32 if dtype == "fp32" else torch.bfloat16
+    enc = load_det(User_Encoder(10, S, D, heads, 0.0, blocks, compute_dtype=cd)).to(DEV)
+    x = torch.from_numpy(det_normal(f"g3{case}.x", (B, S, D), std=0.5)).to(DEV).requires_grad_(True)
+    R = torch.from_numpy(det_normal(f"g3{case}.R", (B, S, D), std=1.0)).to(DEV)
+    y = enc(x, torch.from_numpy(gd[f"{case}.log_mask"]).to(DEV), DEV)
+    tol = 2e-5 if dtype == "fp32" else 6e-2
+    assert relerr(y.detach().cpu().numpy(), gd[f"{case}.y"]) < tol
+    (y * R).sum().backward()
+    gt = 2e-4 if dtype == "fp32" else 8e-2
+    assert relerr(x.grad.cpu().numpy(), gd[f"{case}.dx"]) < gt
+    for k, p in enc.named_parameters():
+        assert relerr(p.grad.cpu().numpy(), gd[f"{case}.grad.{k}"]) < gt, k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["a", "b", "c", "d", "e"])
+def test_g4_id_tower_golden(golden_dir, case, dtype):
+    gd = g(golden_dir, "g1_g4_id_tower.npz")
+    B, S, item_num, D = (int(gd[f"{case}.{k}"]) for k in ("B", "S", "item_num", "D"))
+    m = load_det(Model(make_args(max_seq_len=S, embedding_dim=D, compute_dtype=dtype), item_num, False, None,
+                       gd[f"{case}.pop"])).to(DEV)
+    ids = torch.from_numpy(gd[f"{case}.ids"]).to(DEV).view(-1)
+    loss = m(ids, ids.clone(), torch.from_numpy(gd[f"{case}.log_mask"]).to(DEV), DEV)
+    ref = float(gd[f"{case}.loss"])
+    assert abs(loss.item() - ref) < (5e-5 if dtype == "fp32" else 3e-2) * max(1.0, abs(ref))
+    loss.backward()
+    gt = 3e-4 if dtype == "fp32" else 1e-1
+    if case != "c":   # case c (B = 1): every cell masked but the positive -> all gradients are exactly zero
+        assert relerr(m.id_embedding.weight.grad.cpu().numpy(), gd[f"{case}.grad_id_embedding"]) < gt
+        named = dict(m.named_parameters())
+        for k in [k for k in gd.files if k.startswith(f"{case}.grad.")]:
+            assert relerr(named[k[len(f"{case}.grad."):]].grad.cpu().numpy(), gd[k]) < gt, k
+    else:
+        assert float(m.id_embedding.weight.grad.abs().max()) < 1e-6
+
+
+def _modal(golden, prefix, bert_name, dtype):
+    S, D, T, item_num, B = (int(v) for v in golden[prefix + "cfg"])
+    shape = BertShape.named(bert_name)
+    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=shape.hidden_size, compute_dtype=dtype,
+                     bert_model_load="bert_" + bert_name)
+    m = load_det(Model(args, item_num, True, HipBertModel(shape), golden[prefix + "pop"])).to(DEV)
+    ids = torch.from_numpy(golden[prefix + "ids"]).to(DEV)
+    items = torch.from_numpy(golden[prefix + "content"][golden[prefix + "ids"].reshape(-1)]).to(DEV)
+    lm = torch.from_numpy(golden[prefix + "log_mask"]).to(DEV)
+    return m, ids.view(-1), items, lm, (S, D, T, item_num, B)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_g5_g8_bert_micro_golden(golden_dir, dtype):
+    gd = g(golden_dir, "g5_g8_bert_micro.npz")
+    m, ids, items, lm, (S, D, T, item_num, B) = _modal(gd, "", "micro", dtype)
+    f32 = dtype == "fp32"
+    vec = m.bert_encoder(items)
+    assert vec.dtype == torch.float32
+    assert relerr(vec.detach().cpu().numpy(), gd["item_vecs"]) < (2e-5 if f32 else 5e-2)
+    R = torch.from_numpy(det_normal("g5.R", (B * (S + 1), D))).to(DEV)
+    (vec * R).sum().backward()
+    named = dict(m.named_parameters())
+    gt = 3e-4 if f32 else 1e-1
+    for k in [k for k in gd.files if k.startswith("enc_grad.")]:
+        assert relerr(named[k[len("enc_grad."):]].grad.cpu().numpy(), gd[k]) < gt, k
+    for k in [k for k in gd.files if k.startswith("enc_grad_norm.")]:
+        name = k[len("enc_grad_norm."):]
+        if "pooler" in name:
+            continue
+        got = named[name].grad.double().norm().item()
+        assert abs(got - float(gd[k])) <= (1e-3 if f32 else 1e-1) * float(gd[k]) + 1e-4, name
+    m.zero_grad()
+    loss = m(ids, items, lm, DEV)
+    assert abs(loss.item() - float(gd["loss"])) < (5e-5 if f32 else 3e-2)
+    loss.backward()
+    for k in [k for k in gd.files if k.startswith("grad_norm.")]:
+        name = k[len("grad_norm."):]
+        if "pooler" in name:
+            continue
+        got = named[name].grad.double().norm().item()
+        assert abs(got - float(gd[k])) <= (1e-3 if f32 else 1e-1) * float(gd[k]) + 1e-4, name
+    if not f32:
+        return
+    # g8: one optimisation step with the reference's two AdamW groups (T/run.py:150-162), torch's optimizer
+    # driving OUR gradients -- the drop-in path of run.py
+    pool = [k for k in named if "pooler" in k]
+    bert_p = [p for k, p in named.items() if "bert_model" in k and k not in pool]
+    rec_p = [p for k, p in named.items() if "bert_model" not in k]
+    before = {k: p.detach().clone() for k, p in named.items()}
+    opt = torch.optim.AdamW([{"params": bert_p, "lr": 5e-5, "weight_decay": 0.01},
+                             {"params": rec_p, "lr": 1e-4, "weight_decay": 0.01}])
+    opt.step()
+    for k in [k for k in gd.files if k.startswith("step_delta.")]:
+        name = k[len("step_delta."):]
+        big = (named[name].grad.abs() > 1e-5).cpu().numpy()
+        delta = (named[name].detach() - before[name]).cpu().numpy()
+        assert np.abs(delta - gd[k])[big].max() < 5e-7, name
+    opt.zero_grad()
+    loss2 = m(ids, items, lm, DEV)
+    assert abs(loss2.item() - float(gd["loss_after_step"])) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_g6_full_size_golden(golden_dir, name, dtype):
+    """BERT-tiny / BERT-base (pretrained_models/bert_base_uncased/config.json shapes), D = 512, S = 20, T = 30."""
+    gd = g(golden_dir, "g6_full_scalars.npz")
+    m, ids, items, lm, _ = _modal(gd, name + ".", name, dtype)
+    f32 = dtype == "fp32"
+    with torch.no_grad():
+        vec = m.bert_encoder(items)
+    real = (gd[f"{name}.ids"].reshape(-1) != 0)
+    assert relerr(vec[:, :8].cpu().numpy()[real], gd[f"{name}.item_vec_probe"][real]) < (5e-5 if f32 else 8e-2)
+    loss = m(ids, items, lm, DEV)
+    ref = float(gd[f"{name}.loss"])
+    print(f"g6 {name} {dtype}: loss {loss.item():.6f} ref {ref:.6f}")
+    assert abs(loss.item() - ref) < (1e-4 if f32 else 5e-2)
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in [k for k in gd.files if k.startswith(f"{name}.grad_norm.")]:
+        pn = k[len(f"{name}.grad_norm."):]
+        if "pooler" in pn:
+            continue
+        got = named[pn].grad.double().norm().item()
+        err = abs(got - float(gd[k])) / (float(gd[k]) + 1e-6)
+        worst = max(worst, err)
+        assert err < (2e-3 if f32 else 2e-1), (pn, got, float(gd[k]))
+    print(f"g6 {name} {dtype}: worst grad-norm rel err {worst:.2e}")
+
+
+def test_oracle_midsize_all_grads():
+    """Every parameter gradient of a mid-size modal model against the CPU oracle (autograd over the restatement)."""
+    import morec_oracle as orc
+    S, D, T, item_num, B = 10, 128, 30, 300, 12
+    shape = BertShape(vocab_size=2000, hidden_size=128, num_hidden_layers=3, num_attention_heads=4,
+                      intermediate_size=512, max_position_embeddings=64)
+    rng = np.random.default_rng(7)
+    pop = rng.random(item_num + 1) + 0.05
+    pop[1:] /= pop[1:].sum()
+    pop[0] = 1
+    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=128, compute_dtype="fp32")
+    m = load_det(Model(args, item_num, True, HipBertModel(shape), pop)).to(DEV)
+    content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
+    for i in range(1, item_num + 1):
+        L = int(rng.integers(3, T + 1))
+        content[i, :L] = rng.integers(1, 2000, L)
+        content[i, T:T + L] = 1
+    ids = np.zeros((B, S + 1), dtype=np.int64)
+    lm = np.zeros((B, S), dtype=np.float32)
+    for b in range(B):
+        L = int(rng.integers(2, S + 2))
+        ids[b, S + 1 - L:] = rng.integers(1, item_num + 1, L)
+        lm[b, S + 1 - L:] = 1
+    items = content[ids.reshape(-1)]
+    loss = m(torch.from_numpy(ids).to(DEV).view(-1), torch.from_numpy(items).to(DEV), torch.from_numpy(lm).to(DEV), DEV)
+    loss.backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = orc.model_forward(p, torch.from_numpy(ids).view(-1), torch.from_numpy(items), torch.from_numpy(lm), pop,
+                            max_seq_len=S, embedding_dim=D, n_heads=2, use_modal=True, bert_heads=4)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 5e-5
+    for k, v in m.named_parameters():
+        if "pooler" in k:
+            continue
+        gref = p[k].grad
+        scale = gref.abs().max().item()
+        if scale < 1e-7:   # e.g. key biases: mathematically zero gradient
+            assert v.grad.abs().max().item() < 1e-5, k
+            continue
+        assert relerr(v.grad.cpu().numpy(), gref.numpy()) < 5e-4, k
