@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- end-to-end MoRec in-batch train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic MIND-shaped input, per rank:
+H2D of (ids, token rows, log_mask) -> BERT-base item encoder fwd -> SASRec -> fused in-batch debiased CE
+-> full backward -> gradient all-reduce (N > 1; negatives pooled over ranks by all-gather) -> fused AdamW.
+Workload: BASELINE.json configs[2] = SASRec + BERT-base, B = 128 user sequences per GPU, S = 20 (raw
+history 23), 30-token titles, D = 512, 2 heads, 2 blocks; bf16 MFMA operands / fp32 accumulate / fp32 master
+weights (the reference runs fp16 autocast, T/run.py:242).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="user sequences per GPU")
+    ap.add_argument("--bert", default="base")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--item-num", type=int, default=80000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
+    return ap.parse_args()
+
+
+def synth_catalog(item_num, T, rng):
+    """item_content int64 [item_num + 1, 2T]: [CLS] tokens [SEP] PAD..., mask; row 0 all zero."""
+    content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
+    lens = rng.integers(8, T + 1, item_num)
+    toks = rng.integers(1000, 30522, (item_num, T))
+    ar = np.arange(T)[None, :]
+    valid = ar < lens[:, None]
+    toks = np.where(valid, toks, 0)
+    toks[:, 0] = 101
+    toks[np.arange(item_num), lens - 1] = 102
+    content[1:, :T] = toks
+    content[1:, T:] = valid
+    return content
+
+
+def synth_batches(n, B, S, item_num, rng):
+    """Full-length train sequences (raw history 23 -> S + 1 = 21 items, no padding), Zipf(1.0) popularity."""
+    w = 1.0 / np.arange(1, item_num + 1)
+    w /= w.sum()
+    perm = rng.permutation(item_num) + 1
+    ids = perm[rng.choice(item_num, size=(n, B, S + 1), p=w)]
+    return ids.astype(np.int64)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # 'nccl' is RCCL on ROCm
+
+    from idvs.morec_amd import ops
+    from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    from idvs.morec_amd.train_step import TrainStep
+
+    S, T, D = 20, 30, 512
+    shape = BertShape.named(a.bert)
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_" + a.bert, word_embedding_dim=shape.hidden_size,
+                                 compute_dtype=a.dtype, allow_no_dropout=True)
+    rng = np.random.default_rng(12345)
+    content = synth_catalog(a.item_num, T, rng)
+    n_batches = a.steps + a.warmup
+    ids_all = synth_batches(n_batches, a.batch, S, a.item_num, np.random.default_rng(12345 + 1000 * rank))
+    counts = np.bincount(ids_all.reshape(-1), minlength=a.item_num + 1).astype(np.float64) + 1.0
+    pop = counts / counts[1:].sum()
+    pop[0] = 1.0
+    torch.manual_seed(12345)
+    model = Model(args, a.item_num, True, HipBertModel(shape), pop).to(dev)
+    model.train()
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool)
+
+    # host batches in pinned memory: what the reference's DataLoader hands to T/run.py:232-234
+    host = []
+    for i in range(n_batches):
+        ids = torch.from_numpy(ids_all[i]).pin_memory()
+        items = torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory()
+        lm = torch.ones(a.batch, S).pin_memory()
+        host.append((ids, items, lm))
+
+    # --- per-launch instrumentation of the dominant kernel (the NT GEMM) with HIP events on the launch stream
+    gemm_log = []
+    real_gemm = ops.gemm_nt
+    timing_on = {"v": False}
+
+    def timed_gemm(x, w, **kw):
+        if not timing_on["v"]:
+            return real_gemm(x, w, **kw)
+        M = kw.get("M") or x.shape[0]
+        K = kw.get("K") or x.shape[1]
+        N = kw.get("N") or w.shape[0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real_gemm(x, w, **kw)
+        e1.record()
+        gemm_log.append((2.0 * M * N * K, e0, e1, str(x.dtype)))
+        return out
+
+    ops.gemm_nt = timed_gemm
+
+    def run_step(i):
+        ids, items, lm = host[i]
+        ids_d = ids.to(dev, non_blocking=True)
+        items_d = items.to(dev, non_blocking=True)
+        lm_d = lm.to(dev, non_blocking=True)
+        return ts.step(ids_d.view(-1), items_d, lm_d)
+
+    for i in range(a.warmup):
+        loss = run_step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing_on["v"] = True
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_batches):
+        loss = run_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timing_on["v"] = False
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_v = float(loss.item())
+
+    # roofline of the dominant kernel: algorithmic FLOPs of every GEMM launch / its measured duration
+    fl = sum(f for f, _, _, _ in gemm_log)
+    ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in gemm_log)
+    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS["bf16" if a.dtype == "bf16" else "f32"]
+    roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (128x128 MFMA tile, all NT GEMMs of the step)",
+            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+            "launches_per_step": len(gemm_log) // max(1, a.steps), "gemm_ms_per_step": round(ms / max(1, a.steps), 3)}
+
+    out = {"metric": "user-sequences/sec end-to-end train step, SASRec+BERT-base", "value": round(world * a.batch * a.steps / dt, 2),
+           "unit": "user-seq/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.dtype, "data": "synthetic MIND-shaped (80k items, Zipf(1.0) popularity, 30-token titles, history 23), random-init weights",
+           "config": {"workload": f"SASRec(2 blocks, 2 heads, D=512) + BERT-{a.bert} text encoder, in-batch debiased CE, "
+                                  f"B={a.batch}/GPU, S=20, T=30", "global_batch": world * a.batch, "seq_len": S + 3,
+                      "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
+                      "dropout": "off (not yet implemented in the HIP path; reference config uses 0.1)"},
+           "final_loss": round(loss_v, 4), "roofline": roof}
+
+    if rank == 0 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, shape, content, pop, S, T, D)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, shape, content, pop, S, T, D):
+    """The CPU oracle (own restatement of the reference path, ``oracle/``; the reference's Python cannot travel to
+    the GPU box) timed on the host cores over a bounded sample: a few user sequences, fwd + bwd + AdamW."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import morec_oracle as orc
+    from idvs.morec_amd.model.spec import model_param_shapes
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = a.cpu_batch
+    shapes = model_param_shapes(max_seq_len=S, embedding_dim=D, n_blocks=2, item_num=a.item_num, use_modal=True, bert=shape)
+    g = torch.Generator().manual_seed(0)
+    p = {k: (torch.randn(*s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
+    rng = np.random.default_rng(1)
+    ids = synth_batches(2, Bc, S, a.item_num, rng)
+    states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()}
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        items = torch.from_numpy(content[ids[it].reshape(-1)])
+        loss = orc.model_forward(p, torch.from_numpy(ids[it]).view(-1), items, torch.ones(Bc, S), pop, max_seq_len=S,
+                                 embedding_dim=D, n_heads=2, use_modal=True, bert_heads=shape.num_attention_heads)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in p.items():
+                if v.grad is None or "pooler" in k:
+                    continue
+                lr = 5e-5 if "bert_model" in k else 1e-4
+                orc.adamw_step(v, v.grad, states[k][0], states[k][1], it + 1, lr, 0.01)
+                v.grad = None
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(Bc / best, 4), "unit": "user-seq/s", "cores": cores, "kind": "port",
+            "sample": f"{Bc} user sequences x 2 steps (fwd+bwd+AdamW, PyTorch-CPU fp32, BERT-{a.bert}), best step {best:.2f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -39,9 +39,13 @@ class PreparedLinear:
     wt: torch.Tensor     # [in, pad8(out)] compute dtype (zero padded)
 
 
-def prepare_linear(weight: torch.Tensor, dtype: torch.dtype) -> PreparedLinear:
-    w = weight if weight.dtype == dtype else ops.cast(weight.contiguous(), dtype)
-    wt = ops.transpose(weight.contiguous(), out_dtype=dtype)
+def prepare_linear(weight: torch.Tensor, dtype: torch.dtype, shadow: torch.Tensor | None = None) -> PreparedLinear:
+    """``shadow``: an up-to-date copy of ``weight`` already in the compute dtype (the AdamW kernel's bf16 shadow)."""
+    if shadow is not None and shadow.dtype == dtype:
+        w = shadow
+    else:
+        w = weight if weight.dtype == dtype else ops.cast(weight.contiguous(), dtype)
+    wt = ops.transpose(w.contiguous(), out_dtype=dtype)
     return PreparedLinear(w.contiguous(), wt)
 
 
@@ -116,15 +120,19 @@ def sasrec_layer_names(l: int, prefix: str = UE):
     return a, f
 
 
-def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE):
+def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE, shadow: dict | None = None):
+    sh = shadow or {}
     layers = []
     for l in range(n_layers):
         a, f = sasrec_layer_names(l, prefix)
-        wqkv = torch.cat([p[a + "w_Q.weight"], p[a + "w_K.weight"], p[a + "w_V.weight"]], 0)
-        layers.append(dict(qkv=prepare_linear(wqkv, dtype), bqkv=None, o=prepare_linear(p[a + "fc.weight"], dtype), bo=None,
+        wqkv = p.get(a + "qkv_fused")   # arena view over the three adjacent projections, if the caller has one
+        if wqkv is None:
+            wqkv = torch.cat([p[a + "w_Q.weight"], p[a + "w_K.weight"], p[a + "w_V.weight"]], 0)
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(a + "qkv_fused")), bqkv=None,
+                           o=prepare_linear(p[a + "fc.weight"], dtype, sh.get(a + "fc.weight")), bo=None,
                            ln1_g=p[a + "layer_norm.weight"], ln1_b=p[a + "layer_norm.bias"],
-                           f1=prepare_linear(p[f + "w_1.weight"], dtype), b1=p[f + "w_1.bias"],
-                           f2=prepare_linear(p[f + "w_2.weight"], dtype), b2=p[f + "w_2.bias"],
+                           f1=prepare_linear(p[f + "w_1.weight"], dtype, sh.get(f + "w_1.weight")), b1=p[f + "w_1.bias"],
+                           f2=prepare_linear(p[f + "w_2.weight"], dtype, sh.get(f + "w_2.weight")), b2=p[f + "w_2.bias"],
                            ln2_g=p[f + "layer_norm.weight"], ln2_b=p[f + "layer_norm.bias"]))
     return layers
 
@@ -175,20 +183,23 @@ def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefi
 TE = "bert_encoder.text_encoders.title."
 
 
-def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE):
+def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict | None = None):
+    sh = shadow or {}
     bm = prefix + "bert_model."
     layers = []
     for l in range(n_layers):
         L = bm + f"encoder.layer.{l}."
-        wqkv = torch.cat([p[L + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
-        bqkv = torch.cat([p[L + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
-        layers.append(dict(qkv=prepare_linear(wqkv, dtype), bqkv=bqkv,
-                           o=prepare_linear(p[L + "attention.output.dense.weight"], dtype), bo=p[L + "attention.output.dense.bias"],
+        wqkv, bqkv = p.get(L + "qkv_fused.weight"), p.get(L + "qkv_fused.bias")
+        if wqkv is None:
+            wqkv = torch.cat([p[L + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
+            bqkv = torch.cat([p[L + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(L + "qkv_fused.weight")), bqkv=bqkv,
+                           o=prepare_linear(p[L + "attention.output.dense.weight"], dtype, sh.get(L + "attention.output.dense.weight")), bo=p[L + "attention.output.dense.bias"],
                            ln1_g=p[L + "attention.output.LayerNorm.weight"], ln1_b=p[L + "attention.output.LayerNorm.bias"],
-                           f1=prepare_linear(p[L + "intermediate.dense.weight"], dtype), b1=p[L + "intermediate.dense.bias"],
-                           f2=prepare_linear(p[L + "output.dense.weight"], dtype), b2=p[L + "output.dense.bias"],
+                           f1=prepare_linear(p[L + "intermediate.dense.weight"], dtype, sh.get(L + "intermediate.dense.weight")), b1=p[L + "intermediate.dense.bias"],
+                           f2=prepare_linear(p[L + "output.dense.weight"], dtype, sh.get(L + "output.dense.weight")), b2=p[L + "output.dense.bias"],
                            ln2_g=p[L + "output.LayerNorm.weight"], ln2_b=p[L + "output.LayerNorm.bias"]))
-    return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype))
+    return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype, sh.get(prefix + "fc.weight")))
 
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,

@@ -1,0 +1,218 @@
+"""``TrainStep``: the MI355X-native equivalent of the hot loop of ``T/run.py:231-247`` -- H2D batch ->
+item encoder -> SASRec -> in-batch CE -> backward -> gradient reduce -> AdamW -- with no autograd graph,
+no per-parameter launches and no host synchronisation inside the step.
+
+* Parameters live in ONE flat fp32 arena per hyper-parameter group (the two groups of ``T/run.py:150-162``:
+  names containing ``bert_model`` vs the rest); ``nn.Parameter.data`` of the drop-in ``Model`` are re-pointed
+  at views of it, so ``state_dict()`` / checkpoints stay reference-compatible.  Q/K/V projections are laid
+  out adjacently, so the fused ``[3H, H]`` QKV weight (and its gradient) is a zero-copy view.
+* Gradients live in a matching flat fp32 arena (zeroed by one memset per step, reduced by ONE collective).
+* AdamW is one kernel launch per group over the flat arena and refreshes the bf16 shadow in the same pass.
+* Data parallel (one process per GPU, RCCL): negatives pooled with an all-gather of the encoded item
+  vectors, dE reduce-scattered back to the owning rank, valid-row count and gradients all-reduced (SUM);
+  N ranks x B is then arithmetically the single-process step at batch N*B.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from .functional import _all_gather_cat, _reduce_scatter_sum
+
+
+def _round4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+class ParamArena:
+    """Flat fp32 storage (+ grad, AdamW moments, optional bf16 shadow) for an ordered set of parameters."""
+
+    def __init__(self, named_params, device, shadow: bool):
+        self.offsets = OrderedDict()
+        off = 0
+        for name, p in named_params:
+            self.offsets[name] = (off, p.numel(), tuple(p.shape))
+            off += _round4(p.numel())
+        self.numel = off
+        self.data = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.exp_avg = torch.zeros(off, device=device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(off, device=device, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=device, dtype=torch.bfloat16) if shadow else None
+        for name, p in named_params:
+            o, n, shp = self.offsets[name]
+            self.data[o:o + n].view(shp).copy_(p.data)
+            p.data = self.data[o:o + n].view(shp)       # the module now reads/writes the arena
+        if shadow:
+            ops.cast(self.data, torch.bfloat16, out=self.shadow)
+
+    def view(self, buf, name):
+        o, n, shp = self.offsets[name]
+        return buf[o:o + n].view(shp)
+
+    def span(self, buf, names, shape):
+        """Zero-copy view over several ADJACENT parameters (e.g. q/k/v -> fused [3H, H])."""
+        o0 = self.offsets[names[0]][0]
+        end = o0
+        for nme in names:
+            o, n, _ = self.offsets[nme]
+            assert o == end and n % 4 == 0, "parameters are not adjacent in the arena"
+            end = o + n
+        return buf[o0:end].view(shape)
+
+
+def _order_bert(names):
+    """Arena order for the text encoder: q/k/v weights adjacent, q/k/v biases adjacent (per layer)."""
+    out, seen = [], set()
+    for n in names:
+        if n in seen:
+            continue
+        if ".attention.self.query.weight" in n:
+            base = n[: -len("query.weight")]
+            grp = [base + "query.weight", base + "key.weight", base + "value.weight",
+                   base + "query.bias", base + "key.bias", base + "value.bias"]
+            out += grp
+            seen.update(grp)
+        elif ".attention.self." in n:
+            continue
+        else:
+            out.append(n)
+            seen.add(n)
+    return out
+
+
+class TrainStep:
+    def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
+                 betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True):
+        self.model = model
+        self.dtype = model.compute_dtype
+        self.device = next(model.parameters()).device
+        self.betas, self.eps = betas, eps
+        self.pool = pool_negatives
+        self.step_count = 0
+        named = OrderedDict((n, p) for n, p in model.named_parameters())
+        train = [n for n, p in named.items() if p.requires_grad and ".pooler." not in n]
+        g0 = _order_bert([n for n in train if "bert_model" in n])          # T/run.py:155: 'bert_model' in name
+        g1 = [n for n in train if "bert_model" not in n]
+        use_shadow = self.dtype == torch.bfloat16
+        self.groups = []
+        if g0:
+            self.groups.append(dict(arena=ParamArena([(n, named[n]) for n in g0], self.device, use_shadow),
+                                    lr=fine_tune_lr, wd=fine_tune_l2_weight))
+        self.groups.append(dict(arena=ParamArena([(n, named[n]) for n in g1], self.device, use_shadow), lr=lr, wd=l2_weight))
+        self.frozen = {n: p.data for n, p in named.items() if n not in set(g0) | set(g1)}
+        self._build_views()
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.log_pop = torch.log(model.pop_prob_list).to(self.device)
+
+    # -----------------------------------------------------------------------------------------------
+    def _build_views(self):
+        m = self.model
+        self.p, self.g, self.sh = {}, {}, {}
+        for grp in self.groups:
+            a = grp["arena"]
+            for n in a.offsets:
+                self.p[n] = a.view(a.data, n)
+                self.g[n] = a.view(a.grad, n)
+                if a.shadow is not None:
+                    self.sh[n] = a.view(a.shadow, n)
+        self.p.update(self.frozen)
+        D = m.args.embedding_dim
+        ue = engine.UE
+        a1 = self.groups[-1]["arena"]
+        for l in range(m.args.transformer_block):
+            a, _ = engine.sasrec_layer_names(l, ue)
+            names = [a + "w_Q.weight", a + "w_K.weight", a + "w_V.weight"]
+            self.p[a + "qkv_fused"] = a1.span(a1.data, names, (3 * D, D))
+            self.g[a + "qkv_fused"] = a1.span(a1.grad, names, (3 * D, D))
+            if a1.shadow is not None:
+                self.sh[a + "qkv_fused"] = a1.span(a1.shadow, names, (3 * D, D))
+        if m.use_modal:
+            a0 = self.groups[0]["arena"]
+            bert = m.bert_encoder.text_encoders["title"].bert_model
+            H, L = bert.config.hidden_size, bert.config.num_hidden_layers
+            self.bert_heads = bert.config.num_attention_heads
+            self.bert_layers, self.bert_eps = L, bert.config.layer_norm_eps
+            self.bert_mask_value = m.bert_encoder.text_encoders["title"].mask_value
+            for l in range(L):
+                Lp = engine.TE + f"bert_model.encoder.layer.{l}."
+                wn = [Lp + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+                bn = [Lp + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+                if wn[0] not in a0.offsets:   # frozen layer: fall back to per-step concatenation
+                    continue
+                self.p[Lp + "qkv_fused.weight"] = a0.span(a0.data, wn, (3 * H, H))
+                self.p[Lp + "qkv_fused.bias"] = a0.span(a0.data, bn, (3 * H,))
+                self.g[Lp + "qkv_fused.weight"] = a0.span(a0.grad, wn, (3 * H, H))
+                self.g[Lp + "qkv_fused.bias"] = a0.span(a0.grad, bn, (3 * H,))
+                if a0.shadow is not None:
+                    self.sh[Lp + "qkv_fused.weight"] = a0.span(a0.shadow, wn, (3 * H, H))
+
+    # -----------------------------------------------------------------------------------------------
+    def forward_backward(self, sample_items_id, sample_items, log_mask):
+        """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync)."""
+        m, p, g = self.model, self.p, self.g
+        D, S = m.args.embedding_dim, m.max_seq_len
+        for grp in self.groups:
+            grp["arena"].grad.zero_()
+        # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
+        grads = dict(g)
+        for n, t in self.frozen.items():
+            if ".pooler." not in n:
+                grads[n] = torch.zeros_like(t)
+        ids = sample_items_id.view(-1)
+        if m.use_modal:
+            prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
+            E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
+                                             self.bert_mask_value, engine.TE)
+        else:
+            idx32 = sample_items.view(-1).to(torch.int32).contiguous()
+            E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
+        B = log_mask.shape[0]
+        x_in = E.view(B, S + 1, D)[:, :-1, :].contiguous()
+        prep_s = engine.sasrec_prepare(p, m.args.transformer_block, self.dtype, engine.UE, self.sh)
+        P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE)
+        ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
+        n_valid = ci.row_valid.sum(dtype=torch.float32)
+        Epool = E
+        if self.world > 1 and self.pool:
+            Epool = _all_gather_cat(E, self.world)
+            ci = engine.CeInputs(ci.row_ids, _all_gather_cat(ci.col_ids, self.world), _all_gather_cat(ci.col_logpop, self.world),
+                                 _all_gather_cat(ci.col_valid, self.world), ci.row_valid, ci.B, ci.S, self.rank * E.shape[0])
+            dist.all_reduce(n_valid)
+        loss_sum, saved_c = engine.ce_forward(ci, P, Epool)
+        gscale = (1.0 / n_valid).reshape(1)
+        dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
+        dE = _reduce_scatter_sum(dEpool, self.world, self.rank) if (self.world > 1 and self.pool) else dEpool
+        dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
+        dE.view(B, S + 1, D)[:, :-1, :].add_(dx.view(B, S, D))      # the two sources of dE (T/model/model.py:39-41,49)
+        if m.use_modal:
+            engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE)
+        else:
+            ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
+        return loss_sum[0] / n_valid
+
+    def reduce_gradients(self):
+        """SUM over ranks (the 1/n_valid_global factor is already inside the loss gradient)."""
+        if self.world > 1:
+            for grp in self.groups:
+                dist.all_reduce(grp["arena"].grad)
+                if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
+                    grp["arena"].grad.mul_(1.0 / self.world)
+
+    def optimizer_step(self):
+        self.step_count += 1
+        for grp in self.groups:
+            a = grp["arena"]
+            ops.adamw_(a.data, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, grp["lr"], self.betas[0], self.betas[1],
+                       self.eps, grp["wd"], self.step_count)
+
+    def step(self, sample_items_id, sample_items, log_mask):
+        """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling)."""
+        loss = self.forward_backward(sample_items_id, sample_items, log_mask)
+        self.reduce_gradients()
+        self.optimizer_step()
+        return loss

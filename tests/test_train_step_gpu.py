@@ -1,0 +1,102 @@
+"""TrainStep (flat-arena fused driver) on a real MI355X: one full optimisation step against the CPU oracle,
+and agreement with the drop-in autograd ``Model`` path."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(dtype, use_modal=True, seed=0):
+    from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    from idvs.morec_amd.utils.detgen import det_param
+    S, D, T, item_num, B = 10, 128, 30, 200, 9
+    shape = BertShape(vocab_size=1500, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      intermediate_size=512, max_position_embeddings=64)
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_x", word_embedding_dim=128, compute_dtype=dtype)
+    rng = np.random.default_rng(seed)
+    pop = rng.random(item_num + 1) + 0.05
+    pop[1:] /= pop[1:].sum()
+    pop[0] = 1.0
+    model = Model(args, item_num, use_modal, HipBertModel(shape) if use_modal else None, pop)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(torch.from_numpy(det_param(k, tuple(v.shape))))
+    content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
+    for i in range(1, item_num + 1):
+        L = int(rng.integers(3, T + 1))
+        content[i, :L] = rng.integers(1, 1500, L)
+        content[i, T:T + L] = 1
+    ids = np.zeros((B, S + 1), dtype=np.int64)
+    lm = np.zeros((B, S), dtype=np.float32)
+    for b in range(B):
+        L = int(rng.integers(2, S + 2))
+        ids[b, S + 1 - L:] = rng.integers(1, item_num + 1, L)
+        lm[b, S + 1 - L:] = 1
+    items = content[ids.reshape(-1)] if use_modal else ids.reshape(-1)
+    return model.to(DEV), ids, items, lm, pop, (S, D, shape)
+
+
+@pytest.mark.parametrize("use_modal", [True, False])
+def test_train_step_vs_oracle(use_modal):
+    import morec_oracle as orc
+    from idvs.morec_amd.train_step import TrainStep
+    model, ids, items, lm, pop, (S, D, shape) = _setup("fp32", use_modal)
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.02)
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    losses = []
+    for it in range(2):
+        losses.append(ts.step(tdev(ids).view(-1), tdev(items), tdev(lm)).item())
+    # oracle: two steps of autograd + AdamW with the two groups of T/run.py:150-162
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p_ref.items()}
+    ref_losses = []
+    for it in range(2):
+        loss = orc.model_forward(p_ref, torch.from_numpy(ids).view(-1), torch.from_numpy(items), torch.from_numpy(lm), pop,
+                                 max_seq_len=S, embedding_dim=D, n_heads=2, use_modal=use_modal, bert_heads=4)
+        ref_losses.append(loss.item())
+        loss.backward()
+        with torch.no_grad():
+            for k, v in p_ref.items():
+                if v.grad is None or "pooler" in k:
+                    continue
+                g = v.grad.clone()
+                if k == "id_embedding.weight":
+                    g[0] = 0   # padding_idx
+                lr, wd = (5e-5, 0.02) if "bert_model" in k else (1e-4, 0.01)
+                orc.adamw_step(v, g, st[k][0], st[k][1], it + 1, lr, wd)
+                v.grad = None
+    assert abs(losses[0] - ref_losses[0]) < 5e-5 and abs(losses[1] - ref_losses[1]) < 2e-4, (losses, ref_losses)
+    sd = model.state_dict()
+    worst = 0.0
+    for k, v in p_ref.items():
+        if "pooler" in k:
+            continue
+        d = (sd[k].cpu() - v.detach()).abs().max().item()
+        worst = max(worst, d)
+    # two Adam steps move each weight by <= 2*lr; eps-dominated elements may differ by a fraction of that
+    assert worst < 2.5e-4, worst
+    print("train_step vs oracle: losses", losses, ref_losses, "worst param diff", worst)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_train_step_matches_autograd_model(dtype):
+    from idvs.morec_amd.train_step import TrainStep
+    model, ids, items, lm, pop, _ = _setup(dtype)
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    loss = model(tdev(ids).view(-1), tdev(items), tdev(lm), DEV)
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01)
+    loss2 = ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
+    assert abs(loss.item() - loss2.item()) < 1e-6 * max(1, abs(loss.item())) + (0 if dtype == "fp32" else 1e-3)
+    for k, g in ref.items():
+        got = ts.g[k]
+        scale = g.abs().max().item() + 1e-12
+        assert (got - g).abs().max().item() / scale < (1e-4 if dtype == "fp32" else 2e-2), k
