@@ -55,10 +55,13 @@ def test_g3_sasrec_golden(golden_dir, case, dtype):
     tol = 2e-5 if dtype == "fp32" else 6e-2
     e_y = relerr(y.detach().cpu().numpy(), gd[f"{case}.y"])
     (y * R).sum().backward()
-    gt = 2e-4 if dtype == "fp32" else 2e-1   # tiny D=64 bf16 model: noisy small gradients
-    errs = {"dx": relerr(x.grad.cpu().numpy(), gd[f"{case}.dx"])}
+    # bf16: ReLU masks flip where the pre-activation is ~0, which moves single elements of tiny-model gradients a
+    # lot -> judge bf16 gradients in the Frobenius norm, fp32 ones element-wise (max-abs)
+    gt = 2e-4 if dtype == "fp32" else 1e-1
+    err_fn = relerr if dtype == "fp32" else (lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-30)))
+    errs = {"dx": err_fn(x.grad.cpu().numpy(), gd[f"{case}.dx"])}
     for k, p in enc.named_parameters():
-        errs[k] = relerr(p.grad.cpu().numpy(), gd[f"{case}.grad.{k}"])
+        errs[k] = err_fn(p.grad.cpu().numpy(), gd[f"{case}.grad.{k}"])
     print(f"g3 {case} {dtype}: y err {e_y:.2e}; worst grad err {max(errs.values()):.2e} ({max(errs, key=errs.get)})")
     assert e_y < tol
     assert max(errs.values()) < gt, errs
