@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
 
 class AttnDesc(C.Structure):
     _fields_ = [("n_seq", C.c_int), ("T", C.c_int), ("n_heads", C.c_int), ("dh", C.c_int), ("causal", C.c_int),
-                ("scale", C.c_float), ("mask_value", C.c_float), ("dtype", C.c_int)]
+                ("scale", C.c_float), ("mask_value", C.c_float), ("dtype", C.c_int), ("p_drop", C.c_float),
+                ("seed", C.c_uint64)]
 
 
 class CeDesc(C.Structure):
@@ -45,13 +46,14 @@ _SIGS = {
     "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
-                                      C.c_int, _P]),
-    "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+                                      C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P]),
+    "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_uint64, C.c_float, C.c_uint64, _P]),
     "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),
     "morec_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "morec_bert_embed_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
-                                       C.c_int, _P]),
+                                       C.c_int, C.c_float, C.c_uint64, _P]),
     "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_scatter_add_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -63,6 +65,7 @@ _SIGS = {
     "morec_adamw": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                               C.c_int, C.c_float, _P]),
     "morec_eval_rank": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_dropout_keep_mask": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_uint64, _P]),
     "morec_probe": (C.c_int, [_P, _P]),
 }
 

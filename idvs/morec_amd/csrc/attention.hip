@@ -25,6 +25,7 @@ struct AttnArgs {
     int n_seq, T, n_heads, dh;
     int causal;
     float scale, mask_value;
+    DropRng drop;      // attention-probability dropout (modules.py:30; HF attention_probs_dropout_prob)
 };
 
 // stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to 32 rows
@@ -102,6 +103,15 @@ __device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, 
     }
 }
 
+// dropout keep-mask of the lane's 4 x 4 block: element index ((tile * 32 + i) * 32 + j)
+__device__ __forceinline__ void block_drop_mask(const DropRng& d, uint64_t tile, int i0, int j0, float (&m)[4][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            m[r][c] = drop_keep(d, (tile * 32 + (uint64_t)(i0 + r)) * 32 + (uint64_t)(j0 + c)) ? d.inv_keep : 0.f;
+}
+
 // o[r][0..CW-1] = sum_k W[k][w0 + r] * V[k][c0 .. c0+CW-1]   (W stored [k][32 + pad]: "weights by row k");
 // CW = DC / 8 columns per lane so that the 8 x 8 lane grid covers a [32 x DC] output chunk exactly.
 template <int DC>
@@ -169,6 +179,14 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
     }
     block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+    if (a.drop.thresh) {
+        float m[4][4];
+        block_drop_mask(a.drop, blockIdx.x, i0, j0, m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[r][c] *= m[r][c];
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         *reinterpret_cast<float4*>(sPt + (j0 + c) * PP + i0) = make_float4(s[0][c], s[1][c], s[2][c], s[3][c]);
@@ -223,6 +241,14 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
         __syncthreads();
     }
     block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+    float msk[4][4];
+    if (a.drop.thresh) {
+        block_drop_mask(a.drop, blockIdx.x, i0, j0, msk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dp[r][c] *= msk[r][c];   // dP = dP_dropped o mask / (1 - p)
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float delta = 0.f;
@@ -233,6 +259,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
         delta += __shfl_xor(delta, 4, 64);
 #pragma unroll
         for (int c = 0; c < 4; ++c) dp[r][c] = s[r][c] * (dp[r][c] - delta) * a.scale;   // dp now holds dS
+        if (a.drop.thresh) {   // dV uses the DROPPED probabilities
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[r][c] *= msk[r][c];
+        }
         *reinterpret_cast<float4*>(sP + (i0 + r) * PP + j0) = make_float4(s[r][0], s[r][1], s[r][2], s[r][3]);
         *reinterpret_cast<float4*>(sS + (i0 + r) * PP + j0) = make_float4(dp[r][0], dp[r][1], dp[r][2], dp[r][3]);
     }
@@ -266,6 +296,7 @@ int check_desc(const morec_attn_desc* d) {
     if (d->n_seq <= 0 || d->T <= 0 || d->n_heads <= 0 || d->dh <= 0) return MOREC_E_ARG;
     if (d->T > TP) return MOREC_E_UNSUPPORTED;
     if (d->dh % 8) return MOREC_E_ALIGN;
+    if (d->p_drop < 0.f || d->p_drop >= 1.f) return MOREC_E_ARG;
     return MOREC_OK;
 }
 }  // namespace
@@ -275,7 +306,8 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     int rc = check_desc(d);
     if (rc) return rc;
     if (!qkv || !key_keep || !ctx) return MOREC_E_ARG;
-    AttnArgs a{qkv, key_keep, ctx, nullptr, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value};
+    AttnArgs a{qkv, key_keep, ctx, nullptr, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
+               make_drop(d->p_drop, d->seed)};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MOREC_F32)
@@ -294,7 +326,7 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc) return rc;
     if (!qkv || !key_keep || !dctx || !dqkv) return MOREC_E_ARG;
     AttnArgs a{qkv, key_keep, const_cast<void*>(dctx), dqkv, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale,
-               d->mask_value};
+               d->mask_value, make_drop(d->p_drop, d->seed)};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MOREC_F32)

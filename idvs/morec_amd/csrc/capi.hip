@@ -63,3 +63,17 @@ extern "C" int morec_probe(int32_t* out, void* stream) {
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
+
+// test hook: the keep-mask the kernels derive from (p, seed) for element indices 0 .. n-1
+__global__ void drop_mask_kernel(uint8_t* out, size_t n, DropRng d) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = drop_keep(d, i) ? 1 : 0;
+}
+extern "C" int morec_dropout_keep_mask(uint8_t* out, size_t n, float p, uint64_t seed, void* stream) {
+    if (!out || p < 0.f || p >= 1.f) return MOREC_E_ARG;
+    if (n == 0) return MOREC_OK;
+    hipLaunchKernelGGL(drop_mask_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), out, n, make_drop(p, seed));
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

@@ -82,6 +82,31 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return cdf + x * pdf;
 }
 
+// ---- counter-based dropout RNG: a pure function of (seed, element index), so the backward pass regenerates
+// the forward mask instead of storing it.  Two rounds of a 32-bit avalanche mixer over (index, seed).
+struct DropRng {
+    uint32_t s0, s1, thresh;   // keep iff hash >= thresh, thresh = p * 2^32
+    float inv_keep;            // 1 / (1 - p)
+};
+__host__ __device__ inline DropRng make_drop(float p, uint64_t seed) {
+    DropRng d;
+    d.s0 = (uint32_t)seed;
+    d.s1 = (uint32_t)(seed >> 32);
+    const double t = (double)p * 4294967296.0;
+    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+    d.inv_keep = p <= 0.f ? 1.0f : 1.0f / (1.0f - p);
+    return d;
+}
+__host__ __device__ inline uint32_t drop_hash(const DropRng& d, uint64_t idx) {
+    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) ^ d.s0;
+    h ^= ((uint32_t)(idx >> 32) * 0x85EBCA77u) + d.s1;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    h += d.s1;
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+    return h;
+}
+__host__ __device__ inline bool drop_keep(const DropRng& d, uint64_t idx) { return drop_hash(d, idx) >= d.thresh; }
+
 // ---- host-side argument checks -------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int elt_size(int dtype) { return dtype == MOREC_BF16 ? 2 : 4; }

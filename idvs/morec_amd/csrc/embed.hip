@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
                                                              const float* __restrict__ beta, float eps,
                                                              T* __restrict__ z_out, T* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                             int M, int Tlen, int H) {
+                                                             int M, int Tlen, int H, DropRng dout) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
             o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
             o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
             o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+            if (dout.thresh) {   // HF BertEmbeddings: dropout after the LayerNorm
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+            }
             io<T>::store4(y + base + c, o);
         }
     }
@@ -80,7 +84,10 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
 
 extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
                                     const float* gamma, const float* beta, float eps, void* z_out, void* y,
-                                    float* mean, float* rstd, int M, int T, int H, int dtype, void* stream) {
+                                    float* mean, float* rstd, int M, int T, int H, int dtype, float p_out,
+                                    uint64_t seed_out, void* stream) {
+    if (p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
+    const DropRng dout = make_drop(p_out, seed_out);
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !y || M <= 0 || T <= 0 || H <= 0) return MOREC_E_ARG;
     if (H % 4) return MOREC_E_ALIGN;
     const int vpl = (H + 255) / 256;
@@ -88,7 +95,7 @@ extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define EMB(TT, V)                                                                                                  \
     hipLaunchKernelGGL((bert_embed_fwd_kernel<TT, V>), grid, block, 0, s, ids, word, pos, type0, gamma, beta, eps, \
-                       (TT*)z_out, (TT*)y, mean, rstd, M, T, H)
+                       (TT*)z_out, (TT*)y, mean, rstd, M, T, H, dout)
 #define EMB_DISPATCH(TT)                      \
     do {                                      \
         if (vpl <= 1) EMB(TT, 1);             \

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      int pos_period, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ z_out,
                                                      T* __restrict__ y, float* __restrict__ mean_out,
-                                                     float* __restrict__ rstd_out, int M, int N) {
+                                                     float* __restrict__ rstd_out, int M, int N, DropRng din,
+                                                     DropRng dout) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -26,6 +27,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             if (bias) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + c);
                 v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+            }
+            if (din.thresh) {   // dropout on the sub-layer output BEFORE the residual add (modules.py:16,62; HF Bert*Output)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i][k] = drop_keep(din, base + c + k) ? v[i][k] * din.inv_keep : 0.f;
             }
             if (res) {
                 float r[4];
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
             o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
             o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+            if (dout.thresh) {  // dropout on the LayerNorm output (embedding stages: modules.py:93-94, HF BertEmbeddings)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+            }
             io<T>::store4(y + base + c, o);
         }
     }
@@ -90,8 +99,9 @@ template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     T* __restrict__ dz, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int N, int rows_per_block) {
+                                                     T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int N, int rows_per_block,
+                                                     DropRng din, DropRng dout) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [4][N] dgamma partials
     float* sb = sg + 4 * (size_t)N;                 // [4][N] dbeta partials
@@ -126,6 +136,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
                     for (int k = 0; k < 4; ++k) d[k] += e[k];
                 }
+                if (dout.thresh) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
+                }
                 io<T>::load4(z + base + c, zz);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -151,6 +165,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
                 io<T>::store4(dz + base + c, o);
+                if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
+                    io<T>::store4(dzd + base + c, o);
+                }
             }
         }
     }
@@ -174,12 +193,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 template <typename T>
 static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
                            const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
-                           float* rstd, int M, int N, hipStream_t s) {
+                           float* rstd, int M, int N, DropRng din, DropRng dout, hipStream_t s) {
     const int vpl = (N + 255) / 256;
     dim3 grid((M + 3) / 4), block(256);
 #define LN_FWD(V)                                                                                                   \
     hipLaunchKernelGGL((ln_fwd_kernel<T, V>), grid, block, 0, s, (const T*)x, bias, (const T*)res, pos, pos_period, \
-                       gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N)
+                       gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din, dout)
     if (vpl <= 1) LN_FWD(1);
     else if (vpl <= 2) LN_FWD(2);
     else if (vpl <= 3) LN_FWD(3);
@@ -194,21 +213,25 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
 
 extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const float* pos,
                                    int pos_period, const float* gamma, const float* beta, float eps, void* z_out,
-                                   void* y, float* mean, float* rstd, int M, int N, int dtype, void* stream) {
+                                   void* y, float* mean, float* rstd, int M, int N, int dtype, float p_in,
+                                   uint64_t seed_in, float p_out, uint64_t seed_out, void* stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) return MOREC_E_ARG;
+    if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
+    const DropRng din = make_drop(p_in, seed_in), dout = make_drop(p_out, seed_out);
     if (N % 4 || (dtype == MOREC_BF16 && N % 4)) return MOREC_E_ALIGN;
     if (pos && pos_period <= 0) return MOREC_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
-        return ln_fwd_dispatch<float>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, s);
+        return ln_fwd_dispatch<float>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, s);
     if (dtype == MOREC_BF16)
-        return ln_fwd_dispatch<bf16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, s);
+        return ln_fwd_dispatch<bf16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, s);
     return MOREC_E_DTYPE;
 }
 
 template <typename T>
 static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
-                           const float* gamma, void* dz, float* dgamma, float* dbeta, int M, int N, hipStream_t s) {
+                           const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, int M, int N,
+                           DropRng din, DropRng dout, hipStream_t s) {
     const int vpl = (N + 255) / 256;
     const int rpb = 64;
     dim3 grid((M + rpb - 1) / rpb), block(256);
@@ -219,7 +242,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
         hipLaunchKernelGGL((ln_bwd_kernel<T, V>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,          \
-                           (const T*)z, mean, rstd, gamma, (T*)dz, dgamma, dbeta, M, N, rpb);                   \
+                           (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, M, N, rpb, din, dout); \
     } while (0)
     if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
@@ -234,15 +257,21 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
 }
 
 extern "C" int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean,
-                                   const float* rstd, const float* gamma, void* dz, float* dgamma, float* dbeta,
-                                   int M, int N, int dtype, void* stream) {
+                                   const float* rstd, const float* gamma, void* dz, void* dzd, float* dgamma,
+                                   float* dbeta, int M, int N, int dtype, float p_in, uint64_t seed_in, float p_out,
+                                   uint64_t seed_out, void* stream) {
     if (!dy_a || !z || !mean || !rstd || !gamma || !dz || M <= 0 || N <= 0) return MOREC_E_ARG;
+    if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
+    if ((p_in > 0.f) != (dzd != nullptr)) return MOREC_E_ARG;
+    const DropRng din = make_drop(p_in, seed_in), dout = make_drop(p_out, seed_out);
     if ((dgamma == nullptr) != (dbeta == nullptr)) return MOREC_E_ARG;
     if (N % 4) return MOREC_E_ALIGN;
     if (N > 4096) return MOREC_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MOREC_F32) return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dgamma, dbeta, M, N, s);
-    if (dtype == MOREC_BF16) return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dgamma, dbeta, M, N, s);
+    if (dtype == MOREC_F32)
+        return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, M, N, din, dout, s);
+    if (dtype == MOREC_BF16)
+        return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, M, N, din, dout, s);
     return MOREC_E_DTYPE;
 }
 

@@ -33,6 +33,24 @@ class LayerCfg:
     mask_value: float    # additive value on masked keys: -1e9 (T/model/encoders.py:27) | finfo.min (HF eager)
 
 
+_GOLD = 0x9E3779B97F4A7C15
+
+
+@dataclass
+class DropCfg:
+    """Training-mode dropout of one encoder stack: hidden-state probability, attention-probability probability and the
+    per-step seed; ``site(k)`` derives the independent stream of the k-th dropout site of the stack."""
+    p_hidden: float = 0.0
+    p_attn: float = 0.0
+    seed: int = 0
+
+    def site(self, k: int) -> int:
+        return (self.seed + (k + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
+
+
+NO_DROP = DropCfg()
+
+
 @dataclass
 class PreparedLinear:
     w: torch.Tensor      # [out, in]  compute dtype
@@ -66,40 +84,47 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
 # ---------------------------------------------------------------------------------------------------------
 # one transformer layer
 # ---------------------------------------------------------------------------------------------------------
-def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool):
-    """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b."""
+def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
+                  drop: DropCfg = NO_DROP, site0: int = 0):
+    """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b.
+    Dropout sites of a layer: site0 = attention probabilities, site0+1 = attention sub-layer output, site0+2 = FFN output."""
     dh = cfg.H // cfg.heads
-    desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype)
+    desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
+                         drop.p_attn, drop.site(site0))
+    ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     a = ops.gemm_nt(ctx, w["o"].w)
-    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True)
+    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True,
+                                             p_in=ph, seed_in=s1)
     u = torch.empty((x0.shape[0], w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
     g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u)
     f = ops.gemm_nt(g, w["f2"].w)
-    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True)
-    saved = (desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep) if need_grad else None
+    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
+                                             p_in=ph, seed_in=s2)
+    saved = (desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2) if need_grad else None
     return x2, saved
 
 
 def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     """g: fp32 gradient buffers (accumulated into): qkv [3H,H], bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b
     (bias entries may be None).  Returns (da, db) with dx0 = da + db."""
-    desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep = saved
-    dz2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"])
+    desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2 = saved
+    # dz* = gradient at the residual sum (also the residual branch's gradient); dzd* = after the sub-layer's dropout
+    dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2)
     if g.get("b2") is not None:
-        ops.colsum_(dz2, g["b2"])
-    linear_wgrad_(dz2, gact, g["f2"])
-    du = ops.gemm_nt(dz2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dz2.shape[1], N=u.shape[1])
+        ops.colsum_(dzd2, g["b2"])
+    linear_wgrad_(dzd2, gact, g["f2"])
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
     if g.get("b1") is not None:
         ops.colsum_(du, g["b1"])
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=x1.shape[1])
-    dz1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"])
+    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1)
     if g.get("bo") is not None:
-        ops.colsum_(dz1, g["bo"])
-    linear_wgrad_(dz1, ctx, g["o"])
-    dctx = ops.gemm_nt(dz1, w["o"].wt, K=dz1.shape[1], N=ctx.shape[1])
+        ops.colsum_(dzd1, g["bo"])
+    linear_wgrad_(dzd1, ctx, g["o"])
+    dctx = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=ctx.shape[1])
     dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
     if g.get("bqkv") is not None:
         ops.colsum_(dqkv, g["bqkv"])
@@ -138,24 +163,25 @@ def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE, shadow: dict
 
 
 def sasrec_forward(p: dict, prep, x_in: torch.Tensor, log_mask: torch.Tensor, heads: int, need_grad: bool,
-                   prefix: str = UE):
+                   prefix: str = UE, drop: DropCfg = NO_DROP):
     """x_in [B, S, D] compute dtype (contiguous), log_mask float [B, S] -> [B*S, D]."""
     B, S, D = x_in.shape
     cfg = LayerCfg(H=D, heads=heads, T=S, act=ACT_RELU, eps=1e-6, causal=True, mask_value=-1e9)
     keep = log_mask.to(torch.float32).contiguous()
     x, z0, mean0, rstd0 = ops.layernorm_fwd(x_in.view(B * S, D), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"],
-                                            1e-6, pos=p[prefix + "position_embedding.weight"], pos_period=S)
+                                            1e-6, pos=p[prefix + "position_embedding.weight"], pos_period=S,
+                                            p_out=drop.p_hidden, seed_out=drop.site(0))
     saved_layers = []
-    for w in prep:
-        x, sv = layer_forward(cfg, w, x, keep, B, need_grad)
+    for l, w in enumerate(prep):
+        x, sv = layer_forward(cfg, w, x, keep, B, need_grad, drop, 1 + 3 * l)
         saved_layers.append(sv)
-    saved = (cfg, z0, mean0, rstd0, saved_layers, S) if need_grad else None
+    saved = (cfg, z0, mean0, rstd0, saved_layers, S, drop) if need_grad else None
     return x, saved
 
 
 def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefix: str = UE):
     """grads: name -> fp32 buffer (accumulated).  Returns d(x_in) [B*S, D]."""
-    cfg, z0, mean0, rstd0, saved_layers, S = saved
+    cfg, z0, mean0, rstd0, saved_layers, S, drop = saved
     da, db = dout, None
     for l in reversed(range(len(prep))):
         a, f = sasrec_layer_names(l, prefix)
@@ -171,8 +197,8 @@ def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefi
         da, db = layer_backward(cfg, prep[l], saved_layers[l], da, db, g)
         if not fused:   # hand the three row blocks out as the parameters' gradients (views, no arithmetic)
             grads[a + "w_Q.weight"], grads[a + "w_K.weight"], grads[a + "w_V.weight"] = dqkv[:D], dqkv[D:2 * D], dqkv[2 * D:]
-    dz0 = ops.layernorm_bwd(da, db, z0, mean0, rstd0, p[prefix + "layer_norm.weight"], grads[prefix + "layer_norm.weight"],
-                            grads[prefix + "layer_norm.bias"])
+    dz0, _ = ops.layernorm_bwd(da, db, z0, mean0, rstd0, p[prefix + "layer_norm.weight"], grads[prefix + "layer_norm.weight"],
+                               grads[prefix + "layer_norm.bias"], p_out=drop.p_hidden, seed_out=drop.site(0))
     ops.pos_grad_(dz0, grads[prefix + "position_embedding.weight"], S)
     return dz0
 
@@ -203,7 +229,7 @@ def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict |
 
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
-                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE):
+                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D]."""
     bm = prefix + "bert_model."
     Nc, T2 = text.shape
@@ -216,23 +242,23 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     x, z_e, mean_e, rstd_e = ops.bert_embed_fwd(ids32, p[bm + "embeddings.word_embeddings.weight"],
                                                 p[bm + "embeddings.position_embeddings.weight"], type0,
                                                 p[bm + "embeddings.LayerNorm.weight"], p[bm + "embeddings.LayerNorm.bias"],
-                                                eps, T, dtype)
+                                                eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
     saved_layers = []
-    for w in prep["layers"]:
-        x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad)
+    for l, w in enumerate(prep["layers"]):
+        x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
         saved_layers.append(sv)
     cls = torch.empty((Nc, H), device=x.device, dtype=dtype)
     ops.strided_rows_copy(x, cls, Nc, H, T, 1)
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
-    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H) if need_grad else None
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop) if need_grad else None
     return item, saved
 
 
 def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = TE, pad_id: int = 0):
     bm = prefix + "bert_model."
-    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H = saved
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop = saved
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
     linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
@@ -257,8 +283,9 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             for i, n in enumerate(("query", "key", "value")):
                 grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
                 grads[L + f"attention.self.{n}.bias"] = dbqkv[i * H:(i + 1) * H]
-    dz_e = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
-                             grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"])
+    dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
+                                grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
+                                p_out=drop.p_hidden, seed_out=drop.site(0))
     ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],
                         grads[bm + "embeddings.position_embeddings.weight"],
                         grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T)

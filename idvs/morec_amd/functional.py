@@ -20,14 +20,14 @@ class SasrecFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_in, log_mask, cfg, *params):
-        names, heads, n_layers, dtype, prefix = cfg
+        names, heads, n_layers, dtype, prefix, drop = cfg
         p = dict(zip(names, params))
         need = any(ctx.needs_input_grad)
         x = x_in.contiguous()
         if x.dtype != dtype:
             x = ops.cast(x, dtype)
         prep = engine.sasrec_prepare(p, n_layers, dtype, prefix)
-        out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix)
+        out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix, drop)
         ctx.stuff = (p, prep, saved, names, prefix, x_in.dtype, tuple(x_in.shape))
         return out.view(x_in.shape)
 
@@ -50,11 +50,11 @@ class BertEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, text, cfg, *params):
-        names, heads, n_layers, dtype, prefix, eps, mask_value = cfg
+        names, heads, n_layers, dtype, prefix, eps, mask_value, drop = cfg
         p = dict(zip(names, params))
         need = any(ctx.needs_input_grad)
         prep = engine.bert_prepare(p, n_layers, dtype, prefix)
-        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix)
+        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop)
         ctx.stuff = (p, prep, saved, names, prefix)
         ctx.needs = ctx.needs_input_grad
         return item

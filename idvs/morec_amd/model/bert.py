@@ -67,10 +67,13 @@ class _Pooler(nn.Module):
 
 
 class HipBertModel(nn.Module):
-    def __init__(self, shape: BertShape, initializer_range: float = 0.02):
+    def __init__(self, shape: BertShape, initializer_range: float = 0.02, hidden_dropout_prob: float = 0.1,
+                 attention_probs_dropout_prob: float = 0.1):
         super().__init__()
         self.shape = shape
-        self.config = types.SimpleNamespace(hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
+        self.config = types.SimpleNamespace(hidden_dropout_prob=hidden_dropout_prob,
+                                            attention_probs_dropout_prob=attention_probs_dropout_prob,
+                                            hidden_size=shape.hidden_size, num_hidden_layers=shape.num_hidden_layers,
                                             num_attention_heads=shape.num_attention_heads,
                                             intermediate_size=shape.intermediate_size, vocab_size=shape.vocab_size,
                                             max_position_embeddings=shape.max_position_embeddings,
@@ -97,7 +100,8 @@ class HipBertModel(nn.Module):
                           num_attention_heads=c.num_attention_heads, intermediate_size=c.intermediate_size,
                           max_position_embeddings=c.max_position_embeddings, type_vocab_size=c.type_vocab_size,
                           layer_norm_eps=c.layer_norm_eps)
-        m = HipBertModel(shape)
+        m = HipBertModel(shape, hidden_dropout_prob=getattr(c, "hidden_dropout_prob", 0.1),
+                         attention_probs_dropout_prob=getattr(c, "attention_probs_dropout_prob", 0.1))
         missing, unexpected = m.load_state_dict(hf_model.state_dict(), strict=False)
         assert not missing, missing
         for (n1, p1), (n2, p2) in zip(m.named_parameters(), hf_model.named_parameters()):

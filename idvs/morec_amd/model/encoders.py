@@ -7,6 +7,7 @@ import torch.nn as nn
 from torch.nn.init import constant_, xavier_normal_
 
 from .. import functional as F_
+from ..engine import NO_DROP, DropCfg
 from ..ops import FLT_MIN_MASK
 from .bert import HipBertModel
 from .modules import TransformerEncoder
@@ -34,11 +35,11 @@ class User_Encoder(nn.Module):
             if module.bias is not None:
                 constant_(module.bias.data, 0)
 
-    def encode(self, input_embs, log_mask):
+    def encode(self, input_embs, log_mask, drop: DropCfg = NO_DROP):
         """[B, S, D] -> [B, S, D] in the compute dtype (internal path of ``Model.forward``)."""
         names, params = zip(*self.named_parameters())
         te = self.transformer_encoder
-        cfg = (names, te.n_heads, te.n_layers, self.compute_dtype, "transformer_encoder.")
+        cfg = (names, te.n_heads, te.n_layers, self.compute_dtype, "transformer_encoder.", drop)
         return F_.SasrecFn.apply(input_embs, log_mask, cfg, *params)
 
     def forward(self, input_embs, log_mask, local_rank=None):
@@ -54,11 +55,12 @@ class Text_Encoder(nn.Module):
         self.compute_dtype = compute_dtype or resolve_dtype()
         self.mask_value = FLT_MIN_MASK   # transformers >= 4.3x eager; set to -10000.0 for 4.20.1 behaviour
 
-    def encode(self, text):
+    def encode(self, text, drop: DropCfg = NO_DROP):
         c = self.bert_model.config
         named = [(n, p) for n, p in self.named_parameters() if ".pooler." not in n]
         names, params = zip(*named)
-        cfg = (names, c.num_attention_heads, c.num_hidden_layers, self.compute_dtype, "", c.layer_norm_eps, self.mask_value)
+        cfg = (names, c.num_attention_heads, c.num_hidden_layers, self.compute_dtype, "", c.layer_norm_eps, self.mask_value,
+               drop)
         return F_.BertEncoderFn.apply(text, cfg, *params)
 
     def forward(self, text):
@@ -83,9 +85,9 @@ class Bert_Encoder(nn.Module):
             'title': Text_Encoder(bert_model, args.embedding_dim, args.word_embedding_dim, resolve_dtype(args))})
         self.newsname = [name for name in set(args.news_attributes) & {'title', 'abstract', 'body'}]
 
-    def encode(self, news):
+    def encode(self, news, drop: DropCfg = NO_DROP):
         vecs = [self.text_encoders['title'].encode(
-            torch.narrow(news, 1, self.attributes2start[name], self.attributes2length[name]).contiguous())
+            torch.narrow(news, 1, self.attributes2start[name], self.attributes2length[name]).contiguous(), drop)
             for name in self.newsname]
         return vecs[0] if len(vecs) == 1 else torch.mean(torch.stack(vecs, dim=1), dim=1)
 

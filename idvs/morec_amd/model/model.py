@@ -34,6 +34,26 @@ class Model(nn.Module):
                                             compute_dtype=self.compute_dtype)
             xavier_normal_(self.id_embedding.weight.data)            # T/model/model.py:28 (overwrites the pad row too)
         self.criterion = nn.CrossEntropyLoss()                       # kept for attribute compatibility; unused
+        self._drop_calls = 0
+
+    def dropout_cfgs(self):
+        """Per-call dropout streams (training mode only).  SASRec uses ``args.drop_rate`` on hidden states and attention
+        probabilities (``T/model/modules.py:9,24,48``); BERT uses its own config's probabilities (HF)."""
+        if not self.training:
+            return engine.NO_DROP, engine.NO_DROP
+        self._drop_calls += 1
+        base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        if dist.is_available() and dist.is_initialized():
+            base = (base + dist.get_rank() * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        p = float(self.args.drop_rate)
+        d_user = engine.DropCfg(p, p, base ^ 0x5555555555555555) if p > 0 else engine.NO_DROP
+        d_item = engine.NO_DROP
+        if self.use_modal:
+            c = self.bert_encoder.text_encoders["title"].bert_model.config
+            ph, pa = float(getattr(c, "hidden_dropout_prob", 0.0)), float(getattr(c, "attention_probs_dropout_prob", 0.0))
+            if ph > 0 or pa > 0:
+                d_item = engine.DropCfg(ph, pa, base)
+        return d_item, d_user
 
     def _log_pop_table(self, device):
         if self._log_pop is None or self._log_pop.device != device:
@@ -41,17 +61,15 @@ class Model(nn.Module):
         return self._log_pop
 
     def forward(self, sample_items_id, sample_items, log_mask, local_rank=None):
-        if float(getattr(self.args, "drop_rate", 0.0)) > 0 and self.training and not getattr(self.args, "allow_no_dropout", False):
-            raise NotImplementedError("training-mode dropout is not implemented in the HIP path yet: use model.eval(), "
-                                      "drop_rate=0 or args.allow_no_dropout=True")
         D = self.args.embedding_dim
         ids = sample_items_id.view(-1)
+        d_item, d_user = self.dropout_cfgs()
         if self.use_modal:
-            score_embs = self.bert_encoder.encode(sample_items)
+            score_embs = self.bert_encoder.encode(sample_items, d_item)
         else:
             score_embs = self.id_embedding.encode(sample_items.view(-1))
         input_embs = score_embs.view(-1, self.max_seq_len + 1, D)
-        prec_vec = self.user_encoder.encode(input_embs[:, :-1, :], log_mask).reshape(-1, D)
+        prec_vec = self.user_encoder.encode(input_embs[:, :-1, :], log_mask, d_user).reshape(-1, D)
         ci = engine.ce_inputs_local(ids, log_mask, self._log_pop_table(ids.device))
         pooled = self.pool_negatives and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         mult = self.pool_loss_mult if self.pool_loss_mult is not None else (float(dist.get_world_size()) if pooled else 1.0)

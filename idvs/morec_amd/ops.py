@@ -99,26 +99,31 @@ def colsum_(x, out, M=None, N=None, ld=None):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, save_z=True, z_inplace=False):
+def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, save_z=True, z_inplace=False,
+                  p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
     _dev(x)
     M, N = x.shape
     y = torch.empty_like(x)
-    need_z = save_z and (bias is not None or res is not None or pos is not None)
+    need_z = save_z and (bias is not None or res is not None or pos is not None or p_in > 0)
     z = (x if z_inplace else torch.empty_like(x)) if need_z else None
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
     check(_lib.lib().morec_layernorm_fwd(_p(x), _p(bias), _p(res), _p(pos), pos_period, _p(gamma), _p(beta), eps, _p(z),
-                                         _p(y), _p(mean), _p(rstd), M, N, code(x.dtype), _stream()), "morec_layernorm_fwd")
+                                         _p(y), _p(mean), _p(rstd), M, N, code(x.dtype), p_in, seed_in, p_out, seed_out,
+                                         _stream()), "morec_layernorm_fwd")
     return y, (z if need_z else x), mean, rstd
 
 
-def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta):
+def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+    """Returns (dz, dzd): dz feeds the residual branch, dzd = dropout-backward of dz feeds the sub-layer (dzd is dz when p_in = 0)."""
     _dev(dy_a)
     M, N = z.shape
     dz = torch.empty_like(z)
-    check(_lib.lib().morec_layernorm_bwd(_p(dy_a), _p(dy_b), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dgamma),
-                                         _p(dbeta), M, N, code(z.dtype), _stream()), "morec_layernorm_bwd")
-    return dz
+    dzd = torch.empty_like(z) if p_in > 0 else None
+    check(_lib.lib().morec_layernorm_bwd(_p(dy_a), _p(dy_b), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dzd),
+                                         _p(dgamma), _p(dbeta), M, N, code(z.dtype), p_in, seed_in, p_out, seed_out,
+                                         _stream()), "morec_layernorm_bwd")
+    return dz, (dz if dzd is None else dzd)
 
 
 def pos_grad_(dz, dpos, period):
@@ -126,8 +131,8 @@ def pos_grad_(dz, dpos, period):
     check(_lib.lib().morec_pos_grad(_p(dz), _p(dpos), M, N, period, code(dz.dtype), _stream()), "morec_pos_grad")
 
 
-def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype):
-    return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype))
+def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0):
+    return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype), p_drop, seed)
 
 
 def attn_fwd(desc, qkv, key_keep):
@@ -144,7 +149,7 @@ def attn_bwd(desc, qkv, key_keep, dctx):
     return dqkv
 
 
-def bert_embed_fwd(ids32, word, pos, type0, gamma, beta, eps, T, dtype):
+def bert_embed_fwd(ids32, word, pos, type0, gamma, beta, eps, T, dtype, p_out=0.0, seed_out=0):
     M = ids32.numel()
     H = word.shape[1]
     z = torch.empty((M, H), device=word.device, dtype=dtype)
@@ -152,7 +157,8 @@ def bert_embed_fwd(ids32, word, pos, type0, gamma, beta, eps, T, dtype):
     mean = torch.empty(M, device=word.device, dtype=torch.float32)
     rstd = torch.empty(M, device=word.device, dtype=torch.float32)
     check(_lib.lib().morec_bert_embed_fwd(_p(ids32), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), eps, _p(z),
-                                          _p(y), _p(mean), _p(rstd), M, T, H, code(dtype), _stream()), "morec_bert_embed_fwd")
+                                          _p(y), _p(mean), _p(rstd), M, T, H, code(dtype), p_out, seed_out, _stream()),
+          "morec_bert_embed_fwd")
     return y, z, mean, rstd
 
 
@@ -223,6 +229,12 @@ def eval_rank(prec, item_emb, hist32, target32):
     check(_lib.lib().morec_eval_rank(_p(_dev(prec)), _p(_dev(item_emb)), _p(_dev(hist32)), hist32.shape[1], _p(target32),
                                      _p(rank), _p(ts), U, item_emb.shape[0], D, _stream()), "morec_eval_rank")
     return rank
+
+
+def dropout_keep_mask(n, p, seed, device="cuda"):
+    out = torch.empty(n, device=device, dtype=torch.uint8)
+    check(_lib.lib().morec_dropout_keep_mask(_p(out), n, p, seed, _stream()), "morec_dropout_keep_mask")
+    return out
 
 
 def probe(device="cuda"):

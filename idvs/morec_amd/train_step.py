@@ -164,17 +164,18 @@ class TrainStep:
             if ".pooler." not in n:
                 grads[n] = torch.zeros_like(t)
         ids = sample_items_id.view(-1)
+        d_item, d_user = m.dropout_cfgs()
         if m.use_modal:
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
             E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
-                                             self.bert_mask_value, engine.TE)
+                                             self.bert_mask_value, engine.TE, d_item)
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
             E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
         B = log_mask.shape[0]
         x_in = E.view(B, S + 1, D)[:, :-1, :].contiguous()
         prep_s = engine.sasrec_prepare(p, m.args.transformer_block, self.dtype, engine.UE, self.sh)
-        P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE)
+        P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE, d_user)
         ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
         n_valid = ci.row_valid.sum(dtype=torch.float32)
         Epool = E

@@ -78,17 +78,22 @@ int morec_act_bwd(const void* dy, const void* pre, void* out, size_t n, int act,
 int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * LayerNorm with fused pre-add:  z = x (+ bias[n]) (+ res[m,n]) (+ pos[m % pos_period, n]);
- * y = (z - mean) * rstd * gamma + beta.   (T/model/modules.py:17,63,93; HF BertSelfOutput /
- * BertOutput / BertEmbeddings LayerNorm).  z_out may be NULL (not needed) or alias x.
+ * LayerNorm with fused pre-add:  z = drop_in(x (+ bias[n])) (+ res[m,n]) (+ pos[m % pos_period, n]);
+ * y = drop_out((z - mean) * rstd * gamma + beta).   (T/model/modules.py:14-17,61-63,93-94; HF BertSelfOutput /
+ * BertOutput / BertEmbeddings).  z_out may be NULL (not needed) or alias x.
+ * Dropout is counter-based: element kept iff hash(seed, m*N + n) >= p * 2^32, scaled by 1/(1-p); p = 0 disables.
+ * drop_in  = the Dropout the reference applies to the sub-layer output before the residual add;
+ * drop_out = the Dropout applied to the LayerNorm output of the embedding stages.
  * ------------------------------------------------------------------------------------------ */
 int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
                         const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
-                        float* rstd, int M, int N, int dtype, void* stream);
-/* dz = LN'(dy_a + dy_b; z).  dgamma/dbeta are atomically accumulated (fp32, [N]).  dy_b may be NULL. */
+                        float* rstd, int M, int N, int dtype, float p_in, uint64_t seed_in, float p_out,
+                        uint64_t seed_out, void* stream);
+/* dz = LN'(drop_out'(dy_a + dy_b); z); dzd = drop_in'(dz) (required iff p_in > 0, else NULL).
+ * dgamma/dbeta are atomically accumulated (fp32, [N]).  dy_b may be NULL. */
 int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
-                        const float* gamma, void* dz, float* dgamma, float* dbeta, int M, int N, int dtype,
-                        void* stream);
+                        const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, int M, int N, int dtype,
+                        float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
 /* dpos[m % period, n] += dz[m, n]  (position-embedding gradient, fp32 atomics) */
 int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream);
 
@@ -104,6 +109,8 @@ typedef struct {
     int causal;
     float scale, mask_value;
     int dtype;
+    float p_drop;      /* dropout on the attention probabilities (0 = off) */
+    uint64_t seed;     /* element index = ((seq * n_heads + head) * 32 + i) * 32 + j */
 } morec_attn_desc;
 
 int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx, void* stream);
@@ -116,7 +123,7 @@ int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_k
 /* BERT embeddings: z = word[ids[m]] + pos[m % T] + type0;  y = LN(z)  (HF BertEmbeddings). */
 int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
                          const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
-                         float* rstd, int M, int T, int H, int dtype, void* stream);
+                         float* rstd, int M, int T, int H, int dtype, float p_out, uint64_t seed_out, void* stream);
 /* scatter dz into dword[ids[m]] (skipping pad_id: nn.Embedding padding_idx), dpos[m % T], dtype0 */
 int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0, int pad_id,
                          int M, int T, int H, int dtype, void* stream);
@@ -183,6 +190,9 @@ int morec_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_
 int morec_eval_rank(const float* prec, const float* item_emb, const int32_t* hist, int Hmax, const int32_t* target,
                     int32_t* rank, float* tscore_ws /* float[U] scratch */, int U, int n_items_plus1, int D,
                     void* stream);
+
+/* test hook: out[i] = 1 iff the dropout hash keeps element index i for (p, seed) */
+int morec_dropout_keep_mask(uint8_t* out, size_t n, float p, uint64_t seed, void* stream);
 
 /* diagnostics: dumps MFMA fragment layouts and ds_read_b64_tr_b16 semantics into out (int32[4096]) */
 int morec_probe(int32_t* out, void* stream);

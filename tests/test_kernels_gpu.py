@@ -129,7 +129,8 @@ def test_layernorm(dt, N):
     yr = torch.nn.functional.layer_norm(zs, (N,), gd, bd, 1e-6)
     (yr * (dy_a.double() + dy_b.double())).sum().backward()
     dgamma, dbeta = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
-    dz = ops.layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta)
+    dz, dzd = ops.layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta)
+    assert dzd is dz
     assert rel(dz, zs.grad) < tol(dt)
     assert rel(dgamma, gd.grad) < 1e-4 and rel(dbeta, bd.grad) < 1e-4
     dpos = torch.zeros(S, N, device=DEV)

@@ -95,6 +95,7 @@ def _modal(golden, prefix, bert_name, dtype):
     args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=shape.hidden_size, compute_dtype=dtype,
                      bert_model_load="bert_" + bert_name)
     m = load_det(Model(args, item_num, True, HipBertModel(shape), golden[prefix + "pop"])).to(DEV)
+    m.eval()   # goldens were captured with dropout off (RNG streams cannot match the reference's)
     ids = torch.from_numpy(golden[prefix + "ids"]).to(DEV)
     items = torch.from_numpy(golden[prefix + "content"][golden[prefix + "ids"].reshape(-1)]).to(DEV)
     lm = torch.from_numpy(golden[prefix + "log_mask"]).to(DEV)
@@ -196,6 +197,7 @@ def test_oracle_midsize_all_grads():
     pop[0] = 1
     args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=128, compute_dtype="fp32")
     m = load_det(Model(args, item_num, True, HipBertModel(shape), pop)).to(DEV)
+    m.eval()
     content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
     for i in range(1, item_num + 1):
         L = int(rng.integers(3, T + 1))

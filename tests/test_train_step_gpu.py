@@ -39,6 +39,7 @@ def _setup(dtype, use_modal=True, seed=0):
         ids[b, S + 1 - L:] = rng.integers(1, item_num + 1, L)
         lm[b, S + 1 - L:] = 1
     items = content[ids.reshape(-1)] if use_modal else ids.reshape(-1)
+    model.eval()   # parity runs have dropout off
     return model.to(DEV), ids, items, lm, pop, (S, D, shape)
 
 
