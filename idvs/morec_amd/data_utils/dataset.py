@@ -1,0 +1,85 @@
+"""Datasets / samplers with the reference's class names (``T/data_utils/dataset.py``)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class BuildTrainDataset(Dataset):
+    """``T/data_utils/dataset.py:10-36``: left-pad the user's train sequence with item 0 to S + 1 slots;
+    ``log_mask`` marks the S input positions that are real; modal runs gather the token rows."""
+
+    def __init__(self, u2seq, item_content, item_num, max_seq_len, use_modal):
+        self.u2seq, self.item_content, self.item_num = u2seq, item_content, item_num
+        self.max_seq_len = max_seq_len + 1
+        self.use_modal = use_modal
+
+    def __len__(self):
+        return len(self.u2seq)
+
+    def __getitem__(self, user_id):
+        seq = self.u2seq[user_id]
+        pad = self.max_seq_len - len(seq)
+        ids = torch.LongTensor([0] * pad + list(seq))
+        log_mask = torch.FloatTensor([0] * pad + [1] * (len(seq) - 1))
+        items = torch.LongTensor(self.item_content[ids]) if self.use_modal else ids
+        return ids, items, log_mask
+
+
+def collate_train_batch(u2seq, users, item_content, max_seq_len, use_modal):
+    """Vectorised equivalent of DataLoader(BuildTrainDataset) default collation for a list of users:
+    (ids int64 [B, S+1], items int64 [B, S+1, 2T] | [B, S+1], log_mask float32 [B, S])."""
+    B, L = len(users), max_seq_len + 1
+    ids = np.zeros((B, L), dtype=np.int64)
+    log_mask = np.zeros((B, max_seq_len), dtype=np.float32)
+    for r, u in enumerate(users):
+        seq = u2seq[u]
+        ids[r, L - len(seq):] = seq
+        log_mask[r, L - len(seq):] = 1.0
+    items = np.asarray(item_content)[ids] if use_modal else ids
+    return torch.from_numpy(ids), torch.from_numpy(np.ascontiguousarray(items)).long(), torch.from_numpy(log_mask)
+
+
+class BuildEvalDataset(Dataset):
+    """``T/data_utils/dataset.py:39-65`` (inputs are pre-computed item EMBEDDINGS; label is one-hot over items)."""
+
+    def __init__(self, u2seq, item_content, max_seq_len, item_num):
+        self.u2seq, self.item_content, self.item_num = u2seq, item_content, item_num
+        self.max_seq_len = max_seq_len + 1
+
+    def __len__(self):
+        return len(self.u2seq)
+
+    def __getitem__(self, user_id):
+        seq = self.u2seq[user_id]
+        tokens, target = seq[:-1], seq[-1]
+        pad = self.max_seq_len - len(seq)
+        log_mask = [0] * pad + [1] * len(tokens)
+        labels = np.zeros(self.item_num)
+        labels[target - 1] = 1.0
+        return torch.LongTensor([user_id]), self.item_content[[0] * pad + list(tokens)], torch.FloatTensor(log_mask), labels
+
+
+class SequentialDistributedSampler(torch.utils.data.sampler.Sampler):
+    """``T/data_utils/dataset.py:68-94``: contiguous shards, padded with the last index to a multiple of
+    batch_size * num_replicas."""
+
+    def __init__(self, dataset, batch_size, rank=None, num_replicas=None):
+        if num_replicas is None:
+            num_replicas = torch.distributed.get_world_size()
+        if rank is None:
+            rank = torch.distributed.get_rank()
+        self.dataset, self.num_replicas, self.rank, self.batch_size = dataset, num_replicas, rank, batch_size
+        self.num_samples = int(math.ceil(len(dataset) * 1.0 / batch_size / num_replicas)) * batch_size
+        self.total_size = self.num_samples * num_replicas
+
+    def __iter__(self):
+        idx = list(range(len(self.dataset)))
+        idx += [idx[-1]] * (self.total_size - len(idx))
+        return iter(idx[self.rank * self.num_samples:(self.rank + 1) * self.num_samples])
+
+    def __len__(self):
+        return self.num_samples

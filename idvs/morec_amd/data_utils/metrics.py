@@ -1,0 +1,100 @@
+"""Evaluation with the reference's entry points (``T/data_utils/metrics.py``): ``get_item_embeddings`` and
+``eval_model`` keep their signatures; the per-user Python loop + full argsort (``metrics.py:97-102,49-57``) is
+replaced by the count-greater HIP kernel (``morec_eval_rank``), the score matrix is never materialised."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .dataset import SequentialDistributedSampler
+
+
+def print_metrics(x, Log_file, v_or_t):
+    Log_file.info(v_or_t + "_results   {}".format("\t".join(["{:0.5f}".format(i * 100) for i in x])))
+
+
+def _module(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, local_rank):
+    """``metrics.py:60-74``: encode every item (row 0 = padding item) in eval mode, no grad -> fp32 [item_num+1, D].
+    Stays on the device (the reference round-trips through the CPU)."""
+    model.eval()
+    m = _module(model)
+    content = torch.as_tensor(np.asarray(item_content)).long()
+    outs = []
+    with torch.no_grad():
+        for s in range(0, content.shape[0], test_batch_size):
+            chunk = content[s:s + test_batch_size].to(local_rank)
+            outs.append(m.bert_encoder(chunk) if use_modal else m.id_embedding(chunk))
+    return torch.cat(outs, 0).float().detach()
+
+
+def metrics_from_ranks(ranks: torch.Tensor, topK: int = 10):
+    """Hit@K and nDCG@K per user from 1-based ranks (``metrics_topK``, ``metrics.py:49-57``)."""
+    hit = (ranks <= topK).float()
+    ndcg = torch.where(ranks <= topK, 1.0 / torch.log2(ranks.float() + 1.0), torch.zeros_like(hit))
+    return hit, ndcg
+
+
+def eval_ranks(model, user_history, eval_seq, item_embeddings, users, args, local_rank):
+    """1-based target ranks for ``users`` (list of user ids): user states from the SASRec encoder, ranks by the HIP kernel."""
+    m = _module(model)
+    S = args.max_seq_len
+    U = len(users)
+    D = item_embeddings.shape[1]
+    idx = np.zeros((U, S), dtype=np.int64)
+    lm = np.zeros((U, S), dtype=np.float32)
+    hmax = max(1, max(len(user_history[u]) for u in users))
+    hist = np.full((U, hmax), -1, dtype=np.int32)
+    target = np.zeros(U, dtype=np.int32)
+    for r, u in enumerate(users):
+        seq = eval_seq[u]
+        toks = seq[:-1]
+        idx[r, S - len(toks):] = toks
+        lm[r, S - len(toks):] = 1
+        h = np.asarray(user_history[u])
+        hist[r, :len(h)] = h
+        target[r] = seq[-1]
+    dev = item_embeddings.device
+    with torch.no_grad():
+        embs = item_embeddings[torch.from_numpy(idx).to(dev)]                      # [U, S, D] gather (plumbing)
+        prec = m.user_encoder(embs, torch.from_numpy(lm).to(dev), local_rank)[:, -1].float().contiguous()
+        return ops.eval_rank(prec, item_embeddings.contiguous(), torch.from_numpy(hist).to(dev),
+                             torch.from_numpy(target).to(dev)).long()
+
+
+def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, args, item_num, Log_file, v_or_t, local_rank):
+    """``metrics.py:77-107``: mean Hit@10 / nDCG@10 over all users (sharded over ranks like the reference's
+    SequentialDistributedSampler, gathered with all_gather).  Returns Hit@10."""
+    model.eval()
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    n_users = len(eval_seq)
+    users_all = list(range(n_users))
+    sampler = SequentialDistributedSampler(users_all, test_batch_size, rank=rank, num_replicas=world)
+    mine = list(iter(sampler))
+    item_embeddings = item_embeddings.to(local_rank)
+    hits, ndcgs = [], []
+    for s in range(0, len(mine), test_batch_size):
+        ranks = eval_ranks(model, user_history, eval_seq, item_embeddings, mine[s:s + test_batch_size], args, local_rank)
+        h, n = metrics_from_ranks(ranks)
+        hits.append(h)
+        ndcgs.append(n)
+    hit, ndcg = torch.cat(hits), torch.cat(ndcgs)
+    if world > 1:
+        parts_h = [torch.empty_like(hit) for _ in range(world)]
+        parts_n = [torch.empty_like(ndcg) for _ in range(world)]
+        dist.all_gather(parts_h, hit)
+        dist.all_gather(parts_n, ndcg)
+        hit, ndcg = torch.cat(parts_h)[:n_users], torch.cat(parts_n)[:n_users]
+    mean_eval = [hit.mean().item(), ndcg.mean().item()]
+    if Log_file is not None:
+        Log_file.info(v_or_t + "_methods   {}".format("\t".join(["Hit10", "nDCG10"])))
+        print_metrics(mean_eval, Log_file, v_or_t)
+    return mean_eval[0]

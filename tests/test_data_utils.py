@@ -1,0 +1,42 @@
+"""CPU tests: the product's preprocessing / collation against goldens captured from the reference."""
+import os
+
+import numpy as np
+import torch
+
+from idvs.morec_amd.data_utils import BuildTrainDataset, collate_train_batch, read_behaviors, read_news
+from morec_oracle import bookkeeping as bk
+
+
+def test_read_behaviors_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_read_behaviors.npz"))
+    a, b, c = read_news(os.path.join(golden_dir, "g2_items.tsv"))
+    item_num, id2dic, tr, va, te, hv, ht, name2id, pop = read_behaviors(os.path.join(golden_dir, "g2_users.tsv"), a, b, c,
+                                                                         int(g["S"]), int(g["min_seq_len"]), None)
+    assert item_num == int(g["item_num"]) and len(tr) == int(g["n_users"])
+    assert np.array_equal(np.asarray(pop, dtype=np.float64), g["pop"])          # bit-exact float64
+    assert name2id == dict(zip(g["names"].tolist(), g["name_ids"].tolist()))
+    for u in range(len(tr)):
+        assert np.array_equal(tr[u], g[f"train.{u}"]) and np.array_equal(va[u], g[f"valid.{u}"])
+        assert np.array_equal(te[u], g[f"test.{u}"])
+        assert np.array_equal(hv[u].numpy(), g[f"hv.{u}"]) and np.array_equal(ht[u].numpy(), g[f"ht.{u}"])
+
+
+def test_train_dataset_and_vector_collate(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_g4_id_tower.npz"))
+    for case in "abde":
+        ids, lm = g[f"{case}.ids"], g[f"{case}.log_mask"]
+        S = int(g[f"{case}.S"])
+        u2seq = {u: [int(v) for v in ids[u][-(int(lm[u].sum()) + 1):]] for u in range(ids.shape[0])}
+        content = np.arange(int(g[f"{case}.item_num"]) + 1)
+        ds = BuildTrainDataset(u2seq, content, int(g[f"{case}.item_num"]), S, use_modal=False)
+        for u in range(ids.shape[0]):
+            i, it, m = ds[u]
+            assert np.array_equal(i.numpy(), ids[u]) and np.array_equal(m.numpy(), lm[u]) and np.array_equal(it.numpy(), ids[u])
+            oi, om = bk.collate_train_sample(u2seq[u], S)
+            assert np.array_equal(oi, ids[u]) and np.array_equal(om, lm[u])
+        bi, bit, bm = collate_train_batch(u2seq, list(range(ids.shape[0])), content, S, False)
+        assert np.array_equal(bi.numpy(), ids) and np.array_equal(bm.numpy(), lm)
+        table = np.arange((int(g[f"{case}.item_num"]) + 1) * 4).reshape(-1, 4)
+        _, bit2, _ = collate_train_batch(u2seq, list(range(ids.shape[0])), table, S, True)
+        assert np.array_equal(bit2.numpy(), table[ids])
