@@ -1,0 +1,61 @@
+"""Command-line surface of ``T/parameters.py`` (same flags and defaults) plus what the reference forgot or
+what ROCm / torchrun need: ``--news`` (read by ``T/run.py:79,100`` but never declared), ``--local-rank`` (torch >= 2.0
+launcher spelling), and the MI355X-path switches."""
+import argparse
+import os
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # ============== data_dir ==============
+    p.add_argument("--mode", type=str, default="train")
+    p.add_argument("--item_tower", type=str, default="id")
+    p.add_argument("--root_data_dir", type=str, default="../")
+    p.add_argument("--dataset", type=str, default="MIND-small")
+    p.add_argument("--behaviors", type=str, default="behaviors_l5_tr_v.tsv")
+    p.add_argument("--news", type=str, default="news.tsv")
+    # ============== train parameters ==============
+    p.add_argument("--batch_size", type=int, default=64)
+    p.add_argument("--epoch", type=int, default=1)
+    p.add_argument("--lr", type=float, default=1e-5)
+    p.add_argument("--fine_tune_lr", type=float, default=1e-5)
+    p.add_argument("--l2_weight", type=float, default=0)
+    p.add_argument("--fine_tune_l2_weight", type=float, default=0)
+    p.add_argument("--drop_rate", type=float, default=0.1)
+    # ============== model parameters ==============
+    p.add_argument("--bert_model_load", type=str, default="bert-base-uncased")
+    p.add_argument("--freeze_paras_before", type=int, default=165)
+    p.add_argument("--word_embedding_dim", type=int, default=768)
+    p.add_argument("--embedding_dim", type=int, default=256)
+    p.add_argument("--num_attention_heads", type=int, default=2)
+    p.add_argument("--transformer_block", type=int, default=2)
+    p.add_argument("--max_seq_len", type=int, default=20)
+    p.add_argument("--min_seq_len", type=int, default=5)
+    # ============== switch and logging setting ==============
+    p.add_argument("--num_workers", type=int, default=12)
+    p.add_argument("--load_ckpt_name", type=str, default="None")
+    p.add_argument("--label_screen", type=str, default="None")
+    p.add_argument("--logging_num", type=int, default=8)
+    p.add_argument("--testing_num", type=int, default=1)
+    p.add_argument("--local_rank", "--local-rank", dest="local_rank", default=int(os.environ.get("LOCAL_RANK", -1)), type=int)
+    # ============== news information ==============
+    p.add_argument("--num_words_title", type=int, default=30)
+    p.add_argument("--num_words_abstract", type=int, default=50)
+    p.add_argument("--num_words_body", type=int, default=50)
+    p.add_argument("--news_attributes", type=str, default="title")
+    # ============== MI355X path ==============
+    p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"],
+                   help="bf16 MFMA operands / fp32 accumulate (default) or exact-fp32 MFMA parity mode")
+    p.add_argument("--pool_negatives", action="store_true", help="pool in-batch negatives over ranks (RCCL all-gather)")
+    p.add_argument("--fused_step", action="store_true",
+                   help="flat-arena TrainStep (fused AdamW, one gradient all-reduce) instead of DDP + torch.optim.AdamW")
+    p.add_argument("--synthetic", type=int, default=0, help="N > 0: train on N synthetic MIND-shaped users (no data files)")
+    p.add_argument("--synthetic_items", type=int, default=20000)
+    p.add_argument("--max_steps", type=int, default=0)
+    return p
+
+
+def parse_args(argv=None):
+    args = build_parser().parse_args(argv)
+    args.news_attributes = args.news_attributes.split(",")
+    return args

@@ -1,0 +1,166 @@
+"""Training driver with the shape of ``T/run.py``: ``train(args, use_modal, local_rank)``, ``run_eval``,
+``setup_seed`` and a ``__main__`` that works under ``torchrun`` on ROCm (RCCL behind backend ``'nccl'``).
+
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m idvs.morec_amd.run --item_tower modal \
+        --bert_model_load bert_base_uncased --synthetic 60000 --batch_size 128 --embedding_dim 512 --fused_step --pool_negatives
+
+Two optimisation paths: the reference's (DDP + torch.optim.AdamW on the drop-in ``Model``; ``T/run.py:148-162,241-247``
+without the fp16 GradScaler, which bf16 does not need) and ``--fused_step`` (``train_step.TrainStep``)."""
+from __future__ import annotations
+
+import logging
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from .data_utils import collate_train_batch, eval_model, get_item_embeddings, read_behaviors, read_news
+from .model import BertShape, HipBertModel, Model
+from .parameters import parse_args
+from .train_step import TrainStep
+
+Log = logging.getLogger("morec")
+
+
+def setup_seed(seed):   # T/run.py:307-314
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def synthetic_dataset(n_users, n_items, S, T, seed=12345):
+    """MIND-shaped synthetic data in the structures ``read_behaviors`` / ``get_doc_input_bert`` return."""
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, n_items + 1)
+    w /= w.sum()
+    perm = rng.permutation(n_items) + 1
+    lens = rng.integers(5, S + 4, n_users)
+    users_train, users_valid, users_test, hist_valid, hist_test = {}, {}, {}, {}, {}
+    counts = np.zeros(n_items + 1)
+    for u in range(n_users):
+        seq = [int(v) for v in perm[rng.choice(n_items, size=int(lens[u]), p=w)]]
+        users_train[u], users_valid[u], users_test[u] = seq[:-2], seq[-(S + 2):-1], seq[-(S + 1):]
+        np.add.at(counts, seq[:-2], 1)
+        hist_valid[u], hist_test[u] = torch.LongTensor(seq[:-2]), torch.LongTensor(seq[:-1])
+    counts[1:] += 1e-9
+    pop = np.append([1], counts[1:] / counts[1:].sum())
+    content = np.zeros((n_items + 1, 2 * T), dtype=np.int64)
+    tl = rng.integers(8, T + 1, n_items)
+    toks = rng.integers(1000, 30522, (n_items, T))
+    valid = np.arange(T)[None, :] < tl[:, None]
+    toks = np.where(valid, toks, 0)
+    toks[:, 0] = 101
+    toks[np.arange(n_items), tl - 1] = 102
+    content[1:, :T], content[1:, T:] = toks, valid
+    return n_items, content, users_train, users_valid, users_test, hist_valid, hist_test, pop
+
+
+def run_eval(model, item_content, user_history, users_eval, batch_size, item_num, use_modal, args, mode, local_rank):
+    t0 = time.time()
+    item_embeddings = get_item_embeddings(model, item_content, batch_size, args, use_modal, local_rank)
+    hit10 = eval_model(model, user_history, users_eval, item_embeddings, batch_size, args, item_num, Log, mode, local_rank)
+    Log.info("eval %.1f s, Hit10 %.5f" % (time.time() - t0, hit10 * 100))
+    return hit10
+
+
+def train(args, use_modal, local_rank):
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    S, T = args.max_seq_len, args.num_words_title
+    if args.synthetic > 0:
+        item_num, content, users_train, users_valid, users_test, hist_valid, hist_test, pop = synthetic_dataset(
+            args.synthetic, args.synthetic_items, S, T)
+        item_content = content if use_modal else np.arange(item_num + 1)
+    else:
+        a, b, c = read_news(os.path.join(args.root_data_dir, args.dataset, args.news))
+        item_num, _, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(
+            os.path.join(args.root_data_dir, args.dataset, args.behaviors), a, b, c, S, args.min_seq_len, Log)
+        if use_modal:
+            raise SystemExit("modal runs on real data need the tokenizer files of the reference's pretrained_models/ "
+                             "(read_news_bert + get_doc_input_bert are provided in data_utils.preprocess)")
+        item_content = np.arange(item_num + 1)
+    bert = None
+    if use_modal:
+        shape = BertShape.named(args.bert_model_load)
+        args.word_embedding_dim = shape.hidden_size              # T/run.py:55-72
+        bert = HipBertModel(shape)
+        pooler = {"pooler.dense.weight", "pooler.dense.bias"}
+        for index, (name, param) in enumerate(bert.named_parameters()):   # T/run.py:73-75
+            if index < args.freeze_paras_before or name in pooler:
+                param.requires_grad = False
+    model = Model(args, item_num, use_modal, bert, pop).to(local_rank)
+    users = list(users_train.keys())
+    steps_per_epoch = len(users) // (args.batch_size * world)
+    if args.fused_step:
+        stepper = TrainStep(model, lr=args.lr, fine_tune_lr=args.fine_tune_lr, l2_weight=args.l2_weight,
+                            fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives)
+        wrapped = model
+    else:
+        wrapped = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True) if world > 1 else model
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        groups = [{"params": [p for n, p in named if "bert_model" in n], "lr": args.fine_tune_lr, "weight_decay": args.fine_tune_l2_weight},
+                  {"params": [p for n, p in named if "bert_model" not in n], "lr": args.lr, "weight_decay": args.l2_weight}]
+        optimizer = optim.AdamW([g for g in groups if g["params"]])   # T/run.py:159-162
+    best, step = 0.0, 0
+    for ep in range(1, args.epoch + 1):
+        model.train()
+        order = np.random.default_rng(ep).permutation(len(users))      # DistributedSampler.set_epoch analogue
+        order = order[rank::world]
+        t0, loss_acc = time.time(), None
+        for b in range(steps_per_epoch):
+            batch_users = [users[i] for i in order[b * args.batch_size:(b + 1) * args.batch_size]]
+            ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
+            ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
+            items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
+            if args.fused_step:
+                loss = stepper.step(ids.view(-1), items, log_mask)
+            else:
+                optimizer.zero_grad()
+                loss = wrapped(ids.view(-1), items, log_mask, local_rank)
+                loss.backward()
+                optimizer.step()
+            loss_acc = loss.detach() if loss_acc is None else loss_acc + loss.detach()
+            step += 1
+            if args.max_steps and step >= args.max_steps:
+                break
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        mean_loss = float(loss_acc.item()) / max(1, b + 1)
+        if torch.isnan(torch.tensor(mean_loss)):                        # T/run.py:249-251
+            Log.info("NaN loss, stopping")
+            break
+        Log.info("epoch %d: %d steps, mean loss %.5f, %.1f user-seq/s" % (ep, b + 1, mean_loss, (b + 1) * args.batch_size * world / dt))
+        hit10 = run_eval(wrapped, item_content, hist_valid, users_valid, 512, item_num, use_modal, args, "valid", local_rank)
+        best = max(best, hit10)
+        if args.max_steps and step >= args.max_steps:
+            break
+    return best
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="[%(levelname)s %(asctime)s] %(message)s")
+    local_rank = args.local_rank if args.local_rank >= 0 else int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")                         # RCCL on ROCm (T/run.py:321)
+    setup_seed(12345)
+    use_modal = "modal" in args.item_tower
+    if dist.is_initialized() and dist.get_rank() != 0:
+        Log.setLevel(logging.WARNING)
+    best = train(args, use_modal, local_rank)
+    Log.info("max eval Hit10 %.5f" % (best * 100))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
