@@ -92,7 +92,8 @@ def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, 
         parts_n = [torch.empty_like(ndcg) for _ in range(world)]
         dist.all_gather(parts_h, hit)
         dist.all_gather(parts_n, ndcg)
-        hit, ndcg = torch.cat(parts_h)[:n_users], torch.cat(parts_n)[:n_users]
+        hit, ndcg = torch.cat(parts_h), torch.cat(parts_n)
+    hit, ndcg = hit[:n_users], ndcg[:n_users]       # drop the sampler's padding (metrics.py:33-37 ``[:num_total_examples]``)
     mean_eval = [hit.mean().item(), ndcg.mean().item()]
     if Log_file is not None:
         Log_file.info(v_or_t + "_methods   {}".format("\t".join(["Hit10", "nDCG10"])))
