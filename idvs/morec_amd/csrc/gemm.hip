@@ -209,22 +209,42 @@ extern "C" int morec_cast(const void* in, void* out, size_t n, int in_dtype, int
     return MOREC_OK;
 }
 
-// column sums: each block reduces a [rows_per_block x 256-column] slab, one atomicAdd per column per block
+// column sums: each block reduces a [rows_per_block x 64-column] slab with 4-element vector loads (16 column
+// groups x 16 row lanes), folds the row lanes through LDS and leaves ONE atomicAdd per column per block
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int M, int N,
                                                      int ld, int rows_per_block) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float part[16][65];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + cg * 4;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += io<T>::load1(in + (size_t)r * ld + n);
-    atomicAdd(out + n, s);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        for (int r = r0 + rl; r < r1; r += 16) {
+            float v[4];
+            io<T>::load4(in + (size_t)r * ld + n, v);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[rl][cg * 4 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += part[r][threadIdx.x];
+            atomicAdd(out + c, t);
+        }
+    }
 }
 
 extern "C" int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream) {
     if (!in || !out || M <= 0 || N <= 0) return MOREC_E_ARG;
-    const int rpb = 128;
-    dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+    if (N % 4 || ld % 4) return MOREC_E_ALIGN;
+    const int rpb = 512;
+    dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
         hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)in, out, M, N, ld, rpb);
