@@ -301,6 +301,10 @@ int check_desc(const morec_attn_desc* d) {
 }
 }  // namespace
 
+// bf16 fast path on the matrix cores (attention_mfma.hip); MOREC_E_UNSUPPORTED = shape outside it
+int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
+                           void* dqkv, bool backward, hipStream_t s);
+
 extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx,
                               void* stream) {
     int rc = check_desc(d);
@@ -310,6 +314,8 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
                make_drop(d->p_drop, d->seed)};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
     if (d->dtype == MOREC_F32)
         hipLaunchKernelGGL((attn_fwd_kernel<float, 64>), grid, block, 0, s, a);
     else if (d->dtype == MOREC_BF16)
@@ -329,6 +335,8 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
                d->mask_value, make_drop(d->p_drop, d->seed)};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
     if (d->dtype == MOREC_F32)
         hipLaunchKernelGGL((attn_bwd_kernel<float, 32>), grid, block, 0, s, a);
     else if (d->dtype == MOREC_BF16)

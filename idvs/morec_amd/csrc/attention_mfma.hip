@@ -1,0 +1,317 @@
+// attention_mfma.hip -- bf16 small-tile attention on the matrix cores (T <= 32, head width a multiple of 32).
+//
+// Same contract as attention.hip (which stays the exact-fp32 path): one wavefront per (sequence, head), no
+// forward state kept for the backward, counter-based dropout on the probabilities.  What changes is where
+// the arithmetic runs:
+//   * S = Q K^T and dP = dO V^T: v_mfma_f32_16x16x32_bf16 with both operands read d-contiguous (NT form)
+//     from LDS tiles, issued "swapped" so a lane ends up with S[query = qb*16 + (lane&15)]
+//     [key = kb*16 + 4*(lane>>4) + r] -- a whole softmax row lives in 4 lanes x 8 registers, the row
+//     max / sum are two shuffles (xor 16, 32);
+//   * the second products (P V, dS K, dS^T Q, P^T dO) contract over keys or queries, i.e. over the ROW index
+//     of the row-major LDS tiles: those fragments come from ds_read_b64_tr_b16 (hardware transpose read,
+//     semantics measured in profiles/r01_probe_mfma_trb16.txt: lane c of a 16-lane group receives
+//     element (c & 3) of the 8-byte words addressed by lanes 4j + (c >> 2), j = 0..3).  The k-slot <-> key
+//     permutation this induces is the same one the packed P / dS register fragments use, so nothing is shuffled.
+// LDS rows carry a 32-byte pad (pitch / 32 odd) which makes both the b128 and the transpose reads conflict-free.
+#include "common.hpp"
+
+namespace {
+constexpr int DCH = 64;                       // head-width chunk staged per pass (elements)
+constexpr int PITCH = DCH * 2 + 32;           // bytes per LDS tile row
+constexpr int TILE = 32 * PITCH;              // one [32 x DCH] bf16 tile
+constexpr int PP = 32 * 2 + 32;               // bytes per row of the [32 x 32] bf16 probability tiles
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+struct AttnMArgs {
+    const bf16* qkv;
+    const float* key_keep;
+    bf16* ctx;          // fwd: output; bwd: dctx input
+    bf16* dqkv;
+    int n_seq, T, n_heads, dh, causal;
+    float scale, mask_value;
+    DropRng drop;
+};
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf_bits(a) | ((uint32_t)f2bf_bits(b) << 16); }
+
+// stage rows [0, T) x columns [col0, col0 + DCH) of a row-major global matrix into an LDS tile (rows >= T zeroed)
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, size_t row0, int pitch, int col0, int ncols,
+                                           int Tlen, char* __restrict__ tile) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 8 + (lane >> 3), s = lane & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < Tlen && s * 8 < ncols) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * (size_t)pitch + col0 + s * 8);
+        *reinterpret_cast<uint4*>(tile + r * PITCH + s * 16) = v;
+    }
+}
+
+// NT fragment: 8 consecutive d of row (blk*16 + lane&15), d offset ks*32 + (lane>>4)*8
+__device__ __forceinline__ bf16x8_t frag_nt(const char* tile, int blk, int ks) {
+    const int lane = threadIdx.x;
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + (blk * 16 + (lane & 15)) * PITCH + (ks * 32 + (lane >> 4) * 8) * 2);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// transposed fragment of a row-major tile: lane (c = lane&15, g = lane>>4) receives, for column col0 + c, the rows
+// 4g .. 4g+3 (elements 0..3) and 16+4g .. 16+4g+3 (elements 4..7)
+__device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int pitch_bytes, int col0) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, g = lane >> 4;
+    const char* p0 = tile + (4 * g + (c >> 2)) * pitch_bytes + (col0 + 4 * (c & 3)) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * pitch_bytes));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// register fragment of a [query][key] quantity held as x[qb][kb][r]: k-slots (g, e) = keys 4g+e | 16+4g+(e-4)
+__device__ __forceinline__ bf16x8_t frag_regs(const f32x4_t (&x)[2]) {
+    const uint4 v = make_uint4(pack2(x[0][0], x[0][1]), pack2(x[0][2], x[0][3]), pack2(x[1][0], x[1][1]), pack2(x[1][2], x[1][3]));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// masked, scaled softmax (+ optional dropout mask out) of the lane's scores s[qb][kb][r]
+__device__ __forceinline__ void softmax_regs(f32x4_t (&s)[2][2], const AttnMArgs& a, const float* keep_row) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    float keep[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = kb * 16 + 4 * g + r;
+            keep[kb][r] = (j < a.T) ? keep_row[j] : 0.f;
+        }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int i = qb * 16 + c;
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kb * 16 + 4 * g + r;
+                const bool kept = (keep[kb][r] != 0.f) && (!a.causal || j <= i);
+                const float v = s[qb][kb][r] * a.scale + (kept ? 0.f : a.mask_value);
+                s[qb][kb][r] = (j < a.T) ? v : -INFINITY;
+                m = fmaxf(m, s[qb][kb][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (kb * 16 + 4 * g + r < a.T) ? expf(s[qb][kb][r] - m) : 0.f;
+                s[qb][kb][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = (i < a.T) ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qb][kb][r] *= inv;
+    }
+}
+
+__device__ __forceinline__ void drop_mask_regs(const DropRng& d, uint64_t tile, float (&m)[2][2][4]) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                m[qb][kb][r] = drop_keep(d, (tile * 32 + (uint64_t)(qb * 16 + c)) * 32 + (uint64_t)(kb * 16 + 4 * g + r))
+                                   ? d.inv_keep : 0.f;
+}
+
+// store the 4 consecutive d values of one (row, 16-col block) held by the lane
+__device__ __forceinline__ void store4d(bf16* dst, size_t row, int pitch, int col, const f32x4_t& o) {
+    uint2 v;
+    v.x = pack2(o[0], o[1]);
+    v.y = pack2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(dst + row * (size_t)pitch + col) = v;
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
+    __shared__ __attribute__((aligned(16))) char sQ[TILE];
+    __shared__ __attribute__((aligned(16))) char sK[TILE];
+    __shared__ __attribute__((aligned(16))) char sV[TILE];
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const size_t row0 = (size_t)seq * a.T;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t s[2][2] = {{zero, zero}, {zero, zero}};
+    const int nch = (a.dh + DCH - 1) / DCH;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
+        stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
+        stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
+        if (nch == 1) stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh, nc, a.T, sV);
+        __syncthreads();
+        for (int ks = 0; ks < nc / 32; ++ks) {
+            bf16x8_t qf[2] = {frag_nt(sQ, 0, ks), frag_nt(sQ, 1, ks)};
+            bf16x8_t kf[2] = {frag_nt(sK, 0, ks), frag_nt(sK, 1, ks)};
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    softmax_regs(s, a, a.key_keep + row0);
+    if (a.drop.thresh) {
+        float m[2][2][4];
+        drop_mask_regs(a.drop, blockIdx.x, m);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[qb][kb][r] *= m[qb][kb][r];
+    }
+    const bf16x8_t pf[2] = {frag_regs(s[0]), frag_regs(s[1])};
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
+        if (nch > 1) {
+            stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh + d0, nc, a.T, sV);
+            __syncthreads();
+        }
+        for (int db = 0; db < nc / 16; ++db) {
+            const bf16x8_t vf = frag_tr(sV, PITCH, db * 16);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const f32x4_t o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], zero, 0, 0, 0);
+                const int q = qb * 16 + c;
+                if (q < a.T) store4d(a.ctx, row0 + q, H, head * a.dh + d0 + db * 16 + 4 * g, o);
+            }
+        }
+        if (nch > 1) __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
+    __shared__ __attribute__((aligned(16))) char sQ[TILE];
+    __shared__ __attribute__((aligned(16))) char sK[TILE];
+    __shared__ __attribute__((aligned(16))) char sV[TILE];
+    __shared__ __attribute__((aligned(16))) char sO[TILE];
+    __shared__ __attribute__((aligned(16))) char sP[32 * PP];    // dropped probabilities  [query][key] bf16
+    __shared__ __attribute__((aligned(16))) char sS[32 * PP];    // dS                     [query][key] bf16
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const size_t row0 = (size_t)seq * a.T;
+    const bf16* dctx = a.ctx;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t s[2][2] = {{zero, zero}, {zero, zero}}, dp[2][2] = {{zero, zero}, {zero, zero}};
+    const int nch = (a.dh + DCH - 1) / DCH;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
+        stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
+        stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
+        stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh + d0, nc, a.T, sV);
+        stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
+        __syncthreads();
+        for (int ks = 0; ks < nc / 32; ++ks) {
+            bf16x8_t qf[2] = {frag_nt(sQ, 0, ks), frag_nt(sQ, 1, ks)};
+            bf16x8_t kf[2] = {frag_nt(sK, 0, ks), frag_nt(sK, 1, ks)};
+            bf16x8_t vf[2] = {frag_nt(sV, 0, ks), frag_nt(sV, 1, ks)};
+            bf16x8_t of[2] = {frag_nt(sO, 0, ks), frag_nt(sO, 1, ks)};
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+                    dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb], of[qb], dp[qb][kb], 0, 0, 0);
+                }
+        }
+        if (nch > 1) __syncthreads();
+    }
+    softmax_regs(s, a, a.key_keep + row0);
+    float msk[2][2][4];
+    if (a.drop.thresh) drop_mask_regs(a.drop, blockIdx.x, msk);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float delta = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (a.drop.thresh) dp[qb][kb][r] *= msk[qb][kb][r];     // dP = dP_dropped o mask / (1 - p)
+                delta += s[qb][kb][r] * dp[qb][kb][r];
+            }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dp[qb][kb][r] = s[qb][kb][r] * (dp[qb][kb][r] - delta) * a.scale;   // dS
+                if (a.drop.thresh) s[qb][kb][r] *= msk[qb][kb][r];                  // dV takes the dropped probabilities
+            }
+            const int q = qb * 16 + c, k0 = kb * 16 + 4 * g;
+            *reinterpret_cast<uint2*>(sP + q * PP + k0 * 2) = make_uint2(pack2(s[qb][kb][0], s[qb][kb][1]), pack2(s[qb][kb][2], s[qb][kb][3]));
+            *reinterpret_cast<uint2*>(sS + q * PP + k0 * 2) = make_uint2(pack2(dp[qb][kb][0], dp[qb][kb][1]), pack2(dp[qb][kb][2], dp[qb][kb][3]));
+        }
+    }
+    const bf16x8_t dsf[2] = {frag_regs(dp[0]), frag_regs(dp[1])};
+    __syncthreads();
+    // transposed [key][query-slot] fragments of dS and P for the two key blocks
+    const bf16x8_t dsT[2] = {frag_tr(sS, PP, 0), frag_tr(sS, PP, 16)};
+    const bf16x8_t pT[2] = {frag_tr(sP, PP, 0), frag_tr(sP, PP, 16)};
+    for (int ch = 0; ch < nch; ++ch) {
+        const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
+        if (nch > 1) {
+            __syncthreads();
+            stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
+            stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
+            stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
+            __syncthreads();
+        }
+        for (int db = 0; db < nc / 16; ++db) {
+            const bf16x8_t kt = frag_tr(sK, PITCH, db * 16);   // K [key slots][d]
+            const bf16x8_t qt = frag_tr(sQ, PITCH, db * 16);   // Q [query slots][d]
+            const bf16x8_t ot = frag_tr(sO, PITCH, db * 16);   // dO [query slots][d]
+            const int dcol = head * a.dh + d0 + db * 16 + 4 * g;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int r = b * 16 + c;
+                // dQ[query r][d] = sum_key dS[r][key] K[key][d]
+                const f32x4_t dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[b], zero, 0, 0, 0);
+                // dK[key r][d] = sum_query dS[query][r] Q[query][d];  dV[key r][d] = sum_query P_d[query][r] dO[query][d]
+                const f32x4_t dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsT[b], zero, 0, 0, 0);
+                const f32x4_t dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pT[b], zero, 0, 0, 0);
+                if (r < a.T) {
+                    store4d(a.dqkv, row0 + r, pitch, dcol, dq);
+                    store4d(a.dqkv, row0 + r, pitch, H + dcol, dk);
+                    store4d(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+// returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)
+int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
+                           void* dqkv, bool backward, hipStream_t s) {
+    if (d->dtype != MOREC_BF16 || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
+    AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
+                reinterpret_cast<bf16*>(dqkv), d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
+                make_drop(d->p_drop, d->seed)};
+    dim3 grid(d->n_seq * d->n_heads), block(64);
+    if (backward)
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, block, 0, s, a);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

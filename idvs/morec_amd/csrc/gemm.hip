@@ -160,11 +160,54 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
     }
 }
 
+// vectorised variant (4 elements per global access); needs C % 4 == 0 and both pitches % 4 == 0
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose4_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C,
+                                                         int ld_in, int ld_out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 16, c = c0 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && c < C) io<TI>::load4(in + (size_t)r * ld_in + c, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[ty + i * 16][tx * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 16, r = r0 + tx * 4;
+        if (c < C && r < R) {   // rows past R were zero-filled above, so a partial group writes zeros into the pad
+            const float v[4] = {tile[tx * 4 + 0][ty + i * 16], tile[tx * 4 + 1][ty + i * 16], tile[tx * 4 + 2][ty + i * 16],
+                                tile[tx * 4 + 3][ty + i * 16]};
+            io<TO>::store4(out + (size_t)c * ld_out + r, v);
+        }
+    }
+}
+
 extern "C" int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype,
                                int out_dtype, void* stream) {
     if (!in || !out || R <= 0 || C <= 0) return MOREC_E_ARG;
     dim3 grid((C + 63) / 64, (R + 63) / 64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = (C % 4 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) && (ld_out >= ((R + 3) & ~3)) &&
+                     ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec) {
+        if (in_dtype == MOREC_F32 && out_dtype == MOREC_F32)
+            hipLaunchKernelGGL((transpose4_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ld_in, ld_out);
+        else if (in_dtype == MOREC_F32 && out_dtype == MOREC_BF16)
+            hipLaunchKernelGGL((transpose4_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)in, (bf16*)out, R, C, ld_in, ld_out);
+        else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_BF16)
+            hipLaunchKernelGGL((transpose4_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, R, C, ld_in, ld_out);
+        else if (in_dtype == MOREC_BF16 && out_dtype == MOREC_F32)
+            hipLaunchKernelGGL((transpose4_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)in, (float*)out, R, C, ld_in, ld_out);
+        else
+            return MOREC_E_DTYPE;
+        MOREC_CHECK_LAUNCH();
+        return MOREC_OK;
+    }
     if (in_dtype == MOREC_F32 && out_dtype == MOREC_F32)
         hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, R, C, ld_in, ld_out);
     else if (in_dtype == MOREC_F32 && out_dtype == MOREC_BF16)

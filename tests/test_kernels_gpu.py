@@ -104,9 +104,12 @@ def test_transpose_cast_colsum(dt):
     wt = ops.transpose(w, out_dtype=torch.bfloat16)
     assert torch.equal(wt[:, :96], w.t().to(torch.bfloat16))
     assert torch.equal(ops.cast(w, torch.bfloat16), w.to(torch.bfloat16))
-    out = torch.zeros(170, device=DEV)
-    ops.colsum_(x, out)
-    assert rel(out, x.double().sum(0)) < 1e-5
+    x4 = rnd(1300, 172, dt=dt, seed=3)
+    out = torch.zeros(172, device=DEV)
+    ops.colsum_(x4, out)
+    assert rel(out, x4.double().sum(0)) < 1e-5
+    xt4 = ops.transpose(x4)          # vectorised path (C % 4 == 0), R % 8 != 0 -> zero pad
+    assert xt4.shape == (172, 1304) and torch.equal(xt4[:, :1300], x4.t()) and (xt4[:, 1300:] == 0).all()
 
 
 @pytest.mark.parametrize("dt", DT)
