@@ -100,6 +100,7 @@ def test_model_directional_derivative_under_dropout():
         for k, v in m.state_dict().items():
             v.copy_(torch.from_numpy(det_param(k, tuple(v.shape))))
     m = m.to(DEV).train()
+    torch.manual_seed(20260927)     # the dropout stream derives from torch.initial_seed(): make the test order-independent
     content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
     for i in range(1, item_num + 1):
         L = int(rng.integers(3, T + 1))
@@ -123,10 +124,12 @@ def test_model_directional_derivative_under_dropout():
     assert abs(l0.item() - l_eval) > 1e-3 and math.isfinite(l0.item())     # dropout really is active
     l0.backward()
     params = [p for n, p in m.named_parameters() if p.grad is not None]
-    g = torch.Generator().manual_seed(5)
-    vs = [torch.randn(p.shape, generator=g).to(DEV) for p in params]
-    dot = sum((p.grad.double() * v.double()).sum().item() for p, v in zip(params, vs))
-    eps = 2e-3
+    # probe along the (normalised) gradient itself: the largest first-order signal for the smallest step, which keeps
+    # the fp32 finite difference out of both the round-off and the curvature / ReLU-kink regimes
+    gnorm = math.sqrt(sum((p.grad.double() ** 2).sum().item() for p in params))
+    vs = [(p.grad / gnorm).clone() for p in params]
+    dot = gnorm
+    eps = 1e-2
     with torch.no_grad():
         for p, v in zip(params, vs):
             p.add_(eps * v)
