@@ -17,9 +17,8 @@ struct GemmArgs {
     float alpha;
 };
 
-template <typename TI, typename TO, int KSUB>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
-    using G = GemmTile<TI, KSUB>;
+template <typename G, typename TI, typename TO>
+__global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
     const int wg = xcd_remap(blockIdx.x, nwg);
@@ -28,25 +27,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[G::MI][G::NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < G::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < G::NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    gemm_mainloop<TI, KSUB>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb,
-                            m0, n0, kbeg, kend, smem, acc);
+    gemm_mainloop_cfg<G, TI>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb, m0,
+                             n0, kbeg, kend, smem, acc);
 
     TO* C = reinterpret_cast<TO*>(p.C);
     TO* aux = reinterpret_cast<TO*>(p.aux_out);
     const TO* din = reinterpret_cast<const TO*>(p.dact_in);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = acc_row(m0, mi);
+    for (int mi = 0; mi < G::MI; ++mi) {
+        const int m = acc_row_cfg<G>(m0, mi);
         if (m >= p.M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = acc_col(n0, ni);
+        for (int ni = 0; ni < G::NI; ++ni) {
+            const int n = acc_col_cfg<G>(n0, ni);
             if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
             float v[4];
 #pragma unroll
@@ -94,9 +93,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <typename TI, typename TO, int KSUB>
-static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
-    using G = GemmTile<TI, KSUB>;
+template <typename G, typename TI, typename TO>
+static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
     int kchunk = (d->K + split - 1) / split;
     kchunk = ((kchunk + G::KE - 1) / G::KE) * G::KE;
@@ -106,14 +104,22 @@ static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     a.tiles_n = (d->N + G::TN - 1) / G::TN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<TI, TO, KSUB>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, zs);
-    hipLaunchKernelGGL((gemm_nt_kernel<TI, TO, KSUB>), grid, dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
+}
+
+// 256 x 256 tiles when the problem is large enough to fill the 256 CUs with them, 128 x 128 tiles otherwise
+template <typename TI, typename TO>
+static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+    const long big_tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->split_k < 1 ? 1 : d->split_k);
+    if (big_tiles >= 192) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
+    return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
 }
 
 extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
@@ -132,9 +138,9 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float, 2>(d, a, s);
-    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16, 2>(d, a, s);
-    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_F32) return launch_gemm<bf16, float, 2>(d, a, s);
+    if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float>(d, a, s);
+    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16>(d, a, s);
+    if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_F32) return launch_gemm<bf16, float>(d, a, s);
     return MOREC_E_DTYPE;
 }
 

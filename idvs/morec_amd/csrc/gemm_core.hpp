@@ -17,21 +17,28 @@
 #pragma once
 #include "common.hpp"
 
-template <typename T, int KSUB>
-struct GemmTile {
-    static constexpr int TM = 128, TN = 128, THREADS = 256;
+// Tile configuration: WM x WN waves, each owning MI x NI MFMA 16x16 tiles.
+//   GemmTile<T, 2>                 128 x 128, 4 waves  (small problems, fused CE / eval tiles)
+//   GemmTileCfg<T, 2, 4, 8, 4>     256 x 256, 8 waves  (the encoder GEMMs: twice the MFMA work per staged byte)
+template <typename T, int WM_, int WN_, int MI_, int NI_>
+struct GemmTileCfg {
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
+    static constexpr int TM = WM * MI * 16, TN = WN * NI * 16, NWAVES = WM * WN, THREADS = 64 * NWAVES;
+    static constexpr int KSUB = 2;
     static constexpr int KB = 64 * KSUB;               // bytes of K per row per stage
     static constexpr int KE = KB / (int)sizeof(T);     // elements of K per stage
     static constexpr int EPV = 16 / (int)sizeof(T);    // elements per 16-byte vector
-    static constexpr int SLOTS = KB / 16;              // 16-byte slots per row (8 at KSUB = 2)
-    static constexpr int ROWS_PER_DMA = 64 / SLOTS;    // rows covered by one 1-KiB wave-level LDS-DMA
-    static constexpr int DMA_PER_OP = 128 / ROWS_PER_DMA;        // wave-instructions per operand per stage
-    static constexpr int DMA_PER_WAVE = DMA_PER_OP / 4;
-    static constexpr int OP_BYTES = 128 * KB;          // un-padded: the LDS image of an LDS-DMA is lane-linear
-    static constexpr int STAGE_BYTES = 2 * OP_BYTES;
+    static constexpr int SLOTS = KB / 16;              // 16-byte slots per row (8)
+    static constexpr int ROWS_PER_DMA = 64 / SLOTS;    // rows covered by one 1-KiB wave-level LDS-DMA (8)
+    static constexpr int ADMA_PER_WAVE = TM / ROWS_PER_DMA / NWAVES;
+    static constexpr int BDMA_PER_WAVE = TN / ROWS_PER_DMA / NWAVES;
+    static constexpr int A_BYTES = TM * KB, B_BYTES = TN * KB;   // un-padded: an LDS-DMA image is lane-linear
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-    static_assert(KSUB == 2, "the XOR swizzle below assumes 8 slots (128-byte rows)");
+    static_assert(TM % (ROWS_PER_DMA * NWAVES) == 0 && TN % (ROWS_PER_DMA * NWAVES) == 0, "DMA split");
 };
+template <typename T, int KSUB>
+using GemmTile = GemmTileCfg<T, 2, 2, 4, 4>;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -69,14 +76,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // (the destination stays linear).  Rows past M / N are clamped to the last valid row (their products land in
 // accumulator rows / columns that are never stored); a K tail that does not fill a stage goes through a
 // register-staged, zero-filling path.  Double-buffered: the DMA of tile t+1 flies while tile t is multiplied.
-template <typename T, int KSUB>
-__device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* __restrict__ B, int M, int N, int lda,
-                                              int ldb, int m0, int n0, int kbeg, int kend, char* smem,
-                                              f32x4_t (&acc)[4][4]) {
-    using G = GemmTile<T, KSUB>;
+template <typename G, typename T>
+__device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const T* __restrict__ B, int M, int N, int lda,
+                                                  int ldb, int m0, int n0, int kbeg, int kend, char* smem,
+                                                  f32x4_t (&acc)[G::MI][G::NI]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WN, wn = wave % G::WN;
     const int nk = (kend - kbeg + G::KE - 1) / G::KE;
     if (nk <= 0) return;
     const bool tail = ((kend - kbeg) % G::KE) != 0;
@@ -84,38 +90,46 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
     // per-lane source rows of this wave's DMA instructions (clamped) and the swizzled source slot
     const int drow = lane / G::SLOTS;                       // row within the 1-KiB piece
     const int pslot = lane % G::SLOTS;                      // physical slot this lane's 16 B land in
-    const T* asrc[G::DMA_PER_WAVE];
-    const T* bsrc[G::DMA_PER_WAVE];
+    const T* asrc[G::ADMA_PER_WAVE];
+    const T* bsrc[G::BDMA_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < G::DMA_PER_WAVE; ++i) {
-        const int row = (wave * G::DMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
-        const int lslot = pslot ^ (row & 7);                // logical 16-byte column of the tile row
-        asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + lslot * G::EPV;
-        bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + lslot * G::EPV;
+    for (int i = 0; i < G::ADMA_PER_WAVE; ++i) {
+        const int row = (wave * G::ADMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
+        asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + (pslot ^ (row & 7)) * G::EPV;
+    }
+#pragma unroll
+    for (int i = 0; i < G::BDMA_PER_WAVE; ++i) {
+        const int row = (wave * G::BDMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
+        bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + (pslot ^ (row & 7)) * G::EPV;
     }
     auto dma = [&](int stage, int k0) {
-        char* base = smem + stage * G::STAGE_BYTES + (wave * G::DMA_PER_WAVE) * 1024;
+        char* abase = smem + stage * G::STAGE_BYTES + (wave * G::ADMA_PER_WAVE) * 1024;
+        char* bbase = smem + stage * G::STAGE_BYTES + G::A_BYTES + (wave * G::BDMA_PER_WAVE) * 1024;
 #pragma unroll
-        for (int i = 0; i < G::DMA_PER_WAVE; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k0), (lptr_t)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k0), (lptr_t)(base + G::OP_BYTES + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < G::ADMA_PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k0), (lptr_t)(abase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::BDMA_PER_WAVE; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k0), (lptr_t)(bbase + i * 1024), 16, 0, 0);
     };
     // K tail: plain loads with zero fill, written to the same swizzled image
     auto stage_tail = [&](int stage, int k0) {
         char* base = smem + stage * G::STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < (128 * G::SLOTS) / G::THREADS; ++i) {
+        for (int i = 0; i < (G::TM * G::SLOTS) / G::THREADS; ++i) {
             const int v = tid + G::THREADS * i;
             const int row = v / G::SLOTS, lslot = v % G::SLOTS;
-            const int k = k0 + lslot * G::EPV;
-            const bool kin = k < kend;
-            const int am = m0 + row, bn = n0 + row;
-            const uint4 ra = (kin && am < M) ? *reinterpret_cast<const uint4*>(A + (size_t)am * lda + k) : make_uint4(0, 0, 0, 0);
-            const uint4 rb = (kin && bn < N) ? *reinterpret_cast<const uint4*>(B + (size_t)bn * ldb + k) : make_uint4(0, 0, 0, 0);
-            const int off = row * G::KB + ((lslot ^ (row & 7)) * 16);
-            *reinterpret_cast<uint4*>(base + off) = ra;
-            *reinterpret_cast<uint4*>(base + G::OP_BYTES + off) = rb;
+            const int k = k0 + lslot * G::EPV, am = m0 + row;
+            const uint4 ra = (k < kend && am < M) ? *reinterpret_cast<const uint4*>(A + (size_t)am * lda + k) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(base + row * G::KB + ((lslot ^ (row & 7)) * 16)) = ra;
+        }
+#pragma unroll
+        for (int i = 0; i < (G::TN * G::SLOTS) / G::THREADS; ++i) {
+            const int v = tid + G::THREADS * i;
+            const int row = v / G::SLOTS, lslot = v % G::SLOTS;
+            const int k = k0 + lslot * G::EPV, bn = n0 + row;
+            const uint4 rb = (k < kend && bn < N) ? *reinterpret_cast<const uint4*>(B + (size_t)bn * ldb + k) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(base + G::A_BYTES + row * G::KB + ((lslot ^ (row & 7)) * 16)) = rb;
         }
     };
     auto stage = [&](int st, int t) {
@@ -130,31 +144,41 @@ __device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) stage(cur ^ 1, t + 1);
-        const char* as = smem + cur * G::STAGE_BYTES + (wm * 64 + frow) * G::KB;
-        const char* bs = smem + cur * G::STAGE_BYTES + G::OP_BYTES + (wn * 64 + frow) * G::KB;
+        const char* as = smem + cur * G::STAGE_BYTES + (wm * G::MI * 16 + frow) * G::KB;
+        const char* bs = smem + cur * G::STAGE_BYTES + G::A_BYTES + (wn * G::NI * 16 + frow) * G::KB;
 #pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
+        for (int ks = 0; ks < G::KSUB; ++ks) {
             const int phys = ((ks * 4 + (lane >> 4)) ^ (frow & 7)) * 16;
-            uint4 fa[4], fb[4];
+            uint4 fa[G::MI], fb[G::NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const uint4*>(as + i * 16 * G::KB + phys);
-                fb[i] = *reinterpret_cast<const uint4*>(bs + i * 16 * G::KB + phys);
-            }
+            for (int i = 0; i < G::MI; ++i) fa[i] = *reinterpret_cast<const uint4*>(as + i * 16 * G::KB + phys);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int i = 0; i < G::NI; ++i) fb[i] = *reinterpret_cast<const uint4*>(bs + i * 16 * G::KB + phys);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) mfma_step<T>(acc[mi][ni], fb[ni], fa[mi]);
+            for (int mi = 0; mi < G::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < G::NI; ++ni) mfma_step<T>(acc[mi][ni], fb[ni], fa[mi]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }
 
+template <typename T, int KSUB>
+__device__ __forceinline__ void gemm_mainloop(const T* __restrict__ A, const T* __restrict__ B, int M, int N, int lda,
+                                              int ldb, int m0, int n0, int kbeg, int kend, char* smem,
+                                              f32x4_t (&acc)[4][4]) {
+    gemm_mainloop_cfg<GemmTile<T, KSUB>, T>(A, B, M, N, lda, ldb, m0, n0, kbeg, kend, smem, acc);
+}
+
 // coordinates of accumulator element (mi, ni) of this lane: m (one row), n (first of 4 consecutive columns)
-__device__ __forceinline__ int acc_row(int m0, int mi) {
-    return m0 + ((threadIdx.x >> 6) >> 1) * 64 + mi * 16 + (threadIdx.x & 15);
+template <typename G>
+__device__ __forceinline__ int acc_row_cfg(int m0, int mi) {
+    return m0 + ((threadIdx.x >> 6) / G::WN) * (G::MI * 16) + mi * 16 + (threadIdx.x & 15);
 }
-__device__ __forceinline__ int acc_col(int n0, int ni) {
-    return n0 + ((threadIdx.x >> 6) & 1) * 64 + ni * 16 + ((threadIdx.x & 63) >> 4) * 4;
+template <typename G>
+__device__ __forceinline__ int acc_col_cfg(int n0, int ni) {
+    return n0 + ((threadIdx.x >> 6) % G::WN) * (G::NI * 16) + ni * 16 + ((threadIdx.x & 63) >> 4) * 4;
 }
+__device__ __forceinline__ int acc_row(int m0, int mi) { return acc_row_cfg<GemmTile<float, 2>>(m0, mi); }
+__device__ __forceinline__ int acc_col(int n0, int ni) { return acc_col_cfg<GemmTile<float, 2>>(n0, ni); }

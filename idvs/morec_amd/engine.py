@@ -67,8 +67,19 @@ def prepare_linear(weight: torch.Tensor, dtype: torch.dtype, shadow: torch.Tenso
     return PreparedLinear(w.contiguous(), wt)
 
 
-def _splitk(tiles: int, K: int) -> int:
-    return max(1, min(64, (1024 + tiles - 1) // tiles, K // 512 if K >= 1024 else 1))
+def _cdiv(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+def _splitk(N: int, K: int, Mp: int) -> int:
+    """Split factor over the token dimension for dW[N, K] = dY^T X so that the launch fills the 256 CUs once with
+    256 x 256 tiles (1 workgroup of 8 waves per CU) or, for small weights, twice with 128 x 128 tiles."""
+    big = _cdiv(N, 256) * _cdiv(K, 256)
+    s = max(1, min(round(256 / big), Mp // 1024)) if big <= 256 else 1
+    if big * s >= 192:
+        return s
+    small = _cdiv(N, 128) * _cdiv(K, 128)
+    return max(1, min(round(512 / small), max(1, Mp // 512), 64))
 
 
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
@@ -76,8 +87,7 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt
     N, K, Mp = dyt.shape[0], xt.shape[0], dyt.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    ops.gemm_nt(dyt, xt, out=dw, accumulate=2, split_k=_splitk(tiles, Mp))
+    ops.gemm_nt(dyt, xt, out=dw, accumulate=2, split_k=_splitk(N, K, Mp))
     return dyt, xt
 
 

@@ -25,8 +25,8 @@ for dt in (torch.bfloat16, torch.float32):
     for (N, K, M) in [(2304, 768, 80640), (3072, 768, 80640), (768, 3072, 80640)]:
         a = torch.randn(N, M, device=dev).to(dt); b = torch.randn(K, M, device=dev).to(dt)
         out = torch.zeros(N, K, device=dev)
-        tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        sk = max(1, min(64, (1024 + tiles - 1) // tiles))
+        from idvs.morec_amd.engine import _splitk
+        sk = _splitk(N, K, M)
         ms = timeit(lambda: ops.gemm_nt(a, b, out=out, accumulate=2, split_k=sk))
         print(f"gemm dW  {str(dt)[6:]:8s} {N}x{K}x{M} splitk={sk}: {ms:.3f} ms  {2*M*N*K/ms/1e9:.1f} TFLOP/s")
     M, H = 80640, 768
