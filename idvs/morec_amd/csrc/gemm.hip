@@ -15,6 +15,7 @@ struct GemmArgs {
     int kchunk;
     int tiles_m, tiles_n;
     float alpha;
+    int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
 };
 
 template <typename G, typename TI, typename TO>
@@ -39,6 +40,82 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     TO* C = reinterpret_cast<TO*>(p.C);
     TO* aux = reinterpret_cast<TO*>(p.aux_out);
     const TO* din = reinterpret_cast<const TO*>(p.dact_in);
+    const int lane = threadIdx.x & 63, c16 = lane & 15, g4 = lane >> 4;
+    const int wave = threadIdx.x >> 6, wm = wave / G::WN, wn = wave % G::WN;
+
+    // value of accumulator element block (mi, ni) after the fused epilogue; `pre` receives acc*alpha + bias
+    auto finish = [&](int mi, int ni, int m, int n, float (&v)[4], float (&pre)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pre[r] = v[r];
+        if (p.act == MOREC_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        } else if (p.act == MOREC_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.dact != MOREC_ACT_NONE) {
+            float u[4];
+            io<TO>::load4(din + (size_t)m * p.ldc + n, u);
+            if (p.dact == MOREC_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
+            }
+        }
+    };
+
+    // Fast path: the output tile goes through LDS (free after the main loop) so that every global store is a
+    // full 16-byte lane write along a row -- the direct form (8-byte pieces, 16 different rows per wave
+    // instruction) is store-issue bound and cost more than the K = 768 main loop itself.
+    constexpr int EPV_O = 16 / (int)sizeof(TO);
+    if (p.accumulate == 0 && p.vec_store) {
+        constexpr int ROWB = G::TN * (int)sizeof(TO) + 16;                    // LDS pitch of a staged output row
+        constexpr int NP = (G::TM * ROWB + G::LDS_BYTES - 1) / G::LDS_BYTES;  // passes needed
+        constexpr int NPASS = NP <= 1 ? 1 : (NP <= 2 ? 2 : (NP <= 4 ? 4 : 8));
+        constexpr int MIP = G::MI / NPASS;                                    // mi blocks per pass
+        static_assert(MIP >= 1 && G::WM * MIP * 16 * ROWB <= G::LDS_BYTES, "output staging does not fit");
+        constexpr int RPP = G::WM * MIP * 16;                                 // rows per pass
+        constexpr int VPR = G::TN * (int)sizeof(TO) / 16;                     // 16-byte vectors per row
+        for (int which = 0; which < 2; ++which) {                             // 0: aux (pre-activation), 1: C
+            TO* dst = which == 0 ? aux : C;
+            if (!dst) continue;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                __syncthreads();
+#pragma unroll
+                for (int ml = 0; ml < MIP; ++ml) {
+                    const int mi = pass * MIP + ml;
+                    const int m = acc_row_cfg<G>(m0, mi);
+#pragma unroll
+                    for (int ni = 0; ni < G::NI; ++ni) {
+                        const int n = acc_col_cfg<G>(n0, ni);
+                        float v[4] = {0.f, 0.f, 0.f, 0.f}, pre[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (m < p.M && n < p.N) finish(mi, ni, m, n, v, pre);
+                        char* l = smem + (wm * MIP * 16 + ml * 16 + c16) * ROWB + (wn * G::NI * 16 + ni * 16 + g4 * 4) * (int)sizeof(TO);
+                        io<TO>::store4(reinterpret_cast<TO*>(l), which == 0 ? pre : v);
+                    }
+                }
+                __syncthreads();
+                for (int v = threadIdx.x; v < RPP * VPR; v += G::THREADS) {
+                    const int lrow = v / VPR, cv = v % VPR;
+                    const int m = m0 + (lrow / (MIP * 16)) * (G::MI * 16) + pass * MIP * 16 + (lrow % (MIP * 16));
+                    const int n = n0 + cv * EPV_O;
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + lrow * ROWB + cv * 16);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < G::MI; ++mi) {
         const int m = acc_row_cfg<G>(m0, mi);
@@ -47,33 +124,10 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         for (int ni = 0; ni < G::NI; ++ni) {
             const int n = acc_col_cfg<G>(n0, ni);
             if (n >= p.N) continue;  // N % 4 == 0 is enforced by the launcher
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
-            if (p.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
+            float v[4], pre[4];
+            finish(mi, ni, m, n, v, pre);
             const size_t off = (size_t)m * p.ldc + n;
-            if (aux) io<TO>::store4(aux + off, v);
-            if (p.act == MOREC_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-            } else if (p.act == MOREC_ACT_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (p.dact != MOREC_ACT_NONE) {
-                float u[4];
-                io<TO>::load4(din + off, u);
-                if (p.dact == MOREC_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
-                }
-            }
+            if (aux) io<TO>::store4(aux + off, pre);
             if (p.accumulate == 0) {
                 io<TO>::store4(C + off, v);
             } else if (p.accumulate == 1) {
@@ -137,6 +191,7 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
+    a.vec_store = ((d->N * os) % 16 == 0) && ((d->ldc * os) % 16 == 0) && (!aux_out || aligned16(aux_out));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float>(d, a, s);
     if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16>(d, a, s);
