@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     return ap.parse_args()
@@ -86,11 +88,16 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # 'nccl' is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # 'nccl' is RCCL on ROCm
+        else:
+            dist.init_process_group(a.backend)
 
     from idvs.morec_amd import ops
     from idvs.morec_amd.model import BertShape, HipBertModel, Model
@@ -169,7 +176,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timing_on["v"] = False
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

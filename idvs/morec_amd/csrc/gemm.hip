@@ -1,6 +1,7 @@
 // gemm.hip -- NT GEMM with fused epilogues (bias, GELU/ReLU, activation-derivative, split-K atomics),
 // plus the layout helpers the backward pass needs (transpose with conversion, cast, column sums).
 // Reference arithmetic replaced: see include/morec_hip.h (morec_gemm_nt).
+#include <stdlib.h>
 #include "gemm_core.hpp"
 
 struct GemmArgs {
@@ -172,6 +173,10 @@ static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
 template <typename TI, typename TO>
 static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const long big_tiles = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->split_k < 1 ? 1 : d->split_k);
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("MOREC_GEMM_TILE"); force = e ? atoi(e) : 0; }   // 128 / 256: tuning override
+    if (force == 128) return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
+    if (force == 256) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
     if (big_tiles >= 192) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
     return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
 }

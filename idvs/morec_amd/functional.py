@@ -93,13 +93,21 @@ class IdEmbeddingFn(torch.autograd.Function):
 
 def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend() == "gloo" and t.is_cuda:   # gloo smoke tests on a GPU box: list form, staged through the host
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.detach().cpu().contiguous())
+        return torch.cat(parts, 0).to(t.device)
     dist.all_gather_into_tensor(out, t.contiguous())
     return out
 
 
 def _reduce_scatter_sum(t: torch.Tensor, world: int, rank: int) -> torch.Tensor:
     n = t.shape[0] // world
-    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all-reduce and keep our shard (CPU tests only)
+    if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all-reduce and keep our shard (smoke / CPU tests only)
+        if t.is_cuda:
+            h = t.detach().float().cpu()
+            dist.all_reduce(h)
+            return h[rank * n:(rank + 1) * n].to(t.device).to(t.dtype).contiguous()
         dist.all_reduce(t)
         return t[rank * n:(rank + 1) * n].contiguous()
     out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)

@@ -183,7 +183,7 @@ class TrainStep:
             Epool = _all_gather_cat(E, self.world)
             ci = engine.CeInputs(ci.row_ids, _all_gather_cat(ci.col_ids, self.world), _all_gather_cat(ci.col_logpop, self.world),
                                  _all_gather_cat(ci.col_valid, self.world), ci.row_valid, ci.B, ci.S, self.rank * E.shape[0])
-            dist.all_reduce(n_valid)
+            self._all_reduce(n_valid)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool)
         gscale = (1.0 / n_valid).reshape(1)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
@@ -196,11 +196,20 @@ class TrainStep:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
         return loss_sum[0] / n_valid
 
+    @staticmethod
+    def _all_reduce(t):
+        if dist.get_backend() == "gloo" and t.is_cuda:   # functional smoke test of the N > 1 path on one GPU
+            h = t.detach().cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+
     def reduce_gradients(self):
         """SUM over ranks (the 1/n_valid_global factor is already inside the loss gradient)."""
         if self.world > 1:
             for grp in self.groups:
-                dist.all_reduce(grp["arena"].grad)
+                self._all_reduce(grp["arena"].grad)
                 if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
                     grp["arena"].grad.mul_(1.0 / self.world)
 
