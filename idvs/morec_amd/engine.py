@@ -143,6 +143,65 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     return dx0, dz1
 
 
+def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
+                      drop: DropCfg = NO_DROP, site0: int = 0):
+    """LAST encoder layer when only token 0 of every sequence is consumed downstream (``hidden[:, 0]``,
+    ``T/model/encoders.py:69``): K and V are still needed for every token, but the attention output projection, both
+    LayerNorms and the FFN are row-wise, so they run on the n_seq [CLS] rows only -- 9/12 of the layer's GEMM work is
+    skipped for 29/30 of the tokens.  The reference computes (and discards) all rows; the kept rows are bit-for-bit the
+    same arithmetic.  Returns x2 restricted to the [CLS] rows: [n_seq, H]."""
+    dh = cfg.H // cfg.heads
+    H, T = cfg.H, cfg.T
+    desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
+                         drop.p_attn, drop.site(site0))
+    ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
+    qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
+    ctx = ops.attn_fwd(desc, qkv, key_keep)
+    ctx_c = ops.strided_rows_copy(ctx, torch.empty((n_seq, H), device=x0.device, dtype=x0.dtype), n_seq, H, T, 1)
+    x0_c = ops.strided_rows_copy(x0, torch.empty((n_seq, H), device=x0.device, dtype=x0.dtype), n_seq, H, T, 1)
+    a = ops.gemm_nt(ctx_c, w["o"].w)
+    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
+                                             p_in=ph, seed_in=s1)
+    u = torch.empty((n_seq, w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
+    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u)
+    f = ops.gemm_nt(g, w["f2"].w)
+    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
+                                             p_in=ph, seed_in=s2)
+    saved = (desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq) if need_grad else None
+    return x2, saved
+
+
+def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: dict):
+    """Backward of ``layer_forward_cls``: dx2_c is the gradient at the [CLS] rows [n_seq, H].  Returns (da, db) over ALL
+    tokens with dx0 = da + db (db carries the residual-branch gradient, non-zero on the [CLS] rows only)."""
+    desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq = saved
+    H, T = cfg.H, cfg.T
+    dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2)
+    if g.get("b2") is not None:
+        ops.colsum_(dzd2, g["b2"])
+    linear_wgrad_(dzd2, gact, g["f2"])
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
+    if g.get("b1") is not None:
+        ops.colsum_(du, g["b1"])
+    linear_wgrad_(du, x1, g["f1"])
+    dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=H)
+    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1)
+    if g.get("bo") is not None:
+        ops.colsum_(dzd1, g["bo"])
+    linear_wgrad_(dzd1, ctx_c, g["o"])
+    dctx_c = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=H)
+    dctx = torch.zeros((n_seq * T, H), device=dctx_c.device, dtype=dctx_c.dtype)
+    ops.strided_rows_copy(dctx_c, dctx, n_seq, H, 1, T)
+    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
+    if g.get("bqkv") is not None:
+        ops.colsum_(dqkv, g["bqkv"])
+    linear_wgrad_(dqkv, x0, g["qkv"])
+    dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=H)
+    dres = dctx.zero_()                      # reuse: residual-branch gradient, [CLS] rows only
+    ops.strided_rows_copy(dz1, dres, n_seq, H, 1, T)
+    return dx0, dres
+
+
 # ---------------------------------------------------------------------------------------------------------
 # SASRec user encoder (T/model/encoders.py:7-28, T/model/modules.py:78-96)
 # ---------------------------------------------------------------------------------------------------------
@@ -254,11 +313,15 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
                                                 p[bm + "embeddings.LayerNorm.weight"], p[bm + "embeddings.LayerNorm.bias"],
                                                 eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
     saved_layers = []
+    n_layers = len(prep["layers"])
     for l, w in enumerate(prep["layers"]):
-        x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
+        if l == n_layers - 1:     # only hidden[:, 0] is consumed (encoders.py:69): row-wise work on the [CLS] rows only
+            cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
+        else:
+            x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
         saved_layers.append(sv)
-    cls = torch.empty((Nc, H), device=x.device, dtype=dtype)
-    ops.strided_rows_copy(x, cls, Nc, H, T, 1)
+    if n_layers == 0:
+        cls = ops.strided_rows_copy(x, torch.empty((Nc, H), device=x.device, dtype=dtype), Nc, H, T, 1)
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
@@ -273,10 +336,12 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     ops.colsum_(dv, grads[prefix + "fc.bias"])
     linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
     dcls = ops.gemm_nt(dv, prep["fc"].wt, K=dv.shape[1], N=H)
-    da = torch.zeros((Nc * T, H), device=dcls.device, dtype=dcls.dtype)
-    ops.strided_rows_copy(dcls, da, Nc, H, 1, T)
-    db = None
-    for l in reversed(range(len(prep["layers"]))):
+    n_layers = len(prep["layers"])
+    da, db = None, None
+    if n_layers == 0:
+        da = torch.zeros((Nc * T, H), device=dcls.device, dtype=dcls.dtype)
+        ops.strided_rows_copy(dcls, da, Nc, H, 1, T)
+    for l in reversed(range(n_layers)):
         L = bm + f"encoder.layer.{l}."
         dqkv, dbqkv = grads.get(L + "qkv_fused.weight"), grads.get(L + "qkv_fused.bias")
         fused = dqkv is not None
@@ -288,7 +353,10 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
                  f1=grads[L + "intermediate.dense.weight"], b1=grads[L + "intermediate.dense.bias"],
                  f2=grads[L + "output.dense.weight"], b2=grads[L + "output.dense.bias"],
                  ln2_g=grads[L + "output.LayerNorm.weight"], ln2_b=grads[L + "output.LayerNorm.bias"])
-        da, db = layer_backward(cfg, prep["layers"][l], saved_layers[l], da, db, g)
+        if l == n_layers - 1:
+            da, db = layer_backward_cls(cfg, prep["layers"][l], saved_layers[l], dcls, g)
+        else:
+            da, db = layer_backward(cfg, prep["layers"][l], saved_layers[l], da, db, g)
         if not fused:
             for i, n in enumerate(("query", "key", "value")):
                 grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
