@@ -346,8 +346,8 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
         dqkv, dbqkv = grads.get(L + "qkv_fused.weight"), grads.get(L + "qkv_fused.bias")
         fused = dqkv is not None
         if not fused:
-            dqkv = torch.zeros((3 * H, H), device=da.device, dtype=torch.float32)
-            dbqkv = torch.zeros(3 * H, device=da.device, dtype=torch.float32)
+            dqkv = torch.zeros((3 * H, H), device=dcls.device, dtype=torch.float32)
+            dbqkv = torch.zeros(3 * H, device=dcls.device, dtype=torch.float32)
         g = dict(qkv=dqkv, bqkv=dbqkv, o=grads[L + "attention.output.dense.weight"], bo=grads[L + "attention.output.dense.bias"],
                  ln1_g=grads[L + "attention.output.LayerNorm.weight"], ln1_b=grads[L + "attention.output.LayerNorm.bias"],
                  f1=grads[L + "intermediate.dense.weight"], b1=grads[L + "intermediate.dense.bias"],
