@@ -1,0 +1,172 @@
+// gemm_tn.hip -- weight-gradient GEMM without transposed copies (bf16):
+//      C[n, k] (+)= sum_m DY[m, n] * X[m, k]           (dW = dY^T X of every nn.Linear on the path)
+// Both operands are contracted over their ROW index (tokens), i.e. the MFMA fragments are columns of the
+// row-major global tiles.  The tiles are staged as they lie in memory ([64 tokens][256 columns], LDS-DMA, one
+// wave-instruction = two 512-byte rows) and the fragments are fetched with ds_read_b64_tr_b16, the hardware
+// transpose read: lane (c = lane & 15, g = lane >> 4) receives, for column block*16 + c, the tokens
+// 4g .. 4g+3 and 16+4g .. 16+4g+3 of a 32-token step.  DY and X use the same token permutation, which a
+// dot product does not see.  Round 1 ran this product as an NT GEMM over explicitly transposed copies of DY
+// and X: 8.3 ms of pure transposition per step (rocprof r01c).
+// Bank conflicts: the 8 rows a 32-lane half touches would share banks at a 512-byte pitch; the 32-byte column
+// block index is XOR-ed with (token & 7) on the DMA source side and on the read side (destination stays linear).
+#include "gemm_core.hpp"
+
+namespace {
+constexpr int TT = 64;                 // tokens per stage
+constexpr int TC = 256;                // columns per operand tile
+constexpr int ROWB = TC * 2;           // 512 bytes per staged row
+constexpr int OPB = TT * ROWB;         // 32 KiB per operand per stage
+constexpr int STAGE = 2 * OPB;
+constexpr int LDS_TN = 2 * STAGE;      // 128 KiB
+constexpr int NWAVE = 8, NTHREADS = 512;
+constexpr int WN = 2, WK = 4;          // wave grid: 2 (n) x 4 (k); wave tile 128 n x 64 k
+constexpr int NI = 8, KI = 4;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+struct TnArgs {
+    const bf16* DY;
+    const bf16* X;
+    float* C;
+    int M, N, K, ldy, ldx, ldc, mchunk, tiles_n, tiles_k, atomic;
+};
+
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int ks, int blk) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int row = ks * 32 + 4 * g + (c >> 2);
+    const char* p0 = tile + row * ROWB + ((blk ^ (row & 7)) * 32) + 8 * (c & 3);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * ROWB));   // (row + 16) & 7 == row & 7
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WK, wk = wave % WK;
+    const int wg = xcd_remap(blockIdx.x, p.tiles_n * p.tiles_k);
+    const int n0 = (wg / p.tiles_k) * TC, k0 = (wg % p.tiles_k) * TC;
+    const int mbeg = blockIdx.z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
+    const int nt = (mend - mbeg + TT - 1) / TT;
+    if (nt <= 0) return;
+    const bool tail = ((mend - mbeg) % TT) != 0;
+
+    f32x4_t acc[NI][KI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < KI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // DMA geometry: instruction q of an operand covers token rows 2q, 2q+1; lane -> (row, 16-byte physical slot)
+    const int drow = lane >> 5, pslot = lane & 31;
+    const bf16* ysrc[4];
+    const bf16* xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 2 + drow;                       // token row within the stage
+        const int lslot = (((pslot >> 1) ^ (row & 7)) << 1) | (pslot & 1); // logical 16-byte column slot
+        const int yc = min(n0 + lslot * 8, p.N - 8), xc = min(k0 + lslot * 8, p.K - 8);   // clamp: unused output columns
+        ysrc[i] = p.DY + (size_t)row * p.ldy + yc;
+        xsrc[i] = p.X + (size_t)row * p.ldx + xc;
+    }
+    auto dma = [&](int stage, int m) {
+        char* base = smem + stage * STAGE + (wave * 4) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ysrc[i] + (size_t)m * p.ldy), (lptr_t)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + (size_t)m * p.ldx), (lptr_t)(base + OPB + i * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_tail = [&](int stage, int m) {   // token tail: zero-filled, register staged, same swizzled image
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < (TT * 32) / NTHREADS; ++i) {
+            const int v = tid + NTHREADS * i;
+            const int row = v >> 5, ls = v & 31;
+            const int yc = min(n0 + ls * 8, p.N - 8), xc = min(k0 + ls * 8, p.K - 8);
+            const bool in = (m + row) < mend;
+            const uint4 ry = in ? *reinterpret_cast<const uint4*>(p.DY + (size_t)(m + row) * p.ldy + yc) : make_uint4(0, 0, 0, 0);
+            const uint4 rx = in ? *reinterpret_cast<const uint4*>(p.X + (size_t)(m + row) * p.ldx + xc) : make_uint4(0, 0, 0, 0);
+            const int off = row * ROWB + ((((ls >> 1) ^ (row & 7)) << 1) | (ls & 1)) * 16;
+            *reinterpret_cast<uint4*>(base + off) = ry;
+            *reinterpret_cast<uint4*>(base + OPB + off) = rx;
+        }
+    };
+    auto stage = [&](int st, int t) {
+        if (tail && t == nt - 1) stage_tail(st, mbeg + t * TT);
+        else dma(st, mbeg + t * TT);
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+        const char* ty = smem + cur * STAGE;
+        const char* tx = ty + OPB;
+#pragma unroll
+        for (int ks = 0; ks < TT / 32; ++ks) {
+            bf16x8_t fy[NI], fx[KI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fy[i] = tr_frag(ty, ks, wn * NI + i);
+#pragma unroll
+            for (int j = 0; j < KI; ++j) fx[j] = tr_frag(tx, ks, wk * KI + j);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < KI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // acc[i][j][r] = C[n0 + (wn*NI + i)*16 + (lane & 15)][k0 + (wk*KI + j)*16 + 4*(lane >> 4) + r]
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + (wn * NI + i) * 16 + c;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int k = k0 + (wk * KI + j) * 16 + 4 * g;
+            if (k >= p.K) continue;
+            float* dst = p.C + (size_t)n * p.ldc + k;
+            if (p.atomic) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
+            } else {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc,
+                             int dtype, int split_m, int accumulate, void* stream) {
+    if (!DY || !X || !C || M <= 0 || N <= 0 || K <= 0) return MOREC_E_ARG;
+    if (dtype != MOREC_BF16) return MOREC_E_UNSUPPORTED;   // the exact-fp32 path uses transposed copies + morec_gemm_nt
+    if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldc % 4 || !aligned16(DY) || !aligned16(X) || !aligned16(C)) return MOREC_E_ALIGN;
+    if (split_m > 1 && !accumulate) return MOREC_E_ARG;
+    TnArgs a;
+    a.DY = reinterpret_cast<const bf16*>(DY); a.X = reinterpret_cast<const bf16*>(X); a.C = C;
+    a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.ldc = ldc; a.atomic = accumulate ? 1 : 0;
+    const int split = split_m < 1 ? 1 : split_m;
+    int mchunk = (M + split - 1) / split;
+    mchunk = ((mchunk + TT - 1) / TT) * TT;
+    a.mchunk = mchunk;
+    const int zs = (M + mchunk - 1) / mchunk;
+    a.tiles_n = (N + TC - 1) / TC; a.tiles_k = (K + TC - 1) / TC;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

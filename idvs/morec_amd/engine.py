@@ -84,6 +84,10 @@ def _splitk(N: int, K: int, Mp: int) -> int:
 
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
     """dw[N, K] += dy[M, N]^T @ x[M, K]  (fp32 atomics, split over M)."""
+    if dy.dtype == torch.bfloat16 and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+        M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+        ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
+        return None, None
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt
     N, K, Mp = dyt.shape[0], xt.shape[0], dyt.shape[1]

@@ -61,6 +61,16 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     return out
 
 
+def gemm_tn_(dy, x, out, split_m=1, accumulate=True):
+    """out[N, K] (+)= dy[M, N]^T @ x[M, K] (bf16 operands, fp32 out) without transposed copies."""
+    _dev(dy), _dev(x)
+    M, N = dy.shape
+    K = x.shape[1]
+    check(_lib.lib().morec_gemm_tn(_p(dy), _p(x), _p(out), M, N, K, dy.stride(0), x.stride(0), out.stride(0), code(dy.dtype),
+                                   split_m, int(accumulate), _stream()), "morec_gemm_tn")
+    return out
+
+
 def transpose(x, out=None, out_dtype=None, ld_out=None):
     """[R, C] -> [C, ld_out>=R] (pad columns, if any, are zero)."""
     _dev(x)

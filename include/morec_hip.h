@@ -66,6 +66,12 @@ typedef struct {
 int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                   void* aux_out, const void* dact_in, void* stream);
 
+/* Weight-gradient GEMM without transposed copies (bf16 only; MOREC_E_UNSUPPORTED otherwise):
+ * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z and requires
+ * accumulate != 0 (fp32 atomicAdd into a caller-zeroed C).  Autograd backward of nn.Linear: dW = dY^T X. */
+int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc, int dtype,
+                  int split_m, int accumulate, void* stream);
+
 /* out[c, r] = in[r, c]; in is [R, C] with pitch ld_in, out is [C, R] with pitch ld_out.
  * in_dtype/out_dtype select a fused conversion (f32 -> bf16 weight shadows). */
 int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype, int out_dtype,

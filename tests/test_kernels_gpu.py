@@ -95,6 +95,22 @@ def test_gemm_splitk_atomic(dt):
     assert rel(out, a[:, :K2].double() @ b[:, :K2].double().t()) < tol(dt)
 
 
+@pytest.mark.parametrize("shape", [(64, 256, 256, 1), (200, 96, 264, 1), (4096, 768, 2304, 4), (20160, 768, 768, 9),
+                                   (2590, 1536, 512, 5), (77, 8, 16, 1)])
+def test_gemm_tn(shape):
+    """dW = dY^T X straight from the row-major operands (transpose reads), incl. token / column tails and split-m atomics."""
+    M, N, K, split = shape
+    dy, x = rnd(M, N, dt=torch.bfloat16, scale=0.2), rnd(M, K, dt=torch.bfloat16, scale=0.2, seed=1)
+    out = torch.zeros(N, K, device=DEV)
+    ops.gemm_tn_(dy, x, out, split_m=split)
+    ref = dy.double().t() @ x.double()
+    assert rel(out, ref) < 2e-5 * math.sqrt(M) + 1e-6
+    if split == 1:
+        out2 = torch.full((N, K), 7.0, device=DEV)
+        ops.gemm_tn_(dy, x, out2, split_m=1, accumulate=False)
+        assert torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_transpose_cast_colsum(dt):
     x = rnd(300, 170, dt=dt)
