@@ -150,6 +150,19 @@ def main():
         return out
 
     ops.gemm_nt = timed_gemm
+    real_tn = ops.gemm_tn_
+
+    def timed_tn(dy, x, out, **kw):
+        if not timing_on["v"]:
+            return real_tn(dy, x, out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_tn(dy, x, out, **kw)
+        e1.record()
+        gemm_log.append((2.0 * dy.shape[0] * dy.shape[1] * x.shape[1], e0, e1, "tn"))
+        return r
+
+    ops.gemm_tn_ = timed_tn
 
     def run_step(i):
         ids, items, lm = host[i]
@@ -188,8 +201,14 @@ def main():
     ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in gemm_log)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     peak = MFMA_PEAK_TFLOPS["bf16" if a.dtype == "bf16" else "f32"]
-    roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (128x128 MFMA tile, all NT GEMMs of the step)",
-            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+    traffic = None   # HBM bytes per launch from the PMC passes (profiles/r01_gemm_pmc.json), measured offline with rocprofv3
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as fh:
+            traffic = json.load(fh).get("hbm_bytes_per_launch_avg")
+    except Exception:  # noqa: BLE001
+        pass
+    roof = {"bound": "mfma", "kernel": "gemm_nt_kernel + gemm_tn_kernel (256x256 / 128x128 MFMA tiles; every GEMM launch of the step)",
+            "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": traffic,
             "launches_per_step": len(gemm_log) // max(1, a.steps), "gemm_ms_per_step": round(ms / max(1, a.steps), 3)}
 
     out = {"metric": "user-sequences/sec end-to-end train step, SASRec+BERT-base", "value": round(world * a.batch * a.steps / dt, 2),
