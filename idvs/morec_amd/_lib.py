@@ -48,7 +48,7 @@ _SIGS = {
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P]),
-    "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
+    "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_uint64, C.c_float, C.c_uint64, _P]),
     "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),

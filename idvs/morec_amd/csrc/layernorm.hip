@@ -93,99 +93,126 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 }
 
-// Backward.  Each block owns RPB consecutive rows (4 waves x RPB/4 rows); per-column dgamma/dbeta
-// partials are reduced across the block's waves in LDS and leave as ONE atomicAdd per column per block.
+// Backward.  Each block owns RPB consecutive rows; every wave handles TWO rows per trip (both rows' loads are in
+// flight together: the kernel is latency-bound otherwise).  Per-column dgamma / dbeta (and the sub-layer bias
+// gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave as ONE
+// atomicAdd per column per block.
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int N, int rows_per_block,
-                                                     DropRng din, DropRng dout) {
+                                                     float* __restrict__ dbeta, float* __restrict__ dbias, int M, int N,
+                                                     int rows_per_block, DropRng din, DropRng dout) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [4][N] dgamma partials
     float* sb = sg + 4 * (size_t)N;                 // [4][N] dbeta partials
+    float* sd = sb + 4 * (size_t)N;                 // [4][N] dbias partials (only when dbias)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    float ag[VPL][4], ab[VPL][4], gm[VPL][4];
+    float ag[VPL][4], ab[VPL][4], ad[VPL][4], gm[VPL][4];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; gm[i][k] = 0.f; }
+        for (int k = 0; k < 4; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
         if (c < N) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + c);
             gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
         }
     }
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const size_t base = (size_t)row * N;
-        const float mu = mean[row], rs = rstd[row];
-        float g[VPL][4], xh[VPL][4];
-        float s1 = 0.f, s2 = 0.f;
+    for (int rowp = r0 + wave * 2; rowp < r1; rowp += 8) {
+        float g[2][VPL][4], xh[2][VPL][4];
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < N) {
-                float d[4], zz[4];
-                io<T>::load4(dy_a + base + c, d);
-                if (dy_b) {
-                    float e[4];
-                    io<T>::load4(dy_b + base + c, e);
+        for (int j = 0; j < 2; ++j) {
+            const int row = min(rowp + j, r1 - 1);          // an odd tail re-reads the last row and skips its stores
+            const size_t base = (size_t)row * N;
+            const float mu = mean[row];
+            rs[j] = rstd[row];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] += e[k];
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < N) {
+                    float d[4], zz[4];
+                    io<T>::load4(dy_a + base + c, d);
+                    if (dy_b) {
+                        float e[4];
+                        io<T>::load4(dy_b + base + c, e);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] += e[k];
+                    }
+                    if (dout.thresh) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
+                    }
+                    io<T>::load4(z + base + c, zz);
+                    const bool live = (rowp + j) < r1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xh[j][i][k] = (zz[k] - mu) * rs[j];
+                        if (live) {
+                            ag[i][k] += d[k] * xh[j][i][k];
+                            ab[i][k] += d[k];
+                        }
+                        g[j][i][k] = d[k] * gm[i][k];
+                        s1[j] += g[j][i][k];
+                        s2[j] += g[j][i][k] * xh[j][i][k];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { g[j][i][k] = 0.f; xh[j][i][k] = 0.f; }
                 }
-                if (dout.thresh) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
-                }
-                io<T>::load4(z + base + c, zz);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    xh[i][k] = (zz[k] - mu) * rs;
-                    ag[i][k] += d[k] * xh[i][k];
-                    ab[i][k] += d[k];
-                    g[i][k] = d[k] * gm[i][k];
-                    s1 += g[i][k];
-                    s2 += g[i][k] * xh[i][k];
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { g[i][k] = 0.f; xh[i][k] = 0.f; }
             }
         }
-        s1 = wave_sum(s1) / (float)N;
-        s2 = wave_sum(s2) / (float)N;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < N) {
-                float o[4];
+        for (int j = 0; j < 2; ++j) {
+            s1[j] = wave_sum(s1[j]) / (float)N;
+            s2[j] = wave_sum(s2[j]) / (float)N;
+        }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
-                io<T>::store4(dz + base + c, o);
-                if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
+        for (int j = 0; j < 2; ++j) {
+            if (rowp + j >= r1) continue;
+            const size_t base = (size_t)(rowp + j) * N;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
-                    io<T>::store4(dzd + base + c, o);
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < N) {
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = rs[j] * (g[j][i][k] - s1[j] - xh[j][i][k] * s2[j]);
+                    io<T>::store4(dz + base + c, o);
+                    if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
+                        io<T>::store4(dzd + base + c, o);
+                    }
+                    if (dbias) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) ad[i][k] += io<T>::round(o[k]);   // what colsum over the stored tensor would see
+                    }
                 }
             }
         }
     }
-    if (dgamma) {
+    if (dgamma || dbias) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * 64 + lane) * 4;
             if (c < N) {
                 *reinterpret_cast<float4*>(sg + (size_t)wave * N + c) = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]);
                 *reinterpret_cast<float4*>(sb + (size_t)wave * N + c) = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
+                if (dbias) *reinterpret_cast<float4*>(sd + (size_t)wave * N + c) = make_float4(ad[i][0], ad[i][1], ad[i][2], ad[i][3]);
             }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < N; c += 256) {
-            atomicAdd(dgamma + c, sg[c] + sg[N + c] + sg[2 * N + c] + sg[3 * N + c]);
-            atomicAdd(dbeta + c, sb[c] + sb[N + c] + sb[2 * N + c] + sb[3 * N + c]);
+            if (dgamma) {
+                atomicAdd(dgamma + c, sg[c] + sg[N + c] + sg[2 * N + c] + sg[3 * N + c]);
+                atomicAdd(dbeta + c, sb[c] + sb[N + c] + sb[2 * N + c] + sb[3 * N + c]);
+            }
+            if (dbias) atomicAdd(dbias + c, sd[c] + sd[N + c] + sd[2 * N + c] + sd[3 * N + c]);
         }
     }
 }
@@ -230,19 +257,20 @@ extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void*
 
 template <typename T>
 static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
-                           const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, int M, int N,
-                           DropRng din, DropRng dout, hipStream_t s) {
+                           const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M,
+                           int N, DropRng din, DropRng dout, hipStream_t s) {
     const int vpl = (N + 255) / 256;
     const int rpb = 64;
     dim3 grid((M + rpb - 1) / rpb), block(256);
-    const size_t lds = dgamma ? (size_t)8 * N * sizeof(float) : 0;
+    const size_t lds = (dgamma || dbias) ? (size_t)12 * N * sizeof(float) : 0;
 #define LN_BWD(V)                                                                                               \
     do {                                                                                                        \
         if (lds > 48 * 1024)                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>),                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
         hipLaunchKernelGGL((ln_bwd_kernel<T, V>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,          \
-                           (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, M, N, rpb, din, dout); \
+                           (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, \
+                           dout);                                                                               \
     } while (0)
     if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
@@ -258,8 +286,8 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
 
 extern "C" int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, void* dzd, float* dgamma,
-                                   float* dbeta, int M, int N, int dtype, float p_in, uint64_t seed_in, float p_out,
-                                   uint64_t seed_out, void* stream) {
+                                   float* dbeta, float* dbias, int M, int N, int dtype, float p_in, uint64_t seed_in,
+                                   float p_out, uint64_t seed_out, void* stream) {
     if (!dy_a || !z || !mean || !rstd || !gamma || !dz || M <= 0 || N <= 0) return MOREC_E_ARG;
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
     if ((p_in > 0.f) != (dzd != nullptr)) return MOREC_E_ARG;
@@ -269,9 +297,9 @@ extern "C" int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const voi
     if (N > 4096) return MOREC_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
-        return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, M, N, din, dout, s);
+        return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, s);
     if (dtype == MOREC_BF16)
-        return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, M, N, din, dout, s);
+        return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, s);
     return MOREC_E_DTYPE;
 }
 

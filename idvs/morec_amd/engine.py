@@ -125,18 +125,16 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     (bias entries may be None).  Returns (da, db) with dx0 = da + db."""
     desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2 = saved
     # dz* = gradient at the residual sum (also the residual branch's gradient); dzd* = after the sub-layer's dropout
-    dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2)
-    if g.get("b2") is not None:
-        ops.colsum_(dzd2, g["b2"])
+    dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
+                                  dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
     du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
     if g.get("b1") is not None:
         ops.colsum_(du, g["b1"])
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=x1.shape[1])
-    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1)
-    if g.get("bo") is not None:
-        ops.colsum_(dzd1, g["bo"])
+    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,
+                                  dbias=g.get("bo"))
     linear_wgrad_(dzd1, ctx, g["o"])
     dctx = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=ctx.shape[1])
     dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
@@ -180,18 +178,16 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     tokens with dx0 = da + db (db carries the residual-branch gradient, non-zero on the [CLS] rows only)."""
     desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq = saved
     H, T = cfg.H, cfg.T
-    dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2)
-    if g.get("b2") is not None:
-        ops.colsum_(dzd2, g["b2"])
+    dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
+                                  dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
     du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
     if g.get("b1") is not None:
         ops.colsum_(du, g["b1"])
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=H)
-    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1)
-    if g.get("bo") is not None:
-        ops.colsum_(dzd1, g["bo"])
+    dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,
+                                  dbias=g.get("bo"))
     linear_wgrad_(dzd1, ctx_c, g["o"])
     dctx_c = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=H)
     dctx = torch.zeros((n_seq * T, H), device=dctx_c.device, dtype=dctx_c.dtype)

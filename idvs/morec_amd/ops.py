@@ -124,14 +124,14 @@ def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_per
     return y, (z if need_z else x), mean, rstd
 
 
-def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None):
     """Returns (dz, dzd): dz feeds the residual branch, dzd = dropout-backward of dz feeds the sub-layer (dzd is dz when p_in = 0)."""
     _dev(dy_a)
     M, N = z.shape
     dz = torch.empty_like(z)
     dzd = torch.empty_like(z) if p_in > 0 else None
     check(_lib.lib().morec_layernorm_bwd(_p(dy_a), _p(dy_b), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dzd),
-                                         _p(dgamma), _p(dbeta), M, N, code(z.dtype), p_in, seed_in, p_out, seed_out,
+                                         _p(dgamma), _p(dbeta), _p(dbias), M, N, code(z.dtype), p_in, seed_in, p_out, seed_out,
                                          _stream()), "morec_layernorm_bwd")
     return dz, (dz if dzd is None else dzd)
 

@@ -96,10 +96,11 @@ int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const
                         float* rstd, int M, int N, int dtype, float p_in, uint64_t seed_in, float p_out,
                         uint64_t seed_out, void* stream);
 /* dz = LN'(drop_out'(dy_a + dy_b); z); dzd = drop_in'(dz) (required iff p_in > 0, else NULL).
- * dgamma/dbeta are atomically accumulated (fp32, [N]).  dy_b may be NULL. */
+ * dgamma/dbeta (and, if given, dbias = column sums of dzd: the gradient of the fused pre-add bias) are atomically
+ * accumulated (fp32, [N]).  dy_b and dbias may be NULL. */
 int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
-                        const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, int M, int N, int dtype,
-                        float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
+                        const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M, int N,
+                        int dtype, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
 /* dpos[m % period, n] += dz[m, n]  (position-embedding gradient, fp32 atomics) */
 int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream);
 

@@ -52,8 +52,10 @@ def test_layernorm_dropout(dt):
     dy = torch.randn(M, N, generator=g).to(DEV).to(dt)
     (yr * dy.double()).sum().backward()
     dgamma, dbeta = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dbias = torch.zeros(N, device=DEV)
     dz, dzd = ops.layernorm_bwd(dy, None, z, mean, rstd, gamma, dgamma, dbeta, p_in=p_in, seed_in=s_in, p_out=p_out,
-                                seed_out=s_out)
+                                seed_out=s_out, dbias=dbias)
+    assert rel(dbias, dzd.double().sum(0)) < 1e-5
     assert rel(dz, zs.grad) < tol
     assert rel(dzd, zs.grad * m_in) < tol
 

@@ -148,8 +148,10 @@ def test_layernorm(dt, N):
     yr = torch.nn.functional.layer_norm(zs, (N,), gd, bd, 1e-6)
     (yr * (dy_a.double() + dy_b.double())).sum().backward()
     dgamma, dbeta = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
-    dz, dzd = ops.layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta)
+    dbias = torch.zeros(N, device=DEV)
+    dz, dzd = ops.layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, dbias=dbias)
     assert dzd is dz
+    assert rel(dbias, dz.double().sum(0)) < 1e-5     # fused gradient of the pre-add bias
     assert rel(dz, zs.grad) < tol(dt)
     assert rel(dgamma, gd.grad) < 1e-4 and rel(dbeta, bd.grad) < 1e-4
     dpos = torch.zeros(S, N, device=DEV)
