@@ -29,6 +29,7 @@ struct TnArgs {
     const bf16* X;
     float* C;
     int M, N, K, ldy, ldx, ldc, mchunk, tiles_n, tiles_k, atomic;
+    float* slabs;     // split-m partials [gridDim.z][N][K] (plain stores) -- reduced by reduce_slabs_kernel
 };
 
 __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int ks, int blk) {
@@ -133,6 +134,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
         for (int j = 0; j < KI; ++j) {
             const int k = k0 + (wk * KI + j) * 16 + 4 * g;
             if (k >= p.K) continue;
+            if (p.slabs) {
+                float* sl = p.slabs + ((size_t)blockIdx.z * p.N + n) * p.K + k;
+                *reinterpret_cast<float4*>(sl) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                continue;
+            }
             float* dst = p.C + (size_t)n * p.ldc + k;
             if (p.atomic) {
 #pragma unroll
@@ -143,10 +149,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
         }
     }
 }
+// C[n, k] (+)= sum_s slabs[s][n][k]   (deterministic split-m reduction; replaces 65k fp32 atomics per workgroup)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int N, int K,
+                                                           int ldc, int nslab, int accumulate) {
+    const size_t total4 = (size_t)N * K / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        const int n = (int)(e / K), k = (int)(e % K);
+        float4 s = reinterpret_cast<const float4*>(slabs)[i];
+        for (int t = 1; t < nslab; ++t) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)t * N * K)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(C + (size_t)n * ldc + k);
+        if (accumulate) {
+            const float4 c = *dst;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        }
+        *dst = s;
+    }
+}
 }  // namespace
 
+extern "C" size_t morec_gemm_tn_workspace_bytes(int N, int K, int split_m) {
+    return split_m > 1 ? (size_t)split_m * N * K * sizeof(float) : 0;
+}
+
 extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc,
-                             int dtype, int split_m, int accumulate, void* stream) {
+                             int dtype, int split_m, int accumulate, float* workspace, void* stream) {
     if (!DY || !X || !C || M <= 0 || N <= 0 || K <= 0) return MOREC_E_ARG;
     if (dtype != MOREC_BF16) return MOREC_E_UNSUPPORTED;   // the exact-fp32 path uses transposed copies + morec_gemm_nt
     if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldc % 4 || !aligned16(DY) || !aligned16(X) || !aligned16(C)) return MOREC_E_ALIGN;
@@ -160,6 +190,8 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     a.mchunk = mchunk;
     const int zs = (M + mchunk - 1) / mchunk;
     a.tiles_n = (N + TC - 1) / TC; a.tiles_k = (K + TC - 1) / TC;
+    a.slabs = (zs > 1 && workspace) ? workspace : nullptr;
+    if (a.slabs && (K % 4 || !aligned16(workspace))) return MOREC_E_ALIGN;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
@@ -168,5 +200,12 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
                        reinterpret_cast<hipStream_t>(stream), a);
     MOREC_CHECK_LAUNCH();
+    if (a.slabs) {
+        const size_t total4 = (size_t)N * K / 4;
+        const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs, C, N,
+                           K, ldc, zs, accumulate ? 1 : 0);
+        MOREC_CHECK_LAUNCH();
+    }
     return MOREC_OK;
 }

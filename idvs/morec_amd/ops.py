@@ -61,13 +61,24 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     return out
 
 
-def gemm_tn_(dy, x, out, split_m=1, accumulate=True):
-    """out[N, K] (+)= dy[M, N]^T @ x[M, K] (bf16 operands, fp32 out) without transposed copies."""
+_TN_WS = {}
+
+
+def gemm_tn_(dy, x, out, split_m=1, accumulate=True, slabs=True):
+    """out[N, K] (+)= dy[M, N]^T @ x[M, K] (bf16 operands, fp32 out) without transposed copies.  ``slabs``: reduce the
+    split-m partials through a reusable fp32 workspace (deterministic) instead of fp32 atomics."""
     _dev(dy), _dev(x)
     M, N = dy.shape
     K = x.shape[1]
+    ws = None
+    if slabs and split_m > 1:
+        need = _lib.lib().morec_gemm_tn_workspace_bytes(N, K, split_m) // 4
+        ws = _TN_WS.get(dy.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 20 * 1024 * 1024), device=dy.device, dtype=torch.float32)
+            _TN_WS[dy.device] = ws
     check(_lib.lib().morec_gemm_tn(_p(dy), _p(x), _p(out), M, N, K, dy.stride(0), x.stride(0), out.stride(0), code(dy.dtype),
-                                   split_m, int(accumulate), _stream()), "morec_gemm_tn")
+                                   split_m, int(accumulate), _p(ws), _stream()), "morec_gemm_tn")
     return out
 
 

@@ -70,7 +70,10 @@ int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* 
  * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z and requires
  * accumulate != 0 (fp32 atomicAdd into a caller-zeroed C).  Autograd backward of nn.Linear: dW = dY^T X. */
 int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc, int dtype,
-                  int split_m, int accumulate, void* stream);
+                  int split_m, int accumulate, float* workspace, void* stream);
+/* workspace (optional, fp32): morec_gemm_tn_workspace_bytes(N, K, split_m).  With it the split-m partial tiles are written
+ * as plain slabs and summed by a second kernel (deterministic, ~4x cheaper than the atomics); without it fp32 atomicAdd. */
+size_t morec_gemm_tn_workspace_bytes(int N, int K, int split_m);
 
 /* out[c, r] = in[r, c]; in is [R, C] with pitch ld_in, out is [C, R] with pitch ld_out.
  * in_dtype/out_dtype select a fused conversion (f32 -> bf16 weight shadows). */

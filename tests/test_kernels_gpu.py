@@ -105,6 +105,12 @@ def test_gemm_tn(shape):
     ops.gemm_tn_(dy, x, out, split_m=split)
     ref = dy.double().t() @ x.double()
     assert rel(out, ref) < 2e-5 * math.sqrt(M) + 1e-6
+    out3 = torch.ones(N, K, device=DEV)                      # atomics path accumulates into what is there
+    ops.gemm_tn_(dy, x, out3, split_m=split, slabs=False)
+    assert rel(out3 - 1, ref) < 2e-5 * math.sqrt(M) + 1e-5
+    out4 = torch.ones(N, K, device=DEV)                      # slab path with accumulate: C += sum of slabs
+    ops.gemm_tn_(dy, x, out4, split_m=split)
+    assert rel(out4 - 1, ref) < 2e-5 * math.sqrt(M) + 1e-5
     if split == 1:
         out2 = torch.full((N, K), 7.0, device=DEV)
         ops.gemm_tn_(dy, x, out2, split_m=1, accumulate=False)
