@@ -148,104 +148,6 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-// Persistent variant for the big encoder GEMMs (no split-K, plain store, 16-byte addressable rows): ONE workgroup per
-// CU walks its share of the 256 x 256 tiles.  With a 128 KiB LDS footprint only one workgroup fits per CU, so in the
-// one-tile-per-workgroup kernel every tile pays the full drain of its output stores before the successor workgroup
-// can even start (measured: the store phase cost more than the K = 768 main loop).  Here the waves never terminate
-// between tiles, waves 0-3 own the LDS-DMA + vmcnt waits and waves 4-7 own the global stores, so a tile's stores
-// retire underneath the next tile's MFMAs.
-template <typename G, typename TI, typename TO>
-__global__ __launch_bounds__(G::THREADS) void gemm_nt_persistent_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int lane = threadIdx.x & 63, c16 = lane & 15, g4 = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave / G::WN, wn = wave % G::WN;
-    constexpr int EPV_O = 16 / (int)sizeof(TO);
-    constexpr int ROWB = G::TN * (int)sizeof(TO) + 16;
-    constexpr int NP = (G::TM * ROWB + G::LDS_BYTES - 1) / G::LDS_BYTES;
-    constexpr int NPASS = NP <= 1 ? 1 : (NP <= 2 ? 2 : (NP <= 4 ? 4 : 8));
-    constexpr int MIP = G::MI / NPASS;
-    constexpr int RPP = G::WM * MIP * 16;
-    constexpr int VPR = G::TN * (int)sizeof(TO) / 16;
-    constexpr int STORE_T0 = G::THREADS / 2, STORE_T = G::THREADS / 2;      // waves NWAVES/2 .. NWAVES-1 store
-    TO* C = reinterpret_cast<TO*>(p.C);
-    TO* aux = reinterpret_cast<TO*>(p.aux_out);
-    const TO* din = reinterpret_cast<const TO*>(p.dact_in);
-    auto lds_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int wg = xcd_remap(tile, ntiles);
-        const int m0 = (wg / p.tiles_n) * G::TM, n0 = (wg % p.tiles_n) * G::TN;
-        f32x4_t acc[G::MI][G::NI];
-#pragma unroll
-        for (int i = 0; i < G::MI; ++i)
-#pragma unroll
-            for (int j = 0; j < G::NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        gemm_mainloop_cfg<G, TI, true>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda,
-                                       p.ldb, m0, n0, 0, p.K, smem, acc);
-        for (int which = 0; which < 2; ++which) {
-            TO* dst = which == 0 ? aux : C;
-            if (!dst) continue;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-#pragma unroll
-                for (int ml = 0; ml < MIP; ++ml) {
-                    const int mi = pass * MIP + ml;
-                    const int m = acc_row_cfg<G>(m0, mi);
-#pragma unroll
-                    for (int ni = 0; ni < G::NI; ++ni) {
-                        const int n = acc_col_cfg<G>(n0, ni);
-                        float v[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (m < p.M && n < p.N) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r] * p.alpha;
-                            if (p.bias) {
-                                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                            }
-                            if (which == 1) {
-                                if (p.act == MOREC_ACT_GELU) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-                                } else if (p.act == MOREC_ACT_RELU) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                                }
-                                if (p.dact != MOREC_ACT_NONE) {
-                                    float u[4];
-                                    io<TO>::load4(din + (size_t)m * p.ldc + n, u);
-                                    if (p.dact == MOREC_ACT_GELU) {
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
-                                    } else {
-#pragma unroll
-                                        for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
-                                    }
-                                }
-                            }
-                        }
-                        char* l = smem + (wm * MIP * 16 + ml * 16 + c16) * ROWB + (wn * G::NI * 16 + ni * 16 + g4 * 4) * (int)sizeof(TO);
-                        io<TO>::store4(reinterpret_cast<TO*>(l), v);
-                    }
-                }
-                lds_barrier();
-                if (threadIdx.x >= STORE_T0) {
-                    for (int v = threadIdx.x - STORE_T0; v < RPP * VPR; v += STORE_T) {
-                        const int lrow = v / VPR, cv = v % VPR;
-                        const int m = m0 + (lrow / (MIP * 16)) * (G::MI * 16) + pass * MIP * 16 + (lrow % (MIP * 16));
-                        const int n = n0 + cv * EPV_O;
-                        if (m < p.M && n < p.N)
-                            *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + lrow * ROWB + cv * 16);
-                    }
-                }
-                lds_barrier();      // the staged rows have been read: LDS may be overwritten (next pass / next tile's DMA)
-            }
-        }
-    }
-}
-
 template <typename G, typename TI, typename TO>
 static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
@@ -275,33 +177,7 @@ static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (force < 0) { const char* e = getenv("MOREC_GEMM_TILE"); force = e ? atoi(e) : 0; }   // 128 / 256: tuning override
     if (force == 128) return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
     if (force == 256) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
-    if (big_tiles >= 192) {
-        using G = GemmTileCfg<TI, 2, 4, 8, 4>;
-        static int persist = -1;
-        if (persist < 0) { const char* e = getenv("MOREC_GEMM_PERSIST"); persist = e ? atoi(e) : 1; }
-        if (persist && (d->split_k <= 1) && d->accumulate == 0 && a.vec_store) {
-            a.tiles_m = (d->M + G::TM - 1) / G::TM;
-            a.tiles_n = (d->N + G::TN - 1) / G::TN;
-            a.kchunk = d->K;
-            static bool attr_set = false;
-            static int n_cu = 256;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_persistent_kernel<G, TI, TO>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                    n_cu = prop.multiProcessorCount;
-                attr_set = true;
-            }
-            const int ntiles = a.tiles_m * a.tiles_n;
-            hipLaunchKernelGGL((gemm_nt_persistent_kernel<G, TI, TO>), dim3(ntiles < n_cu ? ntiles : n_cu), dim3(G::THREADS),
-                               G::LDS_BYTES, s, a);
-            MOREC_CHECK_LAUNCH();
-            return MOREC_OK;
-        }
-        return launch_gemm_cfg<G, TI, TO>(d, a, s);
-    }
+    if (big_tiles >= 192) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
     return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
 }
 

@@ -76,29 +76,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // (the destination stays linear).  Rows past M / N are clamped to the last valid row (their products land in
 // accumulator rows / columns that are never stored); a K tail that does not fill a stage goes through a
 // register-staged, zero-filling path.  Double-buffered: the DMA of tile t+1 flies while tile t is multiplied.
-// SPLIT_ROLES (persistent kernel): only the first half of the waves issue LDS-DMA (twice as many pieces each) and wait
-// on vmcnt; the other half never waits on the vector-memory counter inside the loop, so the output stores they issued
-// for the PREVIOUS tile keep draining under this tile's MFMAs (CDNA4's vmcnt is in-order and counts stores too).
-template <typename G, typename T, bool SPLIT_ROLES = false>
+template <typename G, typename T>
 __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const T* __restrict__ B, int M, int N, int lda,
                                                   int ldb, int m0, int n0, int kbeg, int kend, char* smem,
                                                   f32x4_t (&acc)[G::MI][G::NI]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / G::WN, wn = wave % G::WN;
-    constexpr int DMAW = SPLIT_ROLES ? G::NWAVES / 2 : G::NWAVES;        // waves that issue DMA
-    constexpr int APW = G::TM / G::ROWS_PER_DMA / DMAW, BPW = G::TN / G::ROWS_PER_DMA / DMAW;
-    const bool dma_wave = wave < DMAW;
-    auto block_sync = [&]() {
-        if constexpr (SPLIT_ROLES) {
-            if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    };
     const int nk = (kend - kbeg + G::KE - 1) / G::KE;
     if (nk <= 0) return;
     const bool tail = ((kend - kbeg) % G::KE) != 0;
@@ -106,28 +90,26 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
     // per-lane source rows of this wave's DMA instructions (clamped) and the swizzled source slot
     const int drow = lane / G::SLOTS;                       // row within the 1-KiB piece
     const int pslot = lane % G::SLOTS;                      // physical slot this lane's 16 B land in
-    const int dwave = dma_wave ? wave : 0;
-    const T* asrc[APW];
-    const T* bsrc[BPW];
+    const T* asrc[G::ADMA_PER_WAVE];
+    const T* bsrc[G::BDMA_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int row = (dwave * APW + i) * G::ROWS_PER_DMA + drow;
+    for (int i = 0; i < G::ADMA_PER_WAVE; ++i) {
+        const int row = (wave * G::ADMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
         asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + (pslot ^ (row & 7)) * G::EPV;
     }
 #pragma unroll
-    for (int i = 0; i < BPW; ++i) {
-        const int row = (dwave * BPW + i) * G::ROWS_PER_DMA + drow;
+    for (int i = 0; i < G::BDMA_PER_WAVE; ++i) {
+        const int row = (wave * G::BDMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
         bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + (pslot ^ (row & 7)) * G::EPV;
     }
     auto dma = [&](int stage, int k0) {
-        if (!dma_wave) return;
-        char* abase = smem + stage * G::STAGE_BYTES + (dwave * APW) * 1024;
-        char* bbase = smem + stage * G::STAGE_BYTES + G::A_BYTES + (dwave * BPW) * 1024;
+        char* abase = smem + stage * G::STAGE_BYTES + (wave * G::ADMA_PER_WAVE) * 1024;
+        char* bbase = smem + stage * G::STAGE_BYTES + G::A_BYTES + (wave * G::BDMA_PER_WAVE) * 1024;
 #pragma unroll
-        for (int i = 0; i < APW; ++i)
+        for (int i = 0; i < G::ADMA_PER_WAVE; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k0), (lptr_t)(abase + i * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
+        for (int i = 0; i < G::BDMA_PER_WAVE; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + k0), (lptr_t)(bbase + i * 1024), 16, 0, 0);
     };
     // K tail: plain loads with zero fill, written to the same swizzled image
@@ -156,7 +138,8 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
     };
 
     stage(0, 0);
-    block_sync();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const int frow = lane & 15;                             // fragment row within a 16-row block (== row & 15)
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
@@ -176,7 +159,8 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
 #pragma unroll
                 for (int ni = 0; ni < G::NI; ++ni) mfma_step<T>(acc[mi][ni], fb[ni], fa[mi]);
         }
-        block_sync();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 
