@@ -33,7 +33,7 @@ struct AttnMArgs {
     DropRng drop;
 };
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf_bits(a) | ((uint32_t)f2bf_bits(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // stage rows [0, T) x columns [col0, col0 + DCH) of a row-major global matrix into an LDS tile (rows >= T zeroed)
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, size_t row0, int pitch, int col0, int ncols,

@@ -17,11 +17,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16 x) { return __uint_as_float(((uint32_t)x.v) << 16); }
 __device__ __forceinline__ float bfbits2f(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
-__device__ __forceinline__ unsigned short f2bf_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                   // round-nearest-even
-    return (unsigned short)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+// fp32 -> bf16, round-to-nearest-even: the native casts lower to v_cvt_pk_bf16_f32 (ONE instruction per pair; a
+// hand-rolled integer RNE cost ~8 VALU per element and made every bf16 store path -- GEMM epilogue, LayerNorm,
+// attention -- VALU-bound: the 256 x 256 GEMM epilogue alone took as long as its K = 768 main loop)
+__device__ __forceinline__ unsigned short f2bf_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16 f2bf(float f) { return bf16{f2bf_bits(f)}; }
 
@@ -52,10 +57,8 @@ struct io<bf16> {
         o[2] = bfbits2f(v.y & 0xffffu); o[3] = bfbits2f(v.y >> 16);
     }
     __device__ __forceinline__ static void store4(bf16* p, const float (&o)[4]) {
-        uint2 v;
-        v.x = (uint32_t)f2bf_bits(o[0]) | ((uint32_t)f2bf_bits(o[1]) << 16);
-        v.y = (uint32_t)f2bf_bits(o[2]) | ((uint32_t)f2bf_bits(o[3]) << 16);
-        *reinterpret_cast<uint2*>(p) = v;
+        const f32x4_t f = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, __builtin_convertvector(f, bf16x4_t));
     }
     __device__ __forceinline__ static float load1(const bf16* p) { return bf2f(*p); }
     __device__ __forceinline__ static void store1(bf16* p, float v) { *p = f2bf(v); }

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
         if (shadow) {
             uint2 s;
-            s.x = (uint32_t)f2bf_bits(pa[0]) | ((uint32_t)f2bf_bits(pa[1]) << 16);
-            s.y = (uint32_t)f2bf_bits(pa[2]) | ((uint32_t)f2bf_bits(pa[3]) << 16);
+            s.x = pack_bf16x2(pa[0], pa[1]);
+            s.y = pack_bf16x2(pa[2], pa[3]);
             reinterpret_cast<uint2*>(shadow)[i] = s;
         }
     }
