@@ -19,7 +19,11 @@ struct GemmArgs {
     int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
 };
 
-template <typename G, typename TI, typename TO>
+// ACT is a compile-time epilogue selector (0 linear, 1 GELU, 2 ReLU, 3 x GELU'(dact_in), 4 x ReLU'(dact_in)): with the
+// activation chosen at run time every unrolled accumulator block carried the erf / exp expansions and the kernel grew
+// to ~42k instructions (330 KB of code against a 64 KB instruction cache) -- the epilogue then took as long as the
+// K = 768 main loop purely on instruction fetch.
+template <typename G, typename TI, typename TO, int ACT>
 __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -54,17 +58,16 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) pre[r] = v[r];
-        if (p.act == MOREC_ACT_GELU) {
+        if constexpr (ACT == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-        } else if (p.act == MOREC_ACT_RELU) {
+        } else if constexpr (ACT == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.dact != MOREC_ACT_NONE) {
+        } else if constexpr (ACT == 3 || ACT == 4) {
             float u[4];
             io<TO>::load4(din + (size_t)m * p.ldc + n, u);
-            if (p.dact == MOREC_ACT_GELU) {
+            if constexpr (ACT == 3) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
             } else {
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <typename G, typename TI, typename TO>
-static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+template <typename G, typename TI, typename TO, int ACT>
+static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
     int kchunk = (d->K + split - 1) / split;
     kchunk = ((kchunk + G::KE - 1) / G::KE) * G::KE;
@@ -159,14 +162,32 @@ static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
     a.tiles_n = (d->N + G::TN - 1) / G::TN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO, ACT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, zs);
-    hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO, ACT>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
+}
+
+template <typename G, typename TI, typename TO>
+static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+    const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->act == MOREC_ACT_GELU ? 1
+                     : d->act == MOREC_ACT_RELU ? 2 : 0;
+    if constexpr (sizeof(TI) != sizeof(TO)) {     // bf16 operands -> fp32 output: only the linear epilogue is used
+        if (mode != 0) return MOREC_E_UNSUPPORTED;
+        return launch_gemm_act<G, TI, TO, 0>(d, a, s);
+    } else {
+        switch (mode) {
+            case 1: return launch_gemm_act<G, TI, TO, 1>(d, a, s);
+            case 2: return launch_gemm_act<G, TI, TO, 2>(d, a, s);
+            case 3: return launch_gemm_act<G, TI, TO, 3>(d, a, s);
+            case 4: return launch_gemm_act<G, TI, TO, 4>(d, a, s);
+            default: return launch_gemm_act<G, TI, TO, 0>(d, a, s);
+        }
+    }
 }
 
 // 256 x 256 tiles when the problem is large enough to fill the 256 CUs with them, 128 x 128 tiles otherwise
@@ -192,6 +213,7 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
     if (d->split_k > 1 && d->accumulate != 2) return MOREC_E_ARG;
     if (d->accumulate == 2 && d->out_dtype != MOREC_F32) return MOREC_E_DTYPE;
     if (d->dact != MOREC_ACT_NONE && !dact_in) return MOREC_E_ARG;
+    if (d->dact != MOREC_ACT_NONE && d->act != MOREC_ACT_NONE) return MOREC_E_ARG;
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
