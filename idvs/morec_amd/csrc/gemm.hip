@@ -89,12 +89,21 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         static_assert(MIP >= 1 && G::WM * MIP * 16 * ROWB <= G::LDS_BYTES, "output staging does not fit");
         constexpr int RPP = G::WM * MIP * 16;                                 // rows per pass
         constexpr int VPR = G::TN * (int)sizeof(TO) / 16;                     // 16-byte vectors per row
-        for (int which = 0; which < 2; ++which) {                             // 0: aux (pre-activation), 1: C
-            TO* dst = which == 0 ? aux : C;
-            if (!dst) continue;
+        auto flush = [&](TO* dst, int pass) {          // staged rows -> global, full 16-byte lanes along each row
+            __syncthreads();
+            for (int v = threadIdx.x; v < RPP * VPR; v += G::THREADS) {
+                const int lrow = v / VPR, cv = v % VPR;
+                const int m = m0 + (lrow / (MIP * 16)) * (G::MI * 16) + pass * MIP * 16 + (lrow % (MIP * 16));
+                const int n = n0 + cv * EPV_O;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + lrow * ROWB + cv * 16);
+            }
+            __syncthreads();
+        };
 #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                __syncthreads();
+        for (int pass = 0; pass < NPASS; ++pass) {
+            __syncthreads();
+            if (aux) {      // pre-activation first (cheap: acc * alpha + bias), then the activated values reuse the LDS window
 #pragma unroll
                 for (int ml = 0; ml < MIP; ++ml) {
                     const int mi = pass * MIP + ml;
@@ -102,21 +111,35 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                     for (int ni = 0; ni < G::NI; ++ni) {
                         const int n = acc_col_cfg<G>(n0, ni);
-                        float v[4] = {0.f, 0.f, 0.f, 0.f}, pre[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (m < p.M && n < p.N) finish(mi, ni, m, n, v, pre);
+                        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (m < p.M && n < p.N) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pre[r] = acc[mi][ni][r] * p.alpha;
+                            if (p.bias) {
+                                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                                pre[0] += b.x; pre[1] += b.y; pre[2] += b.z; pre[3] += b.w;
+                            }
+                        }
                         char* l = smem + (wm * MIP * 16 + ml * 16 + c16) * ROWB + (wn * G::NI * 16 + ni * 16 + g4 * 4) * (int)sizeof(TO);
-                        io<TO>::store4(reinterpret_cast<TO*>(l), which == 0 ? pre : v);
+                        io<TO>::store4(reinterpret_cast<TO*>(l), pre);
                     }
                 }
-                __syncthreads();
-                for (int v = threadIdx.x; v < RPP * VPR; v += G::THREADS) {
-                    const int lrow = v / VPR, cv = v % VPR;
-                    const int m = m0 + (lrow / (MIP * 16)) * (G::MI * 16) + pass * MIP * 16 + (lrow % (MIP * 16));
-                    const int n = n0 + cv * EPV_O;
-                    if (m < p.M && n < p.N)
-                        *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(smem + lrow * ROWB + cv * 16);
+                flush(aux, pass);
+            }
+#pragma unroll
+            for (int ml = 0; ml < MIP; ++ml) {
+                const int mi = pass * MIP + ml;
+                const int m = acc_row_cfg<G>(m0, mi);
+#pragma unroll
+                for (int ni = 0; ni < G::NI; ++ni) {
+                    const int n = acc_col_cfg<G>(n0, ni);
+                    float v[4] = {0.f, 0.f, 0.f, 0.f}, pre[4];
+                    if (m < p.M && n < p.N) finish(mi, ni, m, n, v, pre);
+                    char* l = smem + (wm * MIP * 16 + ml * 16 + c16) * ROWB + (wn * G::NI * 16 + ni * 16 + g4 * 4) * (int)sizeof(TO);
+                    io<TO>::store4(reinterpret_cast<TO*>(l), v);
                 }
             }
+            flush(C, pass);
         }
         return;
     }
