@@ -28,7 +28,7 @@ struct TnArgs {
     const bf16* DY;
     const bf16* X;
     float* C;
-    int M, N, K, ldy, ldx, ldc, mchunk, tiles_n, tiles_k, atomic, zs;
+    int M, N, K, ldy, ldx, ldc, mchunk, tiles_n, tiles_k, atomic;
     float* slabs;     // split-m partials [gridDim.z][N][K] (plain stores) -- reduced by reduce_slabs_kernel
 };
 
@@ -48,23 +48,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WK, wk = wave % WK;
-    // Workgroup -> (token chunk z, tile) map.  With >= 8 chunks every chunk is pinned to ONE XCD (block b runs on XCD
-    // b % 8): all tiles of a chunk then stream the same [64-token x (N + K)] stage through that XCD's L2 at about the
-    // same time, so each operand byte crosses the fabric once instead of once per tile row / column (PMC: 2.2x the
-    // algorithmic bytes with the chunk-agnostic order, at ~4.2 TB/s -- the kernel was fabric-bound).
-    const int tiles = p.tiles_n * p.tiles_k;
-    int zc, wg;
-    if (p.zs >= 8) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        zc = (idx / tiles) * 8 + xcd;
-        wg = idx % tiles;
-        if (zc >= p.zs) return;
-    } else {
-        zc = blockIdx.x / tiles;
-        wg = xcd_remap(blockIdx.x % tiles, tiles);
-    }
+    const int wg = xcd_remap(blockIdx.x, p.tiles_n * p.tiles_k);
     const int n0 = (wg / p.tiles_k) * TC, k0 = (wg % p.tiles_k) * TC;
-    const int mbeg = zc * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
+    const int mbeg = blockIdx.z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
     const int nt = (mend - mbeg + TT - 1) / TT;
     if (nt <= 0) return;
     const bool tail = ((mend - mbeg) % TT) != 0;
@@ -149,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
             const int k = k0 + (wk * KI + j) * 16 + 4 * g;
             if (k >= p.K) continue;
             if (p.slabs) {
-                float* sl = p.slabs + ((size_t)zc * p.N + n) * p.K + k;
+                float* sl = p.slabs + ((size_t)blockIdx.z * p.N + n) * p.K + k;
                 *reinterpret_cast<float4*>(sl) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 continue;
             }
@@ -204,7 +190,6 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     a.mchunk = mchunk;
     const int zs = (M + mchunk - 1) / mchunk;
     a.tiles_n = (N + TC - 1) / TC; a.tiles_k = (K + TC - 1) / TC;
-    a.zs = zs;
     a.slabs = (zs > 1 && workspace) ? workspace : nullptr;
     if (a.slabs && (K % 4 || !aligned16(workspace))) return MOREC_E_ALIGN;
     static bool attr_set = false;
@@ -212,9 +197,8 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
         attr_set = true;
     }
-    const int tiles = a.tiles_n * a.tiles_k;
-    const int nblocks = zs >= 8 ? tiles * ((zs + 7) / 8) * 8 : tiles * zs;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(nblocks), dim3(NTHREADS), LDS_TN, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
+                       reinterpret_cast<hipStream_t>(stream), a);
     MOREC_CHECK_LAUNCH();
     if (a.slabs) {
         const size_t total4 = (size_t)N * K / 4;

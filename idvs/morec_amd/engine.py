@@ -82,28 +82,11 @@ def _splitk(N: int, K: int, Mp: int) -> int:
     return max(1, min(round(512 / small), max(1, Mp // 512), 64))
 
 
-def _split_tn(N: int, K: int, M: int) -> int:
-    """Token split of the transpose-free dW GEMM.  Chunks are pinned to XCDs (8 per round-robin), so prefer a multiple of 8
-    that fills each XCD's 32 CUs with (tiles x split/8) workgroups; small problems fall back to the generic rule."""
-    tiles = _cdiv(N, 256) * _cdiv(K, 256)
-    best, best_eff = None, 0.0
-    for s in (8, 16, 24, 32):
-        if M // s < 512 or s * N * K * 4 > 200e6:
-            continue
-        per_xcd = tiles * s // 8
-        eff = per_xcd / (_cdiv(per_xcd, 32) * 32)
-        if eff > best_eff + 0.03:
-            best, best_eff = s, eff
-    if best is not None and best_eff >= 0.5:
-        return best
-    return max(1, min(_splitk(N, K, M), 7))
-
-
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
     """dw[N, K] += dy[M, N]^T @ x[M, K]  (fp32 atomics, split over M)."""
     if dy.dtype == torch.bfloat16 and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
         M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
-        ops.gemm_tn_(dy, x, dw, split_m=_split_tn(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
+        ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
         return None, None
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt

@@ -96,7 +96,7 @@ def test_gemm_splitk_atomic(dt):
 
 
 @pytest.mark.parametrize("shape", [(64, 256, 256, 1), (200, 96, 264, 1), (4096, 768, 2304, 4), (20160, 768, 768, 9),
-                                   (2590, 1536, 512, 5), (77, 8, 16, 1), (20160, 768, 768, 16), (9000, 512, 264, 11)])
+                                   (2590, 1536, 512, 5), (77, 8, 16, 1)])
 def test_gemm_tn(shape):
     """dW = dY^T X straight from the row-major operands (transpose reads), incl. token / column tails and split-m atomics."""
     M, N, K, split = shape
