@@ -65,6 +65,44 @@ struct io<bf16> {
     __device__ __forceinline__ static float round(float v) { return bf2f(f2bf(v)); }
 };
 
+// ---- 16-byte vector IO: EV = 4 (f32) or 8 (bf16) elements per lane and access ------------------------------
+template <typename T>
+struct vio;
+template <>
+struct vio<float> {
+    static constexpr int EV = 4;
+    __device__ __forceinline__ static void load(const float* p, float (&o)[4]) { io<float>::load4(p, o); }
+    __device__ __forceinline__ static void store(float* p, const float (&o)[4]) { io<float>::store4(p, o); }
+};
+template <>
+struct vio<bf16> {
+    static constexpr int EV = 8;
+    __device__ __forceinline__ static void load(const bf16* p, float (&o)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        o[0] = bfbits2f(v.x & 0xffffu); o[1] = bfbits2f(v.x >> 16); o[2] = bfbits2f(v.y & 0xffffu); o[3] = bfbits2f(v.y >> 16);
+        o[4] = bfbits2f(v.z & 0xffffu); o[5] = bfbits2f(v.z >> 16); o[6] = bfbits2f(v.w & 0xffffu); o[7] = bfbits2f(v.w >> 16);
+    }
+    __device__ __forceinline__ static void store(bf16* p, const float (&o)[8]) {
+        uint4 v;
+        v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+};
+// EV consecutive fp32 values (parameters: gamma / beta / bias / position rows)
+template <int EV>
+__device__ __forceinline__ void load_f32v(const float* p, float (&o)[EV]) {
+#pragma unroll
+    for (int q = 0; q < EV / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        o[4 * q] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+    }
+}
+template <int EV>
+__device__ __forceinline__ void store_f32v(float* p, const float (&o)[EV]) {
+#pragma unroll
+    for (int q = 0; q < EV / 4; ++q) *reinterpret_cast<float4*>(p + 4 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
 // ---- wave-level reductions (64 lanes) ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -15,43 +15,46 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
                                                              T* __restrict__ z_out, T* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                              int M, int Tlen, int H, DropRng dout) {
+    constexpr int EV = vio<T>::EV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const size_t base = (size_t)row * H;
     const float* w = word + (size_t)ids[row] * H;
     const float* p = pos + (size_t)(row % Tlen) * H;
-    float v[VPL][4];
+    float v[VPL][EV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < H) {
-            const float4 a = *reinterpret_cast<const float4*>(w + c);
-            const float4 b = *reinterpret_cast<const float4*>(p + c);
-            const float4 t = *reinterpret_cast<const float4*>(type0 + c);
+            float a[EV], b[EV], t[EV];
+            load_f32v<EV>(w + c, a);
+            load_f32v<EV>(p + c, b);
+            load_f32v<EV>(type0 + c, t);
             // HF order: (inputs_embeds + token_type_embeddings) + position_embeddings
-            v[i][0] = (a.x + t.x) + b.x; v[i][1] = (a.y + t.y) + b.y;
-            v[i][2] = (a.z + t.z) + b.z; v[i][3] = (a.w + t.w) + b.w;
-            if (z_out) {
-                io<T>::store4(z_out + base + c, v[i]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = io<T>::round(v[i][k]);
+            for (int k = 0; k < EV; ++k) v[i][k] = (a[k] + t[k]) + b[k];
+            if (z_out) {
+                vio<T>::store(z_out + base + c, v[i]);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) v[i][k] = io<T>::round(v[i][k]);
             }
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+#pragma unroll
+            for (int k = 0; k < EV; ++k) sum += v[i][k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[i][k] = 0.f;
+            for (int k = 0; k < EV; ++k) v[i][k] = 0.f;
         }
     }
     const float mean = wave_sum(sum) / (float)H;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < H) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < EV; ++k) {
                 const float d = v[i][k] - mean;
                 sq += d * d;
             }
@@ -64,20 +67,18 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < H) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 b = *reinterpret_cast<const float4*>(beta + c);
-            float o[4];
-            o[0] = (v[i][0] - mean) * rstd * g.x + b.x;
-            o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
-            o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
-            o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+            float g[EV], b[EV], o[EV];
+            load_f32v<EV>(gamma + c, g);
+            load_f32v<EV>(beta + c, b);
+#pragma unroll
+            for (int k = 0; k < EV; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
             if (dout.thresh) {   // HF BertEmbeddings: dropout after the LayerNorm
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
             }
-            io<T>::store4(y + base + c, o);
+            vio<T>::store(y + base + c, o);
         }
     }
 }
@@ -89,8 +90,9 @@ extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const
     if (p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
     const DropRng dout = make_drop(p_out, seed_out);
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !y || M <= 0 || T <= 0 || H <= 0) return MOREC_E_ARG;
-    if (H % 4) return MOREC_E_ALIGN;
-    const int vpl = (H + 255) / 256;
+    const int ev = dtype == MOREC_BF16 ? 8 : 4;
+    if (H % ev) return MOREC_E_ALIGN;
+    const int vpl = (H + 64 * ev - 1) / (64 * ev);
     dim3 grid((M + 3) / 4), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define EMB(TT, V)                                                                                                  \

@@ -4,7 +4,9 @@
 // BertEmbeddings LayerNorm (eps 1e-12); HBM-bound (one read of each input, one write of each output).
 #include "common.hpp"
 
-// VPL = 4-element vectors per lane; a row of N elements needs ceil(N / 256) of them.
+// Every lane moves 16 bytes per access (EV = 4 fp32 / 8 bf16 elements); VPL = such vectors per lane, a row of N
+// elements needs ceil(N / (64 EV)) of them.  (With 8-byte bf16 accesses the kernels were memory-INSTRUCTION bound:
+// same launch time for bf16 and fp32 rows.)
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                      const T* __restrict__ res, const float* __restrict__ pos,
@@ -13,55 +15,61 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int N, DropRng din,
                                                      DropRng dout) {
+    constexpr int EV = vio<T>::EV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const size_t base = (size_t)row * N;
-    float v[VPL][4];
+    float v[VPL][EV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < N) {
-            io<T>::load4(x + base + c, v[i]);
+            vio<T>::load(x + base + c, v[i]);
             if (bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + c);
-                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+                float b[EV];
+                load_f32v<EV>(bias + c, b);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) v[i][k] += b[k];
             }
             if (din.thresh) {   // dropout on the sub-layer output BEFORE the residual add (modules.py:16,62; HF Bert*Output)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = drop_keep(din, base + c + k) ? v[i][k] * din.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) v[i][k] = drop_keep(din, base + c + k) ? v[i][k] * din.inv_keep : 0.f;
             }
             if (res) {
-                float r[4];
-                io<T>::load4(res + base + c, r);
+                float r[EV];
+                vio<T>::load(res + base + c, r);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] += r[k];
+                for (int k = 0; k < EV; ++k) v[i][k] += r[k];
             }
             if (pos) {
-                const float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(row % pos_period) * N + c);
-                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+                float b[EV];
+                load_f32v<EV>(pos + (size_t)(row % pos_period) * N + c, b);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) v[i][k] += b[k];
             }
             if (z_out) {
-                io<T>::store4(z_out + base + c, v[i]);
+                vio<T>::store(z_out + base + c, v[i]);
                 // the backward pass re-reads z at storage precision: normalise exactly what was stored
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[i][k] = io<T>::round(v[i][k]);
+                for (int k = 0; k < EV; ++k) v[i][k] = io<T>::round(v[i][k]);
             }
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+#pragma unroll
+            for (int k = 0; k < EV; ++k) sum += v[i][k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[i][k] = 0.f;
+            for (int k = 0; k < EV; ++k) v[i][k] = 0.f;
         }
     }
     const float mean = wave_sum(sum) / (float)N;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < N) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < EV; ++k) {
                 const float d = v[i][k] - mean;
                 sq += d * d;
             }
@@ -75,28 +83,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
         if (c < N) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            const float4 b = *reinterpret_cast<const float4*>(beta + c);
-            float o[4];
-            o[0] = (v[i][0] - mean) * rstd * g.x + b.x;
-            o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
-            o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
-            o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+            float g[EV], b[EV], o[EV];
+            load_f32v<EV>(gamma + c, g);
+            load_f32v<EV>(beta + c, b);
+#pragma unroll
+            for (int k = 0; k < EV; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
             if (dout.thresh) {  // dropout on the LayerNorm output (embedding stages: modules.py:93-94, HF BertEmbeddings)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
             }
-            io<T>::store4(y + base + c, o);
+            vio<T>::store(y + base + c, o);
         }
     }
 }
 
-// Backward.  Each block owns RPB consecutive rows; every wave handles TWO rows per trip (both rows' loads are in
-// flight together: the kernel is latency-bound otherwise).  Per-column dgamma / dbeta (and the sub-layer bias
-// gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave as ONE
-// atomicAdd per column per block.
+// Backward.  Each block owns RPB consecutive rows, one row per wave per trip.  Per-column dgamma / dbeta (and the
+// sub-layer bias gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave
+// as ONE atomicAdd per column per block.
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                                                      T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias, int M, int N,
                                                      int rows_per_block, DropRng din, DropRng dout) {
+    constexpr int EV = vio<T>::EV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [4][N] dgamma partials
     float* sb = sg + 4 * (size_t)N;                 // [4][N] dbeta partials
@@ -111,87 +117,68 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    float ag[VPL][4], ab[VPL][4], ad[VPL][4], gm[VPL][4];
+    float ag[VPL][EV], ab[VPL][EV], ad[VPL][EV], gm[VPL][EV];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * 4;
+        const int c = (i * 64 + lane) * EV;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
-        if (c < N) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-            gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
-        }
+        for (int k = 0; k < EV; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
+        if (c < N) load_f32v<EV>(gamma + c, gm[i]);
     }
-    for (int rowp = r0 + wave * 2; rowp < r1; rowp += 8) {
-        float g[2][VPL][4], xh[2][VPL][4];
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2];
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const size_t base = (size_t)row * N;
+        const float mu = mean[row], rs = rstd[row];
+        float g[VPL][EV], xh[VPL][EV];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = min(rowp + j, r1 - 1);          // an odd tail re-reads the last row and skips its stores
-            const size_t base = (size_t)row * N;
-            const float mu = mean[row];
-            rs[j] = rstd[row];
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * EV;
+            if (c < N) {
+                float d[EV], zz[EV];
+                vio<T>::load(dy_a + base + c, d);
+                if (dy_b) {
+                    float e[EV];
+                    vio<T>::load(dy_b + base + c, e);
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                if (c < N) {
-                    float d[4], zz[4];
-                    io<T>::load4(dy_a + base + c, d);
-                    if (dy_b) {
-                        float e[4];
-                        io<T>::load4(dy_b + base + c, e);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) d[k] += e[k];
-                    }
-                    if (dout.thresh) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
-                    }
-                    io<T>::load4(z + base + c, zz);
-                    const bool live = (rowp + j) < r1;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        xh[j][i][k] = (zz[k] - mu) * rs[j];
-                        if (live) {
-                            ag[i][k] += d[k] * xh[j][i][k];
-                            ab[i][k] += d[k];
-                        }
-                        g[j][i][k] = d[k] * gm[i][k];
-                        s1[j] += g[j][i][k];
-                        s2[j] += g[j][i][k] * xh[j][i][k];
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { g[j][i][k] = 0.f; xh[j][i][k] = 0.f; }
+                    for (int k = 0; k < EV; ++k) d[k] += e[k];
                 }
+                if (dout.thresh) {
+#pragma unroll
+                    for (int k = 0; k < EV; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
+                }
+                vio<T>::load(z + base + c, zz);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) {
+                    xh[i][k] = (zz[k] - mu) * rs;
+                    ag[i][k] += d[k] * xh[i][k];
+                    ab[i][k] += d[k];
+                    g[i][k] = d[k] * gm[i][k];
+                    s1 += g[i][k];
+                    s2 += g[i][k] * xh[i][k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < EV; ++k) { g[i][k] = 0.f; xh[i][k] = 0.f; }
             }
         }
+        s1 = wave_sum(s1) / (float)N;
+        s2 = wave_sum(s2) / (float)N;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            s1[j] = wave_sum(s1[j]) / (float)N;
-            s2[j] = wave_sum(s2[j]) / (float)N;
-        }
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * EV;
+            if (c < N) {
+                float o[EV];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (rowp + j >= r1) continue;
-            const size_t base = (size_t)(rowp + j) * N;
+                for (int k = 0; k < EV; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+                vio<T>::store(dz + base + c, o);
+                if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                if (c < N) {
-                    float o[4];
+                    for (int k = 0; k < EV; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
+                    vio<T>::store(dzd + base + c, o);
+                }
+                if (dbias) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = rs[j] * (g[j][i][k] - s1[j] - xh[j][i][k] * s2[j]);
-                    io<T>::store4(dz + base + c, o);
-                    if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
-                        io<T>::store4(dzd + base + c, o);
-                    }
-                    if (dbias) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) ad[i][k] += io<T>::round(o[k]);   // what colsum over the stored tensor would see
-                    }
+                    for (int k = 0; k < EV; ++k) ad[i][k] += io<T>::round(o[k]);   // what colsum over the stored tensor would see
                 }
             }
         }
@@ -199,11 +186,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
     if (dgamma || dbias) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * 4;
+            const int c = (i * 64 + lane) * EV;
             if (c < N) {
-                *reinterpret_cast<float4*>(sg + (size_t)wave * N + c) = make_float4(ag[i][0], ag[i][1], ag[i][2], ag[i][3]);
-                *reinterpret_cast<float4*>(sb + (size_t)wave * N + c) = make_float4(ab[i][0], ab[i][1], ab[i][2], ab[i][3]);
-                if (dbias) *reinterpret_cast<float4*>(sd + (size_t)wave * N + c) = make_float4(ad[i][0], ad[i][1], ad[i][2], ad[i][3]);
+                store_f32v<EV>(sg + (size_t)wave * N + c, ag[i]);
+                store_f32v<EV>(sb + (size_t)wave * N + c, ab[i]);
+                if (dbias) store_f32v<EV>(sd + (size_t)wave * N + c, ad[i]);
             }
         }
         __syncthreads();
@@ -221,7 +208,8 @@ template <typename T>
 static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
                            const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
                            float* rstd, int M, int N, DropRng din, DropRng dout, hipStream_t s) {
-    const int vpl = (N + 255) / 256;
+    if (N % vio<T>::EV) return MOREC_E_ALIGN;
+    const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     dim3 grid((M + 3) / 4), block(256);
 #define LN_FWD(V)                                                                                                   \
     hipLaunchKernelGGL((ln_fwd_kernel<T, V>), grid, block, 0, s, (const T*)x, bias, (const T*)res, pos, pos_period, \
@@ -259,7 +247,8 @@ template <typename T>
 static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M,
                            int N, DropRng din, DropRng dout, hipStream_t s) {
-    const int vpl = (N + 255) / 256;
+    if (N % vio<T>::EV) return MOREC_E_ALIGN;
+    const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     const int rpb = 64;
     dim3 grid((M + rpb - 1) / rpb), block(256);
     const size_t lds = (dgamma || dbias) ? (size_t)12 * N * sizeof(float) : 0;
