@@ -333,11 +333,30 @@ def g7(out):
     print("g7 done: hit10", hit10, captured_print)
 
 
+def g10_keys(out):
+    """Ordered ``state_dict`` keys + shapes of the reference ``Model`` (ID tower, BERT micro / base with the installed HF
+    BertModel): the checkpoint / optimizer-grouping surface."""
+    import json
+    from transformers import BertConfig, BertModel
+    res = {}
+    args = make_args(max_seq_len=20, embedding_dim=512, word_embedding_dim=768)
+    m = RefModel(args, 100, False, None, [1.0] * 101)
+    res["id"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    cfg = BertConfig.from_pretrained("/root/reference/pretrained_models/bert_base_uncased", attn_implementation="eager")
+    cfg.num_hidden_layers = 2      # key pattern per layer is what matters; keeps the fixture small
+    m = RefModel(args, 100, True, BertModel(cfg), [1.0] * 101)
+    res["modal_base_2layers"] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    res["named_parameters_modal"] = [k for k, _ in m.named_parameters()]
+    with open(os.path.join(out, "g10_state_dict_keys.json"), "w") as f:
+        json.dump(res, f)
+    print("g10 done:", len(res["id"]), len(res["modal_base_2layers"]))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7)
+    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7, g10=g10_keys)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue
