@@ -68,7 +68,8 @@ def det_param(key: str, shape, seed: int = 12345) -> np.ndarray:
     ``s = min(0.08, 0.6/sqrt(shape[-1]))`` (0.0217 at H=768, BERT's 0.02 class)."""
     shape = tuple(int(s) for s in shape)
     low = key.lower()
-    if low.endswith("layernorm.weight") or low.endswith("layer_norm.weight"):
+    swin_ln = low.endswith((".layernorm_before.weight", ".layernorm_after.weight", ".norm.weight"))   # Swin's LayerNorms
+    if low.endswith("layernorm.weight") or low.endswith("layer_norm.weight") or swin_ln:
         return (1.0 + 0.1 * det_uniform(key, shape, seed=seed)).astype(np.float32)
     if low.endswith(".bias"):
         return det_normal(key, shape, std=0.02, seed=seed)

@@ -146,9 +146,12 @@ def inbatch_ce_loss(prec_vec: torch.Tensor, score_embs: torch.Tensor, sample_ite
 
 
 def model_forward(p: dict, sample_items_id, sample_items, log_mask, pop_prob_list, *, max_seq_len: int,
-                  embedding_dim: int, n_heads: int, use_modal: bool, bert_heads: int = 12):
-    """``Model.forward`` ``T/model/model.py:31-69`` (single process, dropout off)."""
-    if use_modal:
+                  embedding_dim: int, n_heads: int, use_modal: bool, bert_heads: int = 12, item_vecs=None):
+    """``Model.forward`` ``T/model/model.py:31-69`` (single process, dropout off).  ``item_vecs``: already encoded item
+    vectors (the vision tower, ``V/model/model.py:38-39``, is restated in ``swin_ref``)."""
+    if item_vecs is not None:
+        score_embs = item_vecs
+    elif use_modal:
         score_embs = text_encoder_forward(p, sample_items, bert_heads)
     else:
         score_embs = p["id_embedding.weight"][sample_items]

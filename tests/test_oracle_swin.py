@@ -1,0 +1,96 @@
+"""Oracle (``oracle/morec_oracle/swin_ref.py``) against the vision goldens captured from the imported reference
+(``tests/golden/make_golden_vision.py``): Swin micro logits / Vit_Encoder vectors / parameter gradients, and the full
+vision ``Model.forward`` loss.  fp32 CPU on both sides: tolerance 2e-5 relative (summation order only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN_DIR
+from idvs.morec_amd.utils.detgen import det_normal, det_param
+from morec_oracle import nn_ref
+from morec_oracle.swin_ref import SwinCfg, swin_forward, vit_encoder_forward
+
+G = np.load(os.path.join(GOLDEN_DIR, "g11_swin_micro.npz"))
+
+
+def cfg_of(tag):
+    R0, ps, ed, ws, N, D = (int(v) for v in G[f"{tag}.cfg"])
+    return SwinCfg(image_size=R0, patch_size=ps, embed_dim=ed, depths=tuple(int(d) for d in G[f"{tag}.depths"]),
+                   num_heads=tuple(int(h) for h in G[f"{tag}.heads"]), window_size=ws), N, D
+
+
+def params_for(tag, requires_grad=True):
+    names = [k[len(f"{tag}.grad_norm."):] for k in G.files if k.startswith(f"{tag}.grad_norm.")]
+    shapes = swin_shapes(cfg_of(tag)[0], cfg_of(tag)[2])
+    return {n: torch.from_numpy(det_param(n, shapes[n])).requires_grad_(requires_grad) for n in names}
+
+
+def swin_shapes(cfg, D, prefix="cv_encoder.image_net."):
+    """name -> shape for every parameter (derived from the config; the golden only stores names)."""
+    sw = prefix + "swin."
+    out = {sw + "embeddings.patch_embeddings.projection.weight": (cfg.embed_dim, 3, cfg.patch_size, cfg.patch_size),
+           sw + "embeddings.patch_embeddings.projection.bias": (cfg.embed_dim,),
+           sw + "embeddings.norm.weight": (cfg.embed_dim,), sw + "embeddings.norm.bias": (cfg.embed_dim,)}
+    C = cfg.embed_dim
+    for s, depth in enumerate(cfg.depths):
+        for b in range(depth):
+            L = sw + f"encoder.layers.{s}.blocks.{b}."
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                out[L + f"attention.{n}.weight"], out[L + f"attention.{n}.bias"] = (C, C), (C,)
+            out[L + "attention.relative_position_bias.relative_position_bias_table"] = ((2 * cfg.window_size - 1) ** 2, cfg.num_heads[s])
+            for n in ("layernorm_before", "layernorm_after"):
+                out[L + n + ".weight"], out[L + n + ".bias"] = (C,), (C,)
+            out[L + "mlp.fc1.weight"], out[L + "mlp.fc1.bias"] = (4 * C, C), (4 * C,)
+            out[L + "mlp.fc2.weight"], out[L + "mlp.fc2.bias"] = (C, 4 * C), (C,)
+        if s < len(cfg.depths) - 1:
+            Dn = sw + f"encoder.layers.{s}.downsample."
+            out[Dn + "reduction.weight"], out[Dn + "norm.weight"], out[Dn + "norm.bias"] = (2 * C, 4 * C), (4 * C,), (4 * C,)
+            C *= 2
+    out[sw + "layernorm.weight"], out[sw + "layernorm.bias"] = (C,), (C,)
+    out[prefix + "classifier.weight"], out[prefix + "classifier.bias"] = (D, C), (D,)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["m2", "m3"])
+def test_swin_oracle_matches_reference(tag):
+    cfg, N, D = cfg_of(tag)
+    p = params_for(tag)
+    x = torch.from_numpy(det_normal(f"g11{tag}.x", (N, 3, cfg.image_size, cfg.image_size), std=1.0))
+    logits = swin_forward(p, cfg, x)
+    np.testing.assert_allclose(logits.detach().numpy(), G[f"{tag}.logits"], rtol=2e-5, atol=2e-6)
+    y = vit_encoder_forward(p, cfg, x)
+    np.testing.assert_allclose(y.detach().numpy(), G[f"{tag}.y"], rtol=2e-5, atol=2e-6)
+    R = torch.from_numpy(det_normal(f"g11{tag}.R", (N, D), std=1.0))
+    (y * R).sum().backward()
+    for n, t in p.items():
+        ref = float(G[f"{tag}.grad_norm.{n}"])
+        assert abs(float(t.grad.double().norm()) - ref) <= 2e-4 * ref + 1e-7, n
+    for k in G.files:
+        if k.startswith(f"{tag}.grad."):
+            n = k[len(f"{tag}.grad."):]
+            g = G[k]
+            np.testing.assert_allclose(p[n].grad.numpy(), g, rtol=1e-3, atol=2e-5 * np.abs(g).max() + 1e-8, err_msg=n)
+
+
+def test_vision_model_loss_matches_reference():
+    S, D, item_num, B = (int(v) for v in G["full.cfg"])
+    cfg = SwinCfg(image_size=56, patch_size=4, embed_dim=32, depths=(2, 2), num_heads=(1, 2), window_size=7)
+    names = [k[len("full.grad_norm."):] for k in G.files if k.startswith("full.grad_norm.")]
+    shapes = swin_shapes(cfg, D)
+    from idvs.morec_amd.model.spec import sasrec_param_shapes
+    shapes.update(sasrec_param_shapes(S, D, 2))
+    p = {n: torch.from_numpy(det_param(n, shapes[n])).requires_grad_(True) for n in names}
+    ids, log_mask, pop = G["full.ids"], G["full.log_mask"], G["full.pop"]
+    images = det_normal("g11f.images", (item_num + 1, 3, 56, 56), std=1.0).astype(np.float32)
+    images[0] = 0.0
+    px = torch.from_numpy(images[ids.reshape(-1)])
+    E = vit_encoder_forward(p, cfg, px)
+    loss = nn_ref.model_forward(p, torch.from_numpy(ids).view(-1), None, torch.from_numpy(log_mask), pop, max_seq_len=S,
+                                embedding_dim=D, n_heads=2, use_modal=True, item_vecs=E)
+    assert abs(float(loss.detach()) - float(G["full.loss"])) < 2e-5
+    loss.backward()
+    for n in names:
+        ref = float(G[f"full.grad_norm.{n}"])
+        assert abs(float(p[n].grad.double().norm()) - ref) <= 5e-4 * ref + 1e-7, n
