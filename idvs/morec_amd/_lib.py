@@ -36,6 +36,11 @@ class CeDesc(C.Structure):
                 ("dtype", C.c_int)]
 
 
+class SwinAttnDesc(C.Structure):
+    _fields_ = [("n_img", C.c_int), ("H", C.c_int), ("W", C.c_int), ("window", C.c_int), ("shift", C.c_int),
+                ("heads", C.c_int), ("dh", C.c_int), ("scale", C.c_float), ("dtype", C.c_int)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "morec_strerror": (C.c_char_p, [C.c_int]),
@@ -48,9 +53,9 @@ _SIGS = {
     "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
-                                      C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P]),
+                                      C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P, C.c_int, _P]),
     "morec_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
-                                      C.c_uint64, C.c_float, C.c_uint64, _P]),
+                                      C.c_uint64, C.c_float, C.c_uint64, _P, _P, C.c_int, _P]),
     "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),
     "morec_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
@@ -69,6 +74,16 @@ _SIGS = {
     "morec_eval_rank": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_dropout_keep_mask": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_uint64, _P]),
     "morec_probe": (C.c_int, [_P, _P]),
+    "morec_swin_attn_fwd": (C.c_int, [C.POINTER(SwinAttnDesc), _P, _P, _P, _P]),
+    "morec_swin_attn_bwd": (C.c_int, [C.POINTER(SwinAttnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "morec_swin_bias_expand": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "morec_swin_bias_reduce": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "morec_swin_patchify": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_swin_merge": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_swin_pool_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_swin_pool_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_bias_residual": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_droppath_scale": (C.c_int, [_P, C.c_int, C.c_float, C.c_uint64, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -14,12 +14,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const float* __restrict__ beta, float eps, T* __restrict__ z_out,
                                                      T* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int N, DropRng din,
-                                                     DropRng dout) {
+                                                     DropRng dout, const float* __restrict__ rowscale, int rps) {
     constexpr int EV = vio<T>::EV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const size_t base = (size_t)row * N;
+    const float rsc = rowscale ? rowscale[row / rps] : 1.0f;   // DropPath: per-sample scale of the sub-layer branch
     float v[VPL][EV];
     float sum = 0.f;
 #pragma unroll
@@ -32,6 +33,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 load_f32v<EV>(bias + c, b);
 #pragma unroll
                 for (int k = 0; k < EV; ++k) v[i][k] += b[k];
+            }
+            if (rowscale) {
+#pragma unroll
+                for (int k = 0; k < EV; ++k) v[i][k] *= rsc;
             }
             if (din.thresh) {   // dropout on the sub-layer output BEFORE the residual add (modules.py:16,62; HF Bert*Output)
 #pragma unroll
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias, int M, int N,
-                                                     int rows_per_block, DropRng din, DropRng dout) {
+                                                     int rows_per_block, DropRng din, DropRng dout,
+                                                     const T* __restrict__ dres, const float* __restrict__ rowscale, int rps) {
     constexpr int EV = vio<T>::EV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sg = reinterpret_cast<float*>(smem_raw);  // [4][N] dgamma partials
@@ -170,10 +176,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 float o[EV];
 #pragma unroll
                 for (int k = 0; k < EV; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
+                if (dres) {   // pre-LN blocks: the residual stream's own gradient joins the LayerNorm-input gradient
+                    float e[EV];
+                    vio<T>::load(dres + base + c, e);
+#pragma unroll
+                    for (int k = 0; k < EV; ++k) o[k] += e[k];
+                }
                 vio<T>::store(dz + base + c, o);
                 if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
+                    const float rsc = rowscale ? rowscale[row / rps] : 1.0f;
 #pragma unroll
-                    for (int k = 0; k < EV; ++k) o[k] = drop_keep(din, base + c + k) ? o[k] * din.inv_keep : 0.f;
+                    for (int k = 0; k < EV; ++k) o[k] = (!din.thresh || drop_keep(din, base + c + k)) ? o[k] * din.inv_keep * rsc : 0.f;
                     vio<T>::store(dzd + base + c, o);
                 }
                 if (dbias) {
@@ -207,13 +220,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 template <typename T>
 static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
                            const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
-                           float* rstd, int M, int N, DropRng din, DropRng dout, hipStream_t s) {
+                           float* rstd, int M, int N, DropRng din, DropRng dout, const float* rowscale, int rps,
+                           hipStream_t s) {
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     dim3 grid((M + 3) / 4), block(256);
 #define LN_FWD(V)                                                                                                   \
     hipLaunchKernelGGL((ln_fwd_kernel<T, V>), grid, block, 0, s, (const T*)x, bias, (const T*)res, pos, pos_period, \
-                       gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din, dout)
+                       gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din, dout, rowscale, rps)
     if (vpl <= 1) LN_FWD(1);
     else if (vpl <= 2) LN_FWD(2);
     else if (vpl <= 3) LN_FWD(3);
@@ -229,24 +243,26 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
 extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const float* pos,
                                    int pos_period, const float* gamma, const float* beta, float eps, void* z_out,
                                    void* y, float* mean, float* rstd, int M, int N, int dtype, float p_in,
-                                   uint64_t seed_in, float p_out, uint64_t seed_out, void* stream) {
+                                   uint64_t seed_in, float p_out, uint64_t seed_out, const float* rowscale,
+                                   int rows_per_scale, void* stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) return MOREC_E_ARG;
+    if (rowscale && rows_per_scale <= 0) return MOREC_E_ARG;
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
     const DropRng din = make_drop(p_in, seed_in), dout = make_drop(p_out, seed_out);
     if (N % 4 || (dtype == MOREC_BF16 && N % 4)) return MOREC_E_ALIGN;
     if (pos && pos_period <= 0) return MOREC_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
-        return ln_fwd_dispatch<float>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, s);
+        return ln_fwd_dispatch<float>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, rowscale, rows_per_scale, s);
     if (dtype == MOREC_BF16)
-        return ln_fwd_dispatch<bf16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, s);
+        return ln_fwd_dispatch<bf16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, rowscale, rows_per_scale, s);
     return MOREC_E_DTYPE;
 }
 
 template <typename T>
 static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M,
-                           int N, DropRng din, DropRng dout, hipStream_t s) {
+                           int N, DropRng din, DropRng dout, const void* dres, const float* rowscale, int rps, hipStream_t s) {
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     const int rpb = 64;
@@ -259,7 +275,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
         hipLaunchKernelGGL((ln_bwd_kernel<T, V>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,          \
                            (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, \
-                           dout);                                                                               \
+                           dout, (const T*)dres, rowscale, rps);                                                \
     } while (0)
     if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
@@ -276,19 +292,21 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
 extern "C" int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean,
                                    const float* rstd, const float* gamma, void* dz, void* dzd, float* dgamma,
                                    float* dbeta, float* dbias, int M, int N, int dtype, float p_in, uint64_t seed_in,
-                                   float p_out, uint64_t seed_out, void* stream) {
+                                   float p_out, uint64_t seed_out, const void* dres, const float* rowscale,
+                                   int rows_per_scale, void* stream) {
     if (!dy_a || !z || !mean || !rstd || !gamma || !dz || M <= 0 || N <= 0) return MOREC_E_ARG;
     if (p_in < 0.f || p_in >= 1.f || p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
-    if ((p_in > 0.f) != (dzd != nullptr)) return MOREC_E_ARG;
+    if ((p_in > 0.f || rowscale != nullptr) != (dzd != nullptr)) return MOREC_E_ARG;
+    if (rowscale && rows_per_scale <= 0) return MOREC_E_ARG;
     const DropRng din = make_drop(p_in, seed_in), dout = make_drop(p_out, seed_out);
     if ((dgamma == nullptr) != (dbeta == nullptr)) return MOREC_E_ARG;
     if (N % 4) return MOREC_E_ALIGN;
     if (N > 4096) return MOREC_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
-        return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, s);
+        return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rows_per_scale, s);
     if (dtype == MOREC_BF16)
-        return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, s);
+        return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rows_per_scale, s);
     return MOREC_E_DTYPE;
 }
 

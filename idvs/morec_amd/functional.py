@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from . import engine, ops
+from . import engine, ops, swin_engine
 
 
 def _zeros_like_params(names, params, skip=()):
@@ -68,6 +68,32 @@ class BertEncoderFn(torch.autograd.Function):
                for n in ("query", "key", "value") for k in ("weight", "bias")}
         grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
         engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+        needs = ctx.needs[2:]
+        return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
+
+
+class SwinEncoderFn(torch.autograd.Function):
+    """``Vit_Encoder.forward`` (``V/model/encoders.py:30-31``) over HF ``SwinForImageClassification`` arithmetic."""
+
+    @staticmethod
+    def forward(ctx, pixels, cfg, *params):
+        names, shape, dtype, prefix, drop, training = cfg
+        p = dict(zip(names, params))
+        need = any(ctx.needs_input_grad)
+        prep = swin_engine.swin_prepare(p, shape, dtype, prefix)
+        item, saved = swin_engine.swin_forward(p, prep, shape, pixels, dtype, need, prefix, drop, training)
+        ctx.stuff = (p, prep, saved, names, prefix, shape)
+        ctx.needs = ctx.needs_input_grad
+        return item
+
+    @staticmethod
+    def backward(ctx, d_item):
+        p, prep, saved, names, prefix, shape = ctx.stuff
+        ctx.stuff = None
+        qkv = {swin_engine.swin_layer_names(prefix, s, b) + f"attention.{n}.{k}" for s, depth in enumerate(shape.depths)
+               for b in range(depth) for n in ("q_proj", "k_proj", "v_proj") for k in ("weight", "bias")}
+        grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
+        swin_engine.swin_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
         needs = ctx.needs[2:]
         return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
 

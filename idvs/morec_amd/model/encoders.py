@@ -10,6 +10,7 @@ from .. import functional as F_
 from ..engine import NO_DROP, DropCfg
 from ..ops import FLT_MIN_MASK
 from .bert import HipBertModel
+from .swin import HipSwinForImageClassification
 from .modules import TransformerEncoder
 
 
@@ -93,6 +94,27 @@ class Bert_Encoder(nn.Module):
 
     def forward(self, news):
         return self.encode(news).float()
+
+
+class Vit_Encoder(nn.Module):
+    """``V/model/encoders.py:24-31``: ``GELU(image_net(item_content)[0])`` with ``image_net`` a Swin classifier whose head
+    was replaced by ``Linear(num_features, embedding_dim)`` (``V/run.py:47-54``).  BEiT shares the class in the reference;
+    only Swin (the benchmarked tower, ``V/train_swin_tiny.py``) is implemented."""
+
+    def __init__(self, image_net, compute_dtype=None):
+        super().__init__()
+        self.image_net = image_net if isinstance(image_net, HipSwinForImageClassification) \
+            else HipSwinForImageClassification.from_hf(image_net)
+        self.compute_dtype = compute_dtype or resolve_dtype()
+
+    def encode(self, item_content, drop: DropCfg = NO_DROP):
+        named = [(n, p) for n, p in self.named_parameters()]
+        names, params = zip(*named)
+        cfg = (names, self.image_net.shape, self.compute_dtype, "image_net.", drop, self.training)
+        return F_.SwinEncoderFn.apply(item_content, cfg, *params)
+
+    def forward(self, item_content):
+        return self.encode(item_content).float()
 
 
 class IdEmbedding(nn.Module):

@@ -1,6 +1,8 @@
-"""``Model``: drop-in for ``T/model/model.py`` -- same constructor, ``forward`` signature, sub-module attribute
-names (``bert_encoder`` / ``id_embedding`` / ``user_encoder``) and ``state_dict`` keys; every FLOP of the
-forward AND backward runs in hand-written gfx950 kernels behind ``libmorec_hip.so``."""
+"""``Model``: drop-in for ``T/model/model.py`` and ``V/model/model.py`` -- same constructor, ``forward`` signature,
+sub-module attribute names (``bert_encoder`` | ``cv_encoder`` / ``id_embedding`` / ``user_encoder``) and ``state_dict``
+keys; every FLOP of the forward AND backward runs in hand-written gfx950 kernels behind ``libmorec_hip.so``.  The
+vision variant is selected the way the reference's two packages differ: ``args.CV_model_load`` is present
+(``V/model/model.py:24-29``) and the fourth constructor argument is the image network."""
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -8,7 +10,7 @@ from torch.nn.init import xavier_normal_
 
 from .. import engine
 from .. import functional as F_
-from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, resolve_dtype
+from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, Vit_Encoder, resolve_dtype
 
 
 class Model(nn.Module):
@@ -27,7 +29,13 @@ class Model(nn.Module):
         self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
                                          num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
                                          n_layers=args.transformer_block, compute_dtype=self.compute_dtype)
-        if self.use_modal:
+        self.vision = hasattr(args, "CV_model_load")
+        if self.use_modal and self.vision:
+            if "swin" not in args.CV_model_load:
+                raise NotImplementedError("only the Swin tower of V/model/model.py:24-29 is implemented (ResNet / BEiT / MAE "
+                                          "launchers are outside the benchmarked path)")
+            self.cv_encoder = Vit_Encoder(image_net=bert_model, compute_dtype=self.compute_dtype)
+        elif self.use_modal:
             self.bert_encoder = Bert_Encoder(args=args, bert_model=bert_model)
         else:
             self.id_embedding = IdEmbedding(item_num + 1, args.embedding_dim, padding_idx=0,
@@ -48,7 +56,9 @@ class Model(nn.Module):
         p = float(self.args.drop_rate)
         d_user = engine.DropCfg(p, p, base ^ 0x5555555555555555) if p > 0 else engine.NO_DROP
         d_item = engine.NO_DROP
-        if self.use_modal:
+        if self.use_modal and self.vision:
+            d_item = engine.DropCfg(0.0, 0.0, base)      # only the DropPath streams are drawn from it
+        elif self.use_modal:
             c = self.bert_encoder.text_encoders["title"].bert_model.config
             ph, pa = float(getattr(c, "hidden_dropout_prob", 0.0)), float(getattr(c, "attention_probs_dropout_prob", 0.0))
             if ph > 0 or pa > 0:
@@ -64,7 +74,9 @@ class Model(nn.Module):
         D = self.args.embedding_dim
         ids = sample_items_id.view(-1)
         d_item, d_user = self.dropout_cfgs()
-        if self.use_modal:
+        if self.use_modal and self.vision:
+            score_embs = self.cv_encoder.encode(sample_items, d_item)
+        elif self.use_modal:
             score_embs = self.bert_encoder.encode(sample_items, d_item)
         else:
             score_embs = self.id_embedding.encode(sample_items.view(-1))

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, AttnDesc, CeDesc, GemmDesc, check
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, AttnDesc, CeDesc, GemmDesc, SwinAttnDesc, check
 
 FLT_MIN_MASK = -3.4028234663852886e38  # torch.finfo(torch.float32).min: HF eager additive key mask
 
@@ -121,29 +121,31 @@ def colsum_(x, out, M=None, N=None, ld=None):
 
 
 def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, save_z=True, z_inplace=False,
-                  p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+                  p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, rowscale=None, rows_per_scale=0):
     _dev(x)
     M, N = x.shape
     y = torch.empty_like(x)
-    need_z = save_z and (bias is not None or res is not None or pos is not None or p_in > 0)
+    need_z = save_z and (bias is not None or res is not None or pos is not None or p_in > 0 or rowscale is not None)
     z = (x if z_inplace else torch.empty_like(x)) if need_z else None
     mean = torch.empty(M, device=x.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
     check(_lib.lib().morec_layernorm_fwd(_p(x), _p(bias), _p(res), _p(pos), pos_period, _p(gamma), _p(beta), eps, _p(z),
                                          _p(y), _p(mean), _p(rstd), M, N, code(x.dtype), p_in, seed_in, p_out, seed_out,
-                                         _stream()), "morec_layernorm_fwd")
+                                         _p(rowscale), rows_per_scale, _stream()), "morec_layernorm_fwd")
     return y, (z if need_z else x), mean, rstd
 
 
-def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None):
-    """Returns (dz, dzd): dz feeds the residual branch, dzd = dropout-backward of dz feeds the sub-layer (dzd is dz when p_in = 0)."""
+def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None,
+                  dres=None, rowscale=None, rows_per_scale=0):
+    """Returns (dz, dzd): dz feeds the residual branch, dzd = dropout / DropPath backward of dz feeds the sub-layer (dzd is
+    dz when p_in = 0 and there is no rowscale).  ``dres``: gradient arriving at z along a pre-LN residual stream."""
     _dev(dy_a)
     M, N = z.shape
     dz = torch.empty_like(z)
-    dzd = torch.empty_like(z) if p_in > 0 else None
+    dzd = torch.empty_like(z) if (p_in > 0 or rowscale is not None) else None
     check(_lib.lib().morec_layernorm_bwd(_p(dy_a), _p(dy_b), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dzd),
                                          _p(dgamma), _p(dbeta), _p(dbias), M, N, code(z.dtype), p_in, seed_in, p_out, seed_out,
-                                         _stream()), "morec_layernorm_bwd")
+                                         _p(dres), _p(rowscale), rows_per_scale, _stream()), "morec_layernorm_bwd")
     return dz, (dz if dzd is None else dzd)
 
 
@@ -250,6 +252,86 @@ def eval_rank(prec, item_emb, hist32, target32):
     check(_lib.lib().morec_eval_rank(_p(_dev(prec)), _p(_dev(item_emb)), _p(_dev(hist32)), hist32.shape[1], _p(target32),
                                      _p(rank), _p(ts), U, item_emb.shape[0], D, _stream()), "morec_eval_rank")
     return rank
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Swin vision tower
+# ---------------------------------------------------------------------------------------------------------
+def swin_attn_desc(n_img, H, W, window, shift, heads, dh, dtype):
+    return SwinAttnDesc(n_img, H, W, window, shift, heads, dh, float(dh) ** -0.5, code(dtype))
+
+
+def swin_attn_fwd(desc, qkv, bias_t):
+    _dev(qkv), _dev(bias_t)
+    ctx = torch.empty((qkv.shape[0], qkv.shape[1] // 3), device=qkv.device, dtype=qkv.dtype)
+    check(_lib.lib().morec_swin_attn_fwd(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _stream()), "morec_swin_attn_fwd")
+    return ctx
+
+
+def swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t=None):
+    _dev(dctx), _dev(ctx)
+    dqkv = torch.empty_like(qkv)
+    check(_lib.lib().morec_swin_attn_bwd(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _p(dctx), _p(dqkv), _p(dbias_t),
+                                         _stream()), "morec_swin_attn_bwd")
+    return dqkv
+
+
+def swin_bias_expand(table, window):
+    heads = table.shape[1]
+    out = torch.empty((heads, window ** 2, window ** 2), device=table.device, dtype=torch.float32)
+    check(_lib.lib().morec_swin_bias_expand(_p(_dev(table)), _p(out), window, heads, _stream()), "morec_swin_bias_expand")
+    return out
+
+
+def swin_bias_reduce_(dbias_t, dtable, window):
+    check(_lib.lib().morec_swin_bias_reduce(_p(_dev(dbias_t)), _p(dtable), window, dtable.shape[1], _stream()),
+          "morec_swin_bias_reduce")
+
+
+def swin_patchify(pixels, patch, dtype):
+    _dev(pixels)
+    if pixels.dtype != torch.float32:
+        raise _lib.MorecError("pixels must be fp32 NCHW")
+    n, c, R, _ = pixels.shape
+    G = R // patch
+    out = torch.empty((n * G * G, c * patch * patch), device=pixels.device, dtype=dtype)
+    check(_lib.lib().morec_swin_patchify(_p(pixels), _p(out), n, c, R, patch, out.stride(0), code(dtype), _stream()),
+          "morec_swin_patchify")
+    return out
+
+
+def swin_merge(x, n_img, H, W, Cc, reverse=False):
+    _dev(x)
+    out = torch.empty((n_img * H * W, Cc) if reverse else (n_img * (H // 2) * (W // 2), 4 * Cc), device=x.device, dtype=x.dtype)
+    check(_lib.lib().morec_swin_merge(_p(x), _p(out), n_img, H, W, Cc, int(reverse), code(x.dtype), _stream()), "morec_swin_merge")
+    return out
+
+
+def swin_pool_fwd(x, n_img, tokens):
+    out = torch.empty((n_img, x.shape[1]), device=x.device, dtype=x.dtype)
+    check(_lib.lib().morec_swin_pool_fwd(_p(_dev(x)), _p(out), n_img, tokens, x.shape[1], code(x.dtype), _stream()), "morec_swin_pool_fwd")
+    return out
+
+
+def swin_pool_bwd(dout, n_img, tokens):
+    dx = torch.empty((n_img * tokens, dout.shape[1]), device=dout.device, dtype=dout.dtype)
+    check(_lib.lib().morec_swin_pool_bwd(_p(_dev(dout)), _p(dx), n_img, tokens, dout.shape[1], code(dout.dtype), _stream()), "morec_swin_pool_bwd")
+    return dx
+
+
+def bias_residual(a, bias, res, rowscale=None, rows_per_scale=0, inplace=True):
+    """res + rowscale[row / rows_per_scale] * (a + bias), written over ``a`` by default."""
+    _dev(a), _dev(res)
+    out = a if inplace else torch.empty_like(a)
+    check(_lib.lib().morec_bias_residual(_p(a), _p(bias), _p(res), _p(rowscale), rows_per_scale, _p(out), a.shape[0], a.shape[1],
+                                         code(a.dtype), _stream()), "morec_bias_residual")
+    return out
+
+
+def droppath_scale(n, p, seed, device="cuda"):
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    check(_lib.lib().morec_droppath_scale(_p(out), n, p, seed, _stream()), "morec_droppath_scale")
+    return out
 
 
 def dropout_keep_mask(n, p, seed, device="cuda"):

@@ -93,17 +93,21 @@ int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, vo
  * Dropout is counter-based: element kept iff hash(seed, m*N + n) >= p * 2^32, scaled by 1/(1-p); p = 0 disables.
  * drop_in  = the Dropout the reference applies to the sub-layer output before the residual add;
  * drop_out = the Dropout applied to the LayerNorm output of the embedding stages.
+ * rowscale (may be NULL): per-sample DropPath scale of the sub-layer branch (HF SwinDropPath, modeling_swin.py:42-60):
+ * (x + bias) is multiplied by rowscale[m / rows_per_scale] before the residual add.
  * ------------------------------------------------------------------------------------------ */
 int morec_layernorm_fwd(const void* x, const float* bias, const void* res, const float* pos, int pos_period,
                         const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
                         float* rstd, int M, int N, int dtype, float p_in, uint64_t seed_in, float p_out,
-                        uint64_t seed_out, void* stream);
-/* dz = LN'(drop_out'(dy_a + dy_b); z); dzd = drop_in'(dz) (required iff p_in > 0, else NULL).
- * dgamma/dbeta (and, if given, dbias = column sums of dzd: the gradient of the fused pre-add bias) are atomically
- * accumulated (fp32, [N]).  dy_b and dbias may be NULL. */
+                        uint64_t seed_out, const float* rowscale, int rows_per_scale, void* stream);
+/* dz = LN'(drop_out'(dy_a + dy_b); z) (+ dres); dzd = rowscale * drop_in'(dz) (required iff p_in > 0 or rowscale, else
+ * NULL).  dres (may be NULL) is the gradient that reaches z directly along the residual stream of a pre-LN block
+ * (HF SwinLayer, modeling_swin.py:536,560-566).  dgamma/dbeta (and, if given, dbias = column sums of dzd: the gradient of
+ * the fused pre-add bias) are atomically accumulated (fp32, [N]).  dy_b, dgamma/dbeta and dbias may be NULL. */
 int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
                         const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M, int N,
-                        int dtype, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
+                        int dtype, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, const void* dres,
+                        const float* rowscale, int rows_per_scale, void* stream);
 /* dpos[m % period, n] += dz[m, n]  (position-embedding gradient, fp32 atomics) */
 int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream);
 
@@ -126,6 +130,44 @@ typedef struct {
 int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx, void* stream);
 int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx, void* dqkv,
                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Swin vision tower (V/model/encoders.py:24-31 -> HF SwinForImageClassification, built at V/run.py:47-54;
+ * transformers/models/swin/modeling_swin.py).  Token rows are kept in natural (image, y, x) order throughout:
+ * window partition (:486-495), cyclic shift (:609-618) and window reverse (:498-505) are index arithmetic
+ * inside the attention kernel, never copies.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int n_img, H, W;   /* token grid per image */
+    int window;        /* 7 (49 tokens); H, W multiples of it */
+    int shift;         /* 0 | window/2 (SW-MSA blocks): adds the -100 region mask of :584-607 */
+    int heads, dh;     /* dh = 32 */
+    float scale;       /* dh^-0.5 */
+    int dtype;
+} morec_swin_attn_desc;
+/* ctx[row, h*dh..] = softmax(q.k*scale + bias_t[h][j][i] + shift mask) v over the row's window (SwinAttention :401-468).
+ * qkv [rows, 3*heads*dh] = [q | k | v]; bias_t fp32 [heads][window^2 (key j)][window^2 (query i)]. */
+int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, void* stream);
+/* dqkv from dctx (P recomputed; ctx = saved forward output); dbias_t (may be NULL) += dS summed over windows. */
+int morec_swin_attn_bwd(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, const void* ctx,
+                        const void* dctx, void* dqkv, float* dbias_t, void* stream);
+/* bias_t[h][j][i] = table[rel_index(i, j)][h] (SwinRelativePositionBias :329-370) and its transpose-scatter gradient */
+int morec_swin_bias_expand(const float* table, float* bias_t, int window, int heads, void* stream);
+int morec_swin_bias_reduce(const float* dbias_t, float* dtable, int window, int heads, void* stream);
+/* im2col of the patch-embedding conv (SwinPatchEmbeddings :247-286): out[(n,py,px), (c,i,j)] = pixels[n,c,py*p+i,px*p+j];
+ * pixels fp32 NCHW (what V/run.py:201-204 puts on the device), out dtype rows of pitch ld_out. */
+int morec_swin_patchify(const float* pixels, void* out, int n_img, int channels, int R, int patch, int ld_out, int dtype,
+                        void* stream);
+/* SwinPatchMerging gather (:309-320): [n,H,W,C] -> [n,H/2,W/2,4C]; reverse != 0 is the inverse copy (backward). */
+int morec_swin_merge(const void* in, void* out, int n_img, int H, int W, int C, int reverse, int dtype, void* stream);
+/* mean over each image's tokens (AdaptiveAvgPool1d(1), :876-879) and its backward */
+int morec_swin_pool_fwd(const void* x, void* out, int n_img, int tokens, int C, int dtype, void* stream);
+int morec_swin_pool_bwd(const void* dout, void* dx, int n_img, int tokens, int C, int dtype, void* stream);
+/* out = res + rowscale[m / rows_per_scale] * (a + bias)  (bias, rowscale may be NULL) */
+int morec_bias_residual(const void* a, const float* bias, const void* res, const float* rowscale, int rows_per_scale,
+                        void* out, int M, int N, int dtype, void* stream);
+/* DropPath per-sample scales: out[i] = hash(seed, i) kept ? 1/(1-p) : 0  (SwinDropPath :51-57) */
+int morec_droppath_scale(float* out, int n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embeddings

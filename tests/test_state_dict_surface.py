@@ -46,3 +46,47 @@ def test_checkpoint_roundtrip(tmp_path):
     assert load_model(m2, path) == 3
     for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+# ---------------------------------------------------------------------------------------------------------------- vision
+def test_vision_state_dict_surface(golden_dir):
+    """Keys, shapes and ORDER of the vision ``Model`` (``V/model/model.py``) with a Swin-T tower, as captured from the
+    reference + installed HF (``tests/golden/make_golden_vision.py``): checkpoints and the index-based freezing of
+    ``V/run.py:58-60`` depend on them."""
+    import json
+    import os
+    import types
+    from idvs.morec_amd.model import Model
+    from idvs.morec_amd.model.swin import HipSwinForImageClassification
+    from idvs.morec_amd.swin_engine import SwinShape
+    with open(os.path.join(golden_dir, "g12_vision_keys.json")) as f:
+        ref = json.load(f)
+    args = types.SimpleNamespace(max_seq_len=10, embedding_dim=2048, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                 CV_model_load="swin_tiny")
+    kw = ref["swin_tiny_config"]
+    shape = SwinShape(image_size=kw["image_size"], patch_size=kw["patch_size"], embed_dim=kw["embed_dim"], depths=tuple(kw["depths"]),
+                      num_heads=tuple(kw["num_heads"]), window_size=kw["window_size"], mlp_ratio=kw["mlp_ratio"],
+                      layer_norm_eps=kw["layer_norm_eps"], drop_path_rate=kw["drop_path_rate"])
+    m = Model(args, 100, True, HipSwinForImageClassification(shape, 2048), [1.0] * 101)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["state_dict"]
+    assert [k for k, _ in m.named_parameters()] == ref["named_parameters"]
+
+
+import torch  # noqa: E402
+from idvs.morec_amd.model.swin import HipSwinForImageClassification, remap_legacy_swin_keys  # noqa: E402
+from idvs.morec_amd.swin_engine import SwinShape  # noqa: E402
+
+
+def test_legacy_key_remap():
+    shape = SwinShape.named("swin_micro")
+    net = HipSwinForImageClassification(shape, 16)
+    sd = net.state_dict()
+    legacy = {}
+    for k, v in sd.items():
+        k = k.replace(".attention.q_proj.", ".attention.self.query.").replace(".attention.k_proj.", ".attention.self.key.")
+        k = k.replace(".attention.v_proj.", ".attention.self.value.").replace(".attention.o_proj.", ".attention.output.dense.")
+        k = k.replace(".attention.relative_position_bias.relative_position_bias_table", ".attention.self.relative_position_bias_table")
+        k = k.replace(".mlp.fc1.", ".intermediate.dense.").replace(".mlp.fc2.", ".output.dense.")
+        legacy[k] = v
+    legacy["swin.encoder.layers.0.blocks.0.attention.self.relative_position_index"] = torch.zeros(49, 49)
+    assert list(remap_legacy_swin_keys(legacy)) == list(sd)
