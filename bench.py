@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="user sequences per GPU")
     ap.add_argument("--bert", default="base")
+    ap.add_argument("--tower", default="text", help="text (BASELINE.json metric: BERT item encoder) | swin_tiny | swin_base | swin_micro "
+                    "(vision configs of BASELINE.json: Swin item encoder, S=10, D=2048, 224x224 images; default --batch 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,22 +105,33 @@ def main():
     from idvs.morec_amd.model import BertShape, HipBertModel, Model
     from idvs.morec_amd.train_step import TrainStep
 
-    S, T, D = 20, 30, 512
-    shape = BertShape.named(a.bert)
-    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
-                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
-                                 bert_model_load="bert_" + a.bert, word_embedding_dim=shape.hidden_size,
-                                 compute_dtype=a.dtype)
+    vision = a.tower != "text"
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local_rank)}; building synthetic data")
     rng = np.random.default_rng(12345)
-    content = synth_catalog(a.item_num, T, rng)
+    if vision:   # V/train_swin_tiny.py:22-41, V/parameters.py:34-39: B=64/GPU, S=10, D=2048, 224 x 224 images
+        from idvs.morec_amd.model.swin import HipSwinForImageClassification
+        from idvs.morec_amd.swin_engine import SwinShape
+        S, T, D = 10, 0, (2048 if a.tower != "swin_micro" else 64)
+        vshape = SwinShape.named(a.tower)
+        a.item_num = min(a.item_num, 4096)        # the image catalog lives in HBM (fp32 NCHW, what V/run.py:201-204 uploads)
+        args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                     CV_model_load=a.tower, compute_dtype=a.dtype)
+    else:
+        S, T, D = 20, 30, 512
+        shape = BertShape.named(a.bert)
+        args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                     num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                     bert_model_load="bert_" + a.bert, word_embedding_dim=shape.hidden_size,
+                                     compute_dtype=a.dtype)
+        content = synth_catalog(a.item_num, T, rng)
     n_batches = a.steps + a.warmup
     ids_all = synth_batches(n_batches, a.batch, S, a.item_num, np.random.default_rng(12345 + 1000 * rank))
     counts = np.bincount(ids_all.reshape(-1), minlength=a.item_num + 1).astype(np.float64) + 1.0
     pop = counts / counts[1:].sum()
     pop[0] = 1.0
     torch.manual_seed(12345)
-    model = Model(args, a.item_num, True, HipBertModel(shape), pop).to(dev)
+    tower = HipSwinForImageClassification(vshape, D) if vision else HipBertModel(shape)
+    model = Model(args, a.item_num, True, tower, pop).to(dev)
     model.train()
     log("model on device; building TrainStep arenas")
     ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool)
@@ -127,9 +140,13 @@ def main():
     host = []
     for i in range(n_batches):
         ids = torch.from_numpy(ids_all[i]).pin_memory()
-        items = torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory()
+        items = None if vision else torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory()
         lm = torch.ones(a.batch, S).pin_memory()
         host.append((ids, items, lm))
+    if vision:
+        gen = torch.Generator(device=dev).manual_seed(4321)
+        catalog = torch.randn((a.item_num + 1, 3, vshape.image_size, vshape.image_size), device=dev, generator=gen)
+        catalog[0].zero_()
 
     # --- per-launch instrumentation of the dominant kernel (the NT GEMM) with HIP events on the launch stream
     gemm_log = []
@@ -167,7 +184,7 @@ def main():
     def run_step(i):
         ids, items, lm = host[i]
         ids_d = ids.to(dev, non_blocking=True)
-        items_d = items.to(dev, non_blocking=True)
+        items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
         lm_d = lm.to(dev, non_blocking=True)
         return ts.step(ids_d.view(-1), items_d, lm_d)
 
@@ -220,8 +237,19 @@ def main():
                       "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
                       "dropout": "on (p = 0.1 hidden + attention, SASRec and BERT; counter-based masks fused in the kernels)"},
            "final_loss": round(loss_v, 4), "roofline": roof}
+    if vision:
+        out["metric"] = f"user-sequences/sec end-to-end train step, SASRec+{a.tower}"
+        out["data"] = (f"synthetic HM-shaped ({a.item_num} items, {vshape.image_size}x{vshape.image_size} fp32 images resident in HBM, "
+                       "history 11), random-init weights")
+        out["config"] = {"workload": f"SASRec(2 blocks, 2 heads, D={D}) + {a.tower} vision encoder, in-batch debiased CE, "
+                                     f"B={a.batch}/GPU, S={S}, {a.batch * (S + 1)} images/GPU/step", "global_batch": world * a.batch,
+                         "seq_len": S + 1, "parallelism": out["config"]["parallelism"],
+                         "dropout": "on (SASRec p = 0.1; Swin DropPath 0 -> 0.1 linear, per-image scales from the counter-based RNG)"}
 
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline and vision:
+        out["cpu_baseline"] = {"value": None, "unit": "user-seq/s", "cores": None, "kind": "port",
+                               "sample": "not measured for the vision tower (the BASELINE.json metric is the text tower)"}
+    elif rank == 0 and not a.no_cpu_baseline:
         # the CPU oracle runs in a child process under a wall-clock limit so it can never block the result line
         import subprocess
         try:

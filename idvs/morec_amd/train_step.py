@@ -19,12 +19,13 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
-from . import engine, ops
+from . import engine, ops, swin_engine
 from .functional import _all_gather_cat, _reduce_scatter_sum
 
 
-def _round4(n: int) -> int:
-    return (n + 3) & ~3
+def _round8(n: int) -> int:
+    """Arena slots start on 8-element boundaries: 32 B in the fp32 arenas, 16 B (one vector access) in the bf16 shadow."""
+    return (n + 7) & ~7
 
 
 class ParamArena:
@@ -35,7 +36,7 @@ class ParamArena:
         off = 0
         for name, p in named_params:
             self.offsets[name] = (off, p.numel(), tuple(p.shape))
-            off += _round4(p.numel())
+            off += _round8(p.numel())
         self.numel = off
         self.data = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
@@ -59,7 +60,7 @@ class ParamArena:
         end = o0
         for nme in names:
             o, n, _ = self.offsets[nme]
-            assert o == end and n % 4 == 0, "parameters are not adjacent in the arena"
+            assert o == end and n % 8 == 0, "parameters are not adjacent in the arena"
             end = o + n
         return buf[o0:end].view(shape)
 
@@ -84,6 +85,25 @@ def _order_bert(names):
     return out
 
 
+def _order_swin(names):
+    """Arena order for the Swin tower: q/k/v weights adjacent, then q/k/v biases adjacent (per block)."""
+    out, seen = [], set()
+    for n in names:
+        if n in seen:
+            continue
+        if n.endswith(".attention.q_proj.weight"):
+            base = n[: -len("q_proj.weight")]
+            grp = [base + f"{x}_proj.{k}" for k in ("weight", "bias") for x in ("q", "k", "v")]
+            out += grp
+            seen.update(grp)
+        elif any(n.endswith(f".attention.{x}_proj.{k}") for x in ("q", "k", "v") for k in ("weight", "bias")):
+            continue
+        else:
+            out.append(n)
+            seen.add(n)
+    return out
+
+
 class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
                  betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True):
@@ -95,8 +115,17 @@ class TrainStep:
         self.step_count = 0
         named = OrderedDict((n, p) for n, p in model.named_parameters())
         train = [n for n, p in named.items() if p.requires_grad and ".pooler." not in n]
-        g0 = _order_bert([n for n in train if "bert_model" in n])          # T/run.py:155: 'bert_model' in name
-        g1 = [n for n in train if "bert_model" not in n]
+        self.vision = bool(getattr(model, "vision", False) and model.use_modal)
+        if self.vision:
+            # V/run.py:121-130, applied literally to the installed-HF names: 'image_net' parameters whose name contains
+            # 'fc' or 'classifier' (the replaced head -- and, with transformers >= 5 naming, mlp.fc1 / mlp.fc2) train
+            # with the recommender's lr / weight decay
+            tower = [n for n in train if "image_net" in n and not ("fc" in n or "classifier" in n)]
+            g0 = _order_swin(tower)
+            g1 = [n for n in train if n not in set(tower)]
+        else:
+            g0 = _order_bert([n for n in train if "bert_model" in n])      # T/run.py:155: 'bert_model' in name
+            g1 = [n for n in train if "bert_model" not in n]
         use_shadow = self.dtype == torch.bfloat16
         self.groups = []
         if g0:
@@ -131,7 +160,25 @@ class TrainStep:
             self.g[a + "qkv_fused"] = a1.span(a1.grad, names, (3 * D, D))
             if a1.shadow is not None:
                 self.sh[a + "qkv_fused"] = a1.span(a1.shadow, names, (3 * D, D))
-        if m.use_modal:
+        if self.vision:
+            a0 = self.groups[0]["arena"]
+            self.swin_shape = m.cv_encoder.image_net.shape
+            C = self.swin_shape.embed_dim
+            for s_, depth in enumerate(self.swin_shape.depths):
+                for b in range(depth):
+                    A = swin_engine.swin_layer_names(swin_engine.IN, s_, b) + "attention."
+                    wn = [A + f"{x}_proj.weight" for x in ("q", "k", "v")]
+                    bn = [A + f"{x}_proj.bias" for x in ("q", "k", "v")]
+                    if wn[0] not in a0.offsets:   # frozen block (V/run.py:58-60): per-step concatenation instead
+                        continue
+                    self.p[A + "qkv_fused.weight"] = a0.span(a0.data, wn, (3 * C, C))
+                    self.p[A + "qkv_fused.bias"] = a0.span(a0.data, bn, (3 * C,))
+                    self.g[A + "qkv_fused.weight"] = a0.span(a0.grad, wn, (3 * C, C))
+                    self.g[A + "qkv_fused.bias"] = a0.span(a0.grad, bn, (3 * C,))
+                    if a0.shadow is not None:
+                        self.sh[A + "qkv_fused.weight"] = a0.span(a0.shadow, wn, (3 * C, C))
+                C *= 2
+        elif m.use_modal:
             a0 = self.groups[0]["arena"]
             bert = m.bert_encoder.text_encoders["title"].bert_model
             H, L = bert.config.hidden_size, bert.config.num_hidden_layers
@@ -165,7 +212,11 @@ class TrainStep:
                 grads[n] = torch.zeros_like(t)
         ids = sample_items_id.view(-1)
         d_item, d_user = m.dropout_cfgs()
-        if m.use_modal:
+        if self.vision:
+            prep_b = swin_engine.swin_prepare(p, self.swin_shape, self.dtype, swin_engine.IN, self.sh)
+            E, saved_b = swin_engine.swin_forward(p, prep_b, self.swin_shape, sample_items, self.dtype, True, swin_engine.IN,
+                                                  d_item, m.training)
+        elif m.use_modal:
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
             E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
                                              self.bert_mask_value, engine.TE, d_item)
@@ -190,7 +241,9 @@ class TrainStep:
         dE = _reduce_scatter_sum(dEpool, self.world, self.rank) if (self.world > 1 and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
         dE.view(B, S + 1, D)[:, :-1, :].add_(dx.view(B, S, D))      # the two sources of dE (T/model/model.py:39-41,49)
-        if m.use_modal:
+        if self.vision:
+            swin_engine.swin_backward(p, prep_b, saved_b, dE, grads, swin_engine.IN)
+        elif m.use_modal:
             engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE)
         else:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
