@@ -449,6 +449,10 @@ SwinAttnArgs make_args(const morec_swin_attn_desc* d, int& gx) {
 }
 }  // namespace
 
+// bf16 fast path on the matrix cores (swin_attn_mfma.hip); MOREC_E_UNSUPPORTED = shape / dtype outside it
+int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
+                                void* dqkv, float* dbias_t, bool backward, hipStream_t s);
+
 extern "C" int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx,
                                    void* stream) {
     int rc = check_attn(d);
@@ -458,6 +462,8 @@ extern "C" int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qk
     SwinAttnArgs a = make_args(d, gx);
     a.qkv = qkv; a.bias_t = bias_t; a.ctx = ctx;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = morec_swin_attn_mfma_launch(d, qkv, bias_t, ctx, nullptr, nullptr, nullptr, false, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
     dim3 grid(gx, d->heads), block(64);
     if (d->dtype == MOREC_F32) hipLaunchKernelGGL((swin_attn_fwd_kernel<float, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((swin_attn_fwd_kernel<bf16, 7>), grid, block, 0, s, a);
@@ -474,6 +480,8 @@ extern "C" int morec_swin_attn_bwd(const morec_swin_attn_desc* d, const void* qk
     SwinAttnArgs a = make_args(d, gx);
     a.qkv = qkv; a.bias_t = bias_t; a.ctx = const_cast<void*>(ctx); a.dctx = dctx; a.dqkv = dqkv; a.dbias_t = dbias_t;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = morec_swin_attn_mfma_launch(d, qkv, bias_t, const_cast<void*>(ctx), dctx, dqkv, dbias_t, true, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
     dim3 grid(gx, d->heads), block(64);
     if (d->dtype == MOREC_F32) hipLaunchKernelGGL((swin_attn_bwd_kernel<float, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((swin_attn_bwd_kernel<bf16, 7>), grid, block, 0, s, a);

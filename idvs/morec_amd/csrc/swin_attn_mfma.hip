@@ -1,0 +1,455 @@
+// swin_attn_mfma.hip -- bf16 Swin window attention (7 x 7 = 49 tokens, 32-wide heads) on the matrix cores.
+//
+// Same contract as the exact-fp32 / generic kernels in swin.hip (SwinAttention, modeling_swin.py:401-468; window
+// partition / cyclic shift / reverse folded into row addressing).  One wavefront per (window, head), four wavefronts
+// per workgroup, 49 tokens padded to a 64 x 64 score tile = 4 x 4 MFMA 16x16 tiles:
+//   * S^T = K Q^T and dP^T = V dO^T: v_mfma_f32_16x16x32_bf16 whose operands are 16-byte rows of q / k / v / dctx read
+//     straight from global memory (head width 32 = one MFMA k-step, so no LDS staging for these);
+//     a lane ends up with S[query i = 16 ti + (lane & 15)][key j = 16 tj + 4 (lane >> 4) + r]: a softmax row lives in
+//     4 lanes x 16 registers, row max / sum / delta are two shuffles (xor 16, 32);
+//   * products that contract over keys (P V, dS K) take P / dS from those registers as the B operand (the k-slot <-> key
+//     permutation {32 s + 4 g + e, 32 s + 16 + 4 g + e} is the one ds_read_b64_tr_b16 produces, so nothing is shuffled)
+//     and V^T / K^T as hardware-transposed reads of a row-major LDS tile;
+//   * products that contract over queries (P^T dO, dS^T Q) read BOTH operands with transposing LDS reads: P / dS go
+//     through a row-major bf16 LDS tile (pitch 136 B: conflict-free writes and transposed reads).
+// Outputs are produced transposed (O^T, dQ^T, dK^T, dV^T) so that a lane owns 4 consecutive head columns of one token
+// row: 8-byte global stores.
+#include <algorithm>
+#include "common.hpp"
+
+namespace {
+constexpr int DH = 32;
+constexpr int WS = 7, NT = WS * WS;
+constexpr int TROW = 64;              // bytes per row of a [64 x 32] bf16 operand tile
+constexpr int TILE = 64 * TROW;       // 4 KiB
+constexpr int PROW = 136;             // bytes per row of the [64 x 64] bf16 P / dS tile (17 x 8: odd multiple of 8 B)
+constexpr int PTILE = 64 * PROW;
+constexpr int BP = 68;                // floats per row of the shared [NT x 64] bias / dbias tiles
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+struct SwinMArgs {
+    const bf16* qkv;
+    const float* bias_t;   // [heads][j][i]
+    bf16* ctx;
+    const bf16* dctx;
+    bf16* dqkv;
+    float* dbias_t;        // [heads][j][i]
+    int n_img, H, W, shift, heads;
+    float scale;
+    int n_win_total, wpw;  // windows per wavefront
+};
+
+__device__ __forceinline__ f32x4_t mfma(const uint4& a_rows, const uint4& b_rows, f32x4_t acc) {
+    // acc[r] += sum_k A[4 (lane >> 4) + r][k] * B[lane & 15][k]; both operands given as "row (lane & 15), 8 k of chunk lane >> 4"
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_rows), __builtin_bit_cast(bf16x8_t, b_rows), acc, 0, 0, 0);
+}
+
+// transposed fragment of a row-major LDS tile: lane (c, g) receives column col0 + c of rows {32 s + 4 g + e} (e = 0..3) and
+// {32 s + 16 + 4 g + e} (elements 4..7)
+__device__ __forceinline__ uint4 frag_tr(const char* tile, int row_bytes, int col0, int s) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const char* p0 = tile + (32 * s + 4 * g + (c >> 2)) * row_bytes + (col0 + 4 * (c & 3)) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * row_bytes));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(uint4, v);
+}
+
+struct LaneGeom {
+    int row[4];        // natural row of token t = (lane & 15) + 16 k (clamped for padded tokens)
+    bool valid[4];
+    bool edge_r, edge_c;   // window on the last window row / column of a shifted layer: region mask applies
+};
+
+// per-lane constants of the shift-region mask (modeling_swin.py:584-607).  Only windows on the last window row / column
+// contain more than one region; inside them the region of a token is decided by (wy >= WS - shift) / (wx >= WS - shift).
+struct MaskBits {
+    uint32_t ai, bi;   // bit ti: token i = c + 16 ti
+    uint32_t aj, bj;   // bit 4 tj + r: token j = 16 tj + 4 g + r
+};
+
+__device__ __forceinline__ MaskBits make_mask_bits(int shift) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    MaskBits m{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = c + 16 * t, wy = i / WS, wx = i - wy * WS;
+        if (i < NT && wy >= WS - shift) m.ai |= 1u << t;
+        if (i < NT && wx >= WS - shift) m.bi |= 1u << t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * g + r, jy = j / WS, jx = j - jy * WS;
+            if (j < NT && jy >= WS - shift) m.aj |= 1u << (4 * t + r);
+            if (j < NT && jx >= WS - shift) m.bj |= 1u << (4 * t + r);
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ LaneGeom window_geom(const SwinMArgs& a, int g) {
+    const int c = threadIdx.x & 15;
+    const int nWx = a.W / WS, nWy = a.H / WS, nW = nWx * nWy;
+    const int img = g / nW, wi = g - img * nW;
+    const int wr = wi / nWx, wc = wi - wr * nWx;
+    LaneGeom G;
+    G.edge_r = a.shift > 0 && wr == nWy - 1;
+    G.edge_c = a.shift > 0 && wc == nWx - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = c + 16 * k;
+        G.valid[k] = t < NT;
+        const int tt = G.valid[k] ? t : 0;
+        const int wy = tt / WS, wx = tt - wy * WS;
+        int y = wr * WS + wy + a.shift, x = wc * WS + wx + a.shift;
+        if (y >= a.H) y -= a.H;
+        if (x >= a.W) x -= a.W;
+        G.row[k] = (img * a.H + y) * a.W + x;
+    }
+    return G;
+}
+
+// scores (S^T accumulators, layout [tj][ti][r]) -> probabilities, in place.  bias(tj, ti, r) supplies bias + (-inf on padded keys).
+template <typename BiasF>
+__device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, BiasF bias, const LaneGeom& G, const MaskBits& mb) {
+    const bool masked = G.edge_r || G.edge_c;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[tj][ti][r] * scale + bias(tj, ti, r);
+                if (masked) {
+                    const uint32_t da = ((mb.ai >> ti) ^ (mb.aj >> (4 * tj + r))) & 1u, db = ((mb.bi >> ti) ^ (mb.bj >> (4 * tj + r))) & 1u;
+                    if ((G.edge_r && da) || (G.edge_c && db)) v += -100.0f;
+                }
+                s[tj][ti][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[tj][ti][r] - m);
+                s[tj][ti][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[tj][ti][r] *= inv;
+    }
+}
+
+// B-operand fragment (k-step sk over keys) of row block ti from the register tile
+__device__ __forceinline__ uint4 pack_frag(const f32x4_t (&p)[4][4], int ti, int sk) {
+    uint4 f;
+    f.x = pack_bf16x2(p[2 * sk][ti][0], p[2 * sk][ti][1]);
+    f.y = pack_bf16x2(p[2 * sk][ti][2], p[2 * sk][ti][3]);
+    f.z = pack_bf16x2(p[2 * sk + 1][ti][0], p[2 * sk + 1][ti][1]);
+    f.w = pack_bf16x2(p[2 * sk + 1][ti][2], p[2 * sk + 1][ti][3]);
+    return f;
+}
+
+__device__ __forceinline__ void store4_bf16(bf16* p, const f32x4_t& v, float mul) {
+    uint2 o;
+    o.x = pack_bf16x2(v[0] * mul, v[1] * mul);
+    o.y = pack_bf16x2(v[2] * mul, v[3] * mul);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving LDS accesses across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
+    __shared__ __attribute__((aligned(16))) char sVall[4 * TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g4 = lane >> 4;
+    const int head = blockIdx.y, C = a.heads * DH, pitch = 3 * C;
+    char* sV = sVall + wave * TILE;
+    // bias registers in the accumulator layout; padded keys carry -inf (their probabilities become exactly 0)
+    float bias[4][4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * tj + 4 * g4 + r, i = 16 * ti + c;
+                bias[tj][ti][r] = (j >= NT) ? -INFINITY : (i < NT ? a.bias_t[((size_t)head * NT + j) * NT + i] : 0.f);
+            }
+    const MaskBits mb = make_mask_bits(a.shift);
+    const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    for (int g = w0; g < w1; ++g) {
+        const LaneGeom G = window_geom(a, g);
+        uint4 qf[4], kf[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            qf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base) : z;
+            kf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + C) : z;
+            const uint4 vf = G.valid[k] ? *reinterpret_cast<const uint4*>(base + 2 * C) : z;
+            *reinterpret_cast<uint4*>(sV + (c + 16 * k) * TROW + 16 * g4) = vf;
+        }
+        f32x4_t s[4][4];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+        softmax_rows(s, a.scale, [&](int tj, int ti, int r) { return bias[tj][ti][r]; }, G, mb);
+        wave_lds_fence();
+        f32x4_t o[2][4];
+#pragma unroll
+        for (int td = 0; td < 2; ++td)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) o[td][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+            uint4 pf[4];
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) pf[ti] = pack_frag(s, ti, sk);
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                const uint4 vt = frag_tr(sV, TROW, 16 * td, sk);
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) o[td][ti] = mfma(vt, pf[ti], o[td][ti]);
+            }
+        }
+        wave_lds_fence();   // the transposed reads are done before the next window overwrites the tile
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+            if (G.valid[ti]) {
+#pragma unroll
+                for (int td = 0; td < 2; ++td)
+                    store4_bf16(a.ctx + (size_t)G.row[ti] * C + head * DH + 16 * td + 4 * g4, o[td][ti], 1.0f);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sBias = reinterpret_cast<float*>(smem);                 // [NT (query i)][BP] shared by the block's 4 wavefronts
+    float* sDB = sBias + NT * BP;                                  // [NT (key j)][BP] dbias accumulators
+    char* wbase = reinterpret_cast<char*>(sDB + NT * BP);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g4 = lane >> 4;
+    char* sX = wbase + wave * (TILE + PTILE);                      // [64 x 32] operand tile: K, then dO, then Q
+    char* sP = sX + TILE;                                          // [64 x 64] P, then dS
+    const int head = blockIdx.y, C = a.heads * DH, pitch = 3 * C;
+    for (int e = threadIdx.x; e < NT * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        sBias[i * BP + j] = (j < NT) ? a.bias_t[((size_t)head * NT + j) * NT + i] : -INFINITY;
+        sDB[i * BP + j] = 0.f;
+    }
+    __syncthreads();
+    const MaskBits mb = make_mask_bits(a.shift);
+    const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    for (int g = w0; g < w1; ++g) {
+        const LaneGeom G = window_geom(a, g);
+        uint4 qf[4], kf[4], of[4];
+        f32x4_t s[4][4], dp[4][4];
+        {
+            uint4 vf[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                qf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base) : z;
+                kf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + C) : z;
+                vf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + 2 * C) : z;
+                of[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4) : z;
+                *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = kf[k];
+            }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                    dp[tj][ti] = mfma(vf[tj], of[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                }
+        }
+        softmax_rows(s, a.scale, [&](int tj, int ti, int r) {
+            const int i = 16 * ti + c;
+            return i < NT ? sBias[i * BP + 16 * tj + 4 * g4 + r] : (16 * tj + 4 * g4 + r < NT ? 0.f : -INFINITY);
+        }, G, mb);
+        // dS = P o (dP - rowsum(P o dP)); dbias += dS
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            float delta = 0.f;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) delta = fmaf(s[tj][ti][r], dp[tj][ti][r], delta);
+            delta += __shfl_xor(delta, 16, 64);
+            delta += __shfl_xor(delta, 32, 64);
+            const int i = 16 * ti + c;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ds = s[tj][ti][r] * (dp[tj][ti][r] - delta);
+                    dp[tj][ti][r] = ds;
+                    const int j = 16 * tj + 4 * g4 + r;
+                    if (i < NT && j < NT) atomicAdd(sDB + j * BP + i, ds);
+                }
+        }
+        // P to the row-major LDS tile [i][j] (for dV); dS fragments stay in registers (for dQ) and follow P into the tile (for dK)
+        uint4 dsf[4][2];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                dsf[ti][sk] = pack_frag(dp, ti, sk);
+                const uint4 pfr = pack_frag(s, ti, sk);
+                char* prow = sP + (16 * ti + c) * PROW;
+                *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
+                *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
+            }
+        }
+        wave_lds_fence();
+        // dQ^T[d][i] = scale * sum_j K[j][d] dS[i][j]
+        {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int td = 0; td < 2; ++td)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) acc[td][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    const uint4 kt = frag_tr(sX, TROW, 16 * td, sk);
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) acc[td][ti] = mfma(kt, dsf[ti][sk], acc[td][ti]);
+                }
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+                if (G.valid[ti]) {
+#pragma unroll
+                    for (int td = 0; td < 2; ++td)
+                        store4_bf16(a.dqkv + (size_t)G.row[ti] * pitch + head * DH + 16 * td + 4 * g4, acc[td][ti], a.scale);
+                }
+        }
+        wave_lds_fence();
+        // dV^T[d][j] = sum_i dO[i][d] P[i][j]: both operands are transposed reads (dO tile, P tile)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
+        wave_lds_fence();
+        {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int td = 0; td < 2; ++td)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) acc[td][tj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                uint4 pt[4];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) pt[tj] = frag_tr(sP, PROW, 16 * tj, sk);
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    const uint4 ot = frag_tr(sX, TROW, 16 * td, sk);
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(ot, pt[tj], acc[td][tj]);
+                }
+            }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                if (G.valid[tj]) {
+#pragma unroll
+                    for (int td = 0; td < 2; ++td)
+                        store4_bf16(a.dqkv + (size_t)G.row[tj] * pitch + 2 * C + head * DH + 16 * td + 4 * g4, acc[td][tj], 1.0f);
+                }
+        }
+        wave_lds_fence();
+        // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qf[k];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            char* prow = sP + (16 * ti + c) * PROW;
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(dsf[ti][sk].x, dsf[ti][sk].y);
+                *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(dsf[ti][sk].z, dsf[ti][sk].w);
+            }
+        }
+        wave_lds_fence();
+        {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int td = 0; td < 2; ++td)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) acc[td][tj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                uint4 st[4];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) st[tj] = frag_tr(sP, PROW, 16 * tj, sk);
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    const uint4 qt = frag_tr(sX, TROW, 16 * td, sk);
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(qt, st[tj], acc[td][tj]);
+                }
+            }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                if (G.valid[tj]) {
+#pragma unroll
+                    for (int td = 0; td < 2; ++td)
+                        store4_bf16(a.dqkv + (size_t)G.row[tj] * pitch + C + head * DH + 16 * td + 4 * g4, acc[td][tj], a.scale);
+                }
+        }
+        wave_lds_fence();
+    }
+    __syncthreads();
+    if (a.dbias_t) {
+        for (int e = threadIdx.x; e < NT * NT; e += 256) {
+            const int j = e / NT, i = e - j * NT;
+            atomicAdd(a.dbias_t + (size_t)head * NT * NT + e, sDB[j * BP + i]);
+        }
+    }
+}
+}  // namespace
+
+// bf16, window 7, head width 32 only; anything else returns MOREC_E_UNSUPPORTED and the caller falls back to swin.hip's kernels
+int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
+                                void* dqkv, float* dbias_t, bool backward, hipStream_t s) {
+    if (d->dtype != MOREC_BF16 || d->window != WS || d->dh != DH) return MOREC_E_UNSUPPORTED;
+    if ((d->heads * DH) % 8) return MOREC_E_UNSUPPORTED;
+    SwinMArgs a{};
+    a.qkv = reinterpret_cast<const bf16*>(qkv); a.bias_t = bias_t; a.ctx = reinterpret_cast<bf16*>(ctx);
+    a.dctx = reinterpret_cast<const bf16*>(dctx); a.dqkv = reinterpret_cast<bf16*>(dqkv); a.dbias_t = dbias_t;
+    a.n_img = d->n_img; a.H = d->H; a.W = d->W; a.shift = d->shift; a.heads = d->heads; a.scale = d->scale;
+    a.n_win_total = d->n_img * (d->H / WS) * (d->W / WS);
+    const long tiles = (long)a.n_win_total * d->heads;
+    a.wpw = (int)std::max<long>(1, std::min<long>(32, tiles / 8192));
+    const int gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
+    dim3 grid(gx, d->heads), block(256);
+    if (!backward) {
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
+    } else {
+        const size_t lds = (size_t)2 * NT * BP * sizeof(float) + 4 * (TILE + PTILE);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, grid, block, lds, s, a);
+    }
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
