@@ -110,25 +110,36 @@ __device__ __forceinline__ LaneGeom window_geom(const SwinMArgs& a, int g) {
     return G;
 }
 
-// scores (S^T accumulators, layout [tj][ti][r]) -> probabilities, in place.  bias(tj, ti, r) supplies bias + (-inf on padded keys).
+// scores (S^T accumulators, layout [tj][ti][r]) -> probabilities, in place.  bias4(tj, ti) supplies the 4 consecutive keys'
+// bias (+ -inf on padded keys).
 template <typename BiasF>
-__device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, BiasF bias, const LaneGeom& G, const MaskBits& mb) {
+__device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, BiasF bias4, const LaneGeom& G, const MaskBits& mb) {
     const bool masked = G.edge_r || G.edge_c;
+    const uint32_t er = G.edge_r ? 0xffffu : 0u, ec = G.edge_c ? 0xffffu : 0u;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
         float m = -INFINITY;
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < 4; ++tj) {
+            const f32x4_t b = bias4(tj, ti);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = s[tj][ti][r] * scale + bias(tj, ti, r);
-                if (masked) {
-                    const uint32_t da = ((mb.ai >> ti) ^ (mb.aj >> (4 * tj + r))) & 1u, db = ((mb.bi >> ti) ^ (mb.bj >> (4 * tj + r))) & 1u;
-                    if ((G.edge_r && da) || (G.edge_c && db)) v += -100.0f;
-                }
-                s[tj][ti][r] = v;
-                m = fmaxf(m, v);
+                s[tj][ti][r] = fmaf(s[tj][ti][r], scale, b[r]);
+                m = fmaxf(m, s[tj][ti][r]);
             }
+        }
+        if (masked) {   // wave-uniform: only windows on the last window row / column of a shifted block hold several regions
+            // bit (4 tj + r) set <=> key j lies in another region than query i
+            const uint32_t bits = ((((mb.ai >> ti) & 1u) ? ~mb.aj : mb.aj) & er) | ((((mb.bi >> ti) & 1u) ? ~mb.bj : mb.bj) & ec);
+            m = -INFINITY;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[tj][ti][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][ti][r]);
+                    m = fmaxf(m, s[tj][ti][r]);
+                }
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float sum = 0.f;
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
-        softmax_rows(s, a.scale, [&](int tj, int ti, int r) { return bias[tj][ti][r]; }, G, mb);
+        softmax_rows(s, a.scale, [&](int tj, int ti) { return f32x4_t{bias[tj][ti][0], bias[tj][ti][1], bias[tj][ti][2], bias[tj][ti][3]}; }, G, mb);
         wave_lds_fence();
         f32x4_t o[2][4];
 #pragma unroll
@@ -239,52 +250,68 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
+// dbias accumulates in registers (LDS float atomics cost 2x the rest of the kernel) and is reduced once per workgroup.
+// Register budget for two wavefronts per SIMD (<= 256 VGPRs): dbias 64 + P 64 + dP/dS 64 leaves room for two operand
+// fragment sets, so q / dctx fragments are not kept across phases: dO goes to its LDS tile as soon as dP is issued and q is
+// re-read (L2-resident) for the dK product.
+__global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sBias = reinterpret_cast<float*>(smem);                 // [NT (query i)][BP] shared by the block's 4 wavefronts
-    float* sDB = sBias + NT * BP;                                  // [NT (key j)][BP] dbias accumulators
-    char* wbase = reinterpret_cast<char*>(sDB + NT * BP);
+    char* wbase = reinterpret_cast<char*>(sBias + NT * BP);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g4 = lane >> 4;
-    char* sX = wbase + wave * (TILE + PTILE);                      // [64 x 32] operand tile: K, then dO, then Q
+    char* sK = wbase + wave * (2 * TILE + PTILE);                  // [64 x 32] K tile
+    char* sX = sK + TILE;                                          // [64 x 32] dO, then Q
     char* sP = sX + TILE;                                          // [64 x 64] P, then dS
     const int head = blockIdx.y, C = a.heads * DH, pitch = 3 * C;
     for (int e = threadIdx.x; e < NT * 64; e += 256) {
         const int i = e >> 6, j = e & 63;
         sBias[i * BP + j] = (j < NT) ? a.bias_t[((size_t)head * NT + j) * NT + i] : -INFINITY;
-        sDB[i * BP + j] = 0.f;
     }
     __syncthreads();
     const MaskBits mb = make_mask_bits(a.shift);
+    f32x4_t dbacc[4][4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) dbacc[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
-        uint4 qf[4], kf[4], of[4];
+        const uint4 z = make_uint4(0, 0, 0, 0);
         f32x4_t s[4][4], dp[4][4];
         {
-            uint4 vf[4];
+            uint4 qf[4], kf[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
-                const uint4 z = make_uint4(0, 0, 0, 0);
                 qf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base) : z;
                 kf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + C) : z;
-                vf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + 2 * C) : z;
-                of[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4) : z;
-                *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = kf[k];
+                *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = kf[k];
             }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
-                    s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
-                    dp[tj][ti] = mfma(vf[tj], of[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
-                }
+                for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
         }
-        softmax_rows(s, a.scale, [&](int tj, int ti, int r) {
-            const int i = 16 * ti + c;
-            return i < NT ? sBias[i * BP + 16 * tj + 4 * g4 + r] : (16 * tj + 4 * g4 + r < NT ? 0.f : -INFINITY);
+        __builtin_amdgcn_sched_barrier(0);   // keep the v / dctx fragments from being loaded while q / k are still live
+        {
+            uint4 vf[4], of[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + 2 * C + head * DH + 8 * g4) : z;
+                of[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4) : z;
+                *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
+            }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) dp[tj][ti] = mfma(vf[tj], of[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+        }
+        // padded query rows (i >= NT) read the last real row: their probabilities stay finite and are never stored
+        softmax_rows(s, a.scale, [&](int tj, int ti) {
+            return *reinterpret_cast<const f32x4_t*>(sBias + min(16 * ti + c, NT - 1) * BP + 16 * tj + 4 * g4);
         }, G, mb);
-        // dS = P o (dP - rowsum(P o dP)); dbias += dS
+        // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys (P = 0) and padded queries (dO = 0).
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             float delta = 0.f;
@@ -294,15 +321,13 @@ __global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
                 for (int r = 0; r < 4; ++r) delta = fmaf(s[tj][ti][r], dp[tj][ti][r], delta);
             delta += __shfl_xor(delta, 16, 64);
             delta += __shfl_xor(delta, 32, 64);
-            const int i = 16 * ti + c;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float ds = s[tj][ti][r] * (dp[tj][ti][r] - delta);
                     dp[tj][ti][r] = ds;
-                    const int j = 16 * tj + 4 * g4 + r;
-                    if (i < NT && j < NT) atomicAdd(sDB + j * BP + i, ds);
+                    dbacc[tj][ti][r] += ds;
                 }
         }
         // P to the row-major LDS tile [i][j] (for dV); dS fragments stay in registers (for dQ) and follow P into the tile (for dK)
@@ -330,7 +355,7 @@ __global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
                 for (int td = 0; td < 2; ++td) {
-                    const uint4 kt = frag_tr(sX, TROW, 16 * td, sk);
+                    const uint4 kt = frag_tr(sK, TROW, 16 * td, sk);
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti) acc[td][ti] = mfma(kt, dsf[ti][sk], acc[td][ti]);
                 }
@@ -342,11 +367,7 @@ __global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
                         store4_bf16(a.dqkv + (size_t)G.row[ti] * pitch + head * DH + 16 * td + 4 * g4, acc[td][ti], a.scale);
                 }
         }
-        wave_lds_fence();
         // dV^T[d][j] = sum_i dO[i][d] P[i][j]: both operands are transposed reads (dO tile, P tile)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
-        wave_lds_fence();
         {
             f32x4_t acc[2][4];
 #pragma unroll
@@ -376,7 +397,10 @@ __global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
         wave_lds_fence();
         // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qf[k];
+        for (int k = 0; k < 4; ++k) {
+            const uint4 qk = G.valid[k] ? *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4) : z;
+            *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qk;
+        }
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             char* prow = sP + (16 * ti + c) * PROW;
@@ -415,11 +439,28 @@ __global__ __launch_bounds__(256) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
         }
         wave_lds_fence();
     }
-    __syncthreads();
     if (a.dbias_t) {
+        // reduce the 4 wavefronts' register accumulators through LDS (the per-wave tiles are free now), then one global
+        // atomic per (i, j) per workgroup
+        float* red = reinterpret_cast<float*>(wbase);       // [64 (key j)][BP]
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* p = red + (16 * tj + 4 * g4 + r) * BP + 16 * ti + c;
+                            *p = (w == 0) ? dbacc[tj][ti][r] : *p + dbacc[tj][ti][r];
+                        }
+            }
+        }
+        __syncthreads();
         for (int e = threadIdx.x; e < NT * NT; e += 256) {
             const int j = e / NT, i = e - j * NT;
-            atomicAdd(a.dbias_t + (size_t)head * NT * NT + e, sDB[j * BP + i]);
+            atomicAdd(a.dbias_t + (size_t)head * NT * NT + e, red[j * BP + i]);
         }
     }
 }
@@ -442,7 +483,7 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     if (!backward) {
         hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
     } else {
-        const size_t lds = (size_t)2 * NT * BP * sizeof(float) + 4 * (TILE + PTILE);
+        const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
