@@ -2,12 +2,21 @@
 // rows), one wavefront per row, row held in registers, wave64 shuffles for the two reductions.
 // Reference arithmetic: T/model/modules.py:17,63,93 (eps 1e-6) and HF BertSelfOutput / BertOutput /
 // BertEmbeddings LayerNorm (eps 1e-12); HBM-bound (one read of each input, one write of each output).
+#include <algorithm>
 #include "common.hpp"
 
 // Every lane moves 16 bytes per access (EV = 4 fp32 / 8 bf16 elements); VPL = such vectors per lane, a row of N
 // elements needs ceil(N / (64 EV)) of them.  (With 8-byte bf16 accesses the kernels were memory-INSTRUCTION bound:
 // same launch time for bf16 and fp32 rows.)
-template <typename T, int VPL>
+// LPR = lanes per row: narrow rows (Swin stages: N = 96 ... 256) put 4 or 2 rows in one wavefront instead of idling 3/4 of it
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int VPL, int LPR = 64>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                      const T* __restrict__ res, const float* __restrict__ pos,
                                                      int pos_period, const float* __restrict__ gamma,
@@ -16,8 +25,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      float* __restrict__ rstd_out, int M, int N, DropRng din,
                                                      DropRng dout, const float* __restrict__ rowscale, int rps) {
     constexpr int EV = vio<T>::EV;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int GRP = 64 / LPR;
+    const int lane = threadIdx.x & (LPR - 1);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GRP + ((threadIdx.x & 63) / LPR);
     if (row >= M) return;
     const size_t base = (size_t)row * N;
     const float rsc = rowscale ? rowscale[row / rps] : 1.0f;   // DropPath: per-sample scale of the sub-layer branch
@@ -25,7 +35,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * EV;
+        const int c = (i * LPR + lane) * EV;
         if (c < N) {
             vio<T>::load(x + base + c, v[i]);
             if (bias) {
@@ -67,11 +77,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             for (int k = 0; k < EV; ++k) v[i][k] = 0.f;
         }
     }
-    const float mean = wave_sum(sum) / (float)N;
+    const float mean = group_sum<LPR>(sum) / (float)N;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * EV;
+        const int c = (i * LPR + lane) * EV;
         if (c < N) {
 #pragma unroll
             for (int k = 0; k < EV; ++k) {
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
         }
     }
-    const float var = wave_sum(sq) / (float)N;
+    const float var = group_sum<LPR>(sq) / (float)N;
     const float rstd = 1.0f / sqrtf(var + eps);
     if (lane == 0) {
         if (mean_out) mean_out[row] = mean;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * EV;
+        const int c = (i * LPR + lane) * EV;
         if (c < N) {
             float g[EV], b[EV], o[EV];
             load_f32v<EV>(gamma + c, g);
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Backward.  Each block owns RPB consecutive rows, one row per wave per trip.  Per-column dgamma / dbeta (and the
 // sub-layer bias gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave
 // as ONE atomicAdd per column per block.
-template <typename T, int VPL>
+template <typename T, int VPL, int LPR = 64>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -117,28 +127,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                                                      const T* __restrict__ dres, const float* __restrict__ rowscale, int rps) {
     constexpr int EV = vio<T>::EV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sg = reinterpret_cast<float*>(smem_raw);  // [4][N] dgamma partials
-    float* sb = sg + 4 * (size_t)N;                 // [4][N] dbeta partials
-    float* sd = sb + 4 * (size_t)N;                 // [4][N] dbias partials (only when dbias)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int GRP = 64 / LPR, NP = 4 * GRP;     // row groups per wave, column-partial sets per block
+    float* sg = reinterpret_cast<float*>(smem_raw);  // [NP][N] dgamma partials
+    float* sb = sg + NP * (size_t)N;                // [NP][N] dbeta partials
+    float* sd = sb + NP * (size_t)N;                // [NP][N] dbias partials (only when dbias)
+    const int lane = threadIdx.x & (LPR - 1), wave = (threadIdx.x >> 6) * GRP + ((threadIdx.x & 63) / LPR);
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     float ag[VPL][EV], ab[VPL][EV], ad[VPL][EV], gm[VPL][EV];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * 64 + lane) * EV;
+        const int c = (i * LPR + lane) * EV;
 #pragma unroll
         for (int k = 0; k < EV; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
         if (c < N) load_f32v<EV>(gamma + c, gm[i]);
     }
-    for (int row = r0 + wave; row < r1; row += 4) {
+    for (int row = r0 + wave; row < r1; row += NP) {
         const size_t base = (size_t)row * N;
         const float mu = mean[row], rs = rstd[row];
         float g[VPL][EV], xh[VPL][EV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * EV;
+            const int c = (i * LPR + lane) * EV;
             if (c < N) {
                 float d[EV], zz[EV];
                 vio<T>::load(dy_a + base + c, d);
@@ -167,11 +178,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 for (int k = 0; k < EV; ++k) { g[i][k] = 0.f; xh[i][k] = 0.f; }
             }
         }
-        s1 = wave_sum(s1) / (float)N;
-        s2 = wave_sum(s2) / (float)N;
+        s1 = group_sum<LPR>(s1) / (float)N;
+        s2 = group_sum<LPR>(s2) / (float)N;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * EV;
+            const int c = (i * LPR + lane) * EV;
             if (c < N) {
                 float o[EV];
 #pragma unroll
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
     if (dgamma || dbias) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * EV;
+            const int c = (i * LPR + lane) * EV;
             if (c < N) {
                 store_f32v<EV>(sg + (size_t)wave * N + c, ag[i]);
                 store_f32v<EV>(sb + (size_t)wave * N + c, ab[i]);
@@ -208,11 +219,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
         }
         __syncthreads();
         for (int c = threadIdx.x; c < N; c += 256) {
-            if (dgamma) {
-                atomicAdd(dgamma + c, sg[c] + sg[N + c] + sg[2 * N + c] + sg[3 * N + c]);
-                atomicAdd(dbeta + c, sb[c] + sb[N + c] + sb[2 * N + c] + sb[3 * N + c]);
+            float tg = 0.f, tb = 0.f, td = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                tg += sg[q * N + c];
+                tb += sb[q * N + c];
+                if (dbias) td += sd[q * N + c];
             }
-            if (dbias) atomicAdd(dbias + c, sd[c] + sd[N + c] + sd[2 * N + c] + sd[3 * N + c]);
+            if (dgamma) {
+                atomicAdd(dgamma + c, tg);
+                atomicAdd(dbeta + c, tb);
+            }
+            if (dbias) atomicAdd(dbias + c, td);
         }
     }
 }
@@ -225,10 +243,14 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     dim3 grid((M + 3) / 4), block(256);
-#define LN_FWD(V)                                                                                                   \
-    hipLaunchKernelGGL((ln_fwd_kernel<T, V>), grid, block, 0, s, (const T*)x, bias, (const T*)res, pos, pos_period, \
-                       gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din, dout, rowscale, rps)
-    if (vpl <= 1) LN_FWD(1);
+#define LN_FWD_L(V, L)                                                                                                 \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, V, L>), dim3((M + 4 * (64 / L) - 1) / (4 * (64 / L))), block, 0, s, (const T*)x, \
+                       bias, (const T*)res, pos, pos_period, gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din,  \
+                       dout, rowscale, rps)
+#define LN_FWD(V) LN_FWD_L(V, 64)
+    if (N <= 16 * vio<T>::EV) LN_FWD_L(1, 16);
+    else if (N <= 32 * vio<T>::EV) LN_FWD_L(1, 32);
+    else if (vpl <= 1) LN_FWD(1);
     else if (vpl <= 2) LN_FWD(2);
     else if (vpl <= 3) LN_FWD(3);
     else if (vpl <= 4) LN_FWD(4);
@@ -236,6 +258,7 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
     else if (vpl <= 16) LN_FWD(16);
     else return MOREC_E_UNSUPPORTED;
 #undef LN_FWD
+#undef LN_FWD_L
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -265,19 +288,23 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
                            int N, DropRng din, DropRng dout, const void* dres, const float* rowscale, int rps, hipStream_t s) {
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
-    const int rpb = 64;
+    // rows per block: enough blocks to fill the chip, few enough that the per-block column flush (N atomics x 3) stays small
+    const int rpb = std::max(64, (((M + 4095) / 4096) + 15) & ~15);
     dim3 grid((M + rpb - 1) / rpb), block(256);
-    const size_t lds = (dgamma || dbias) ? (size_t)12 * N * sizeof(float) : 0;
-#define LN_BWD(V)                                                                                               \
+#define LN_BWD_L(V, L)                                                                                          \
     do {                                                                                                        \
+        const size_t lds = (dgamma || dbias) ? (size_t)12 * (64 / L) * N * sizeof(float) : 0;                   \
         if (lds > 48 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>),                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V, L>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-        hipLaunchKernelGGL((ln_bwd_kernel<T, V>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,          \
+        hipLaunchKernelGGL((ln_bwd_kernel<T, V, L>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,       \
                            (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, \
                            dout, (const T*)dres, rowscale, rps);                                                \
     } while (0)
-    if (vpl <= 1) LN_BWD(1);
+#define LN_BWD(V) LN_BWD_L(V, 64)
+    if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16);
+    else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32);
+    else if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
     else if (vpl <= 3) LN_BWD(3);
     else if (vpl <= 4) LN_BWD(4);
@@ -285,6 +312,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
     else if (vpl <= 16) LN_BWD(16);
     else return MOREC_E_UNSUPPORTED;
 #undef LN_BWD
+#undef LN_BWD_L
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -26,12 +26,18 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     Stays on the device (the reference round-trips through the CPU)."""
     model.eval()
     m = _module(model)
-    content = torch.as_tensor(np.asarray(item_content)).long()
+    vision = bool(use_modal and getattr(m, "vision", False))
+    # vision (``get_itemLMDB_embeddings``, V/data_utils/metrics.py:63-76): ``item_content`` is the decoded image tensor
+    # f32[item_num+1, 3, R, R] (the LMDB / PIL decode of V/data_utils/dataset.py is host-side I/O outside this library)
+    content = torch.as_tensor(np.asarray(item_content)).float() if vision else torch.as_tensor(np.asarray(item_content)).long()
     outs = []
     with torch.no_grad():
         for s in range(0, content.shape[0], test_batch_size):
             chunk = content[s:s + test_batch_size].to(local_rank)
-            outs.append(m.bert_encoder(chunk) if use_modal else m.id_embedding(chunk))
+            if vision:
+                outs.append(m.cv_encoder(chunk.contiguous()))
+            else:
+                outs.append(m.bert_encoder(chunk) if use_modal else m.id_embedding(chunk))
     return torch.cat(outs, 0).float().detach()
 
 

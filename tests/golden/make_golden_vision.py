@@ -148,5 +148,48 @@ def g11(out):
     print("g12 keys", len(keys["state_dict"]))
 
 
+def g13(out):
+    """Full-size Swin-T (config from pretrained_models/swin_tiny) inside the reference vision ``Model``: scalars only (loss, probe
+    elements of the item vectors, gradient norms); weights come from ``det_param`` on both sides."""
+    res = {}
+    cfg_t = SwinConfig.from_pretrained("/root/reference/pretrained_models/swin_tiny").to_dict()
+    kw = {k: cfg_t[k] for k in ["image_size", "patch_size", "num_channels", "embed_dim", "depths", "num_heads", "window_size",
+                                "mlp_ratio", "drop_path_rate", "layer_norm_eps"]}
+    kw.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    S, D, item_num, B = 3, 256, 12, 2
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 CV_model_load="swin_tiny")
+    pop = np.abs(det_normal("pop.g13", (item_num + 1,), std=1.0)) + 0.05
+    pop = (pop / pop.sum()).astype(np.float32)
+    m = RefModel(args, item_num, True, build_swin(kw, D), pop.tolist())
+    load_det(m)
+    m.eval()
+    ids, log_mask = synth_batch("g13", B, S, item_num)
+    images = det_normal("g13.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
+    images[0] = 0.0
+    px = torch.from_numpy(images[ids.reshape(-1)])
+    m.zero_grad()
+    loss = m(torch.from_numpy(ids).view(-1), px, torch.from_numpy(log_mask), "cpu")
+    loss.backward()
+    with torch.no_grad():
+        vec = m.cv_encoder(px)
+    res["cfg"] = np.array([S, D, item_num, B])
+    res["ids"], res["log_mask"], res["pop"] = ids, log_mask, pop
+    res["loss"] = np.float32(loss.item())
+    res["item_vec_probe"] = vec[:, :8].numpy()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            res[f"grad_norm.{k}"] = np.float64(p.grad.double().norm().item())
+    np.savez_compressed(os.path.join(out, "g13_swin_tiny_scalars.npz"), **res)
+    print("g13 swin-tiny loss", loss.item())
+
+
 if __name__ == "__main__":
-    g11(HERE)
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    if a.only in ("", "g11"):
+        g11(HERE)
+    if a.only in ("", "g13"):
+        g13(HERE)

@@ -94,3 +94,28 @@ def test_vision_model_loss_matches_reference():
     for n in names:
         ref = float(G[f"full.grad_norm.{n}"])
         assert abs(float(p[n].grad.double().norm()) - ref) <= 5e-4 * ref + 1e-7, n
+
+
+def test_swin_tiny_full_size_scalars():
+    """Full Swin-T (depths 2/2/6/2, 224 x 224) inside the vision Model: oracle vs the reference's loss / probes / grad norms."""
+    G13 = np.load(os.path.join(GOLDEN_DIR, "g13_swin_tiny_scalars.npz"))
+    S, D, item_num, B = (int(v) for v in G13["cfg"])
+    cfg = SwinCfg()
+    names = [k[len("grad_norm."):] for k in G13.files if k.startswith("grad_norm.")]
+    shapes = swin_shapes(cfg, D)
+    from idvs.morec_amd.model.spec import sasrec_param_shapes
+    shapes.update(sasrec_param_shapes(S, D, 2))
+    p = {n: torch.from_numpy(det_param(n, shapes[n])).requires_grad_(True) for n in names}
+    ids, log_mask, pop = G13["ids"], G13["log_mask"], G13["pop"]
+    images = det_normal("g13.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
+    images[0] = 0.0
+    px = torch.from_numpy(images[ids.reshape(-1)])
+    E = vit_encoder_forward(p, cfg, px)
+    np.testing.assert_allclose(E[:, :8].detach().numpy(), G13["item_vec_probe"], rtol=1e-4, atol=1e-5)
+    loss = nn_ref.model_forward(p, torch.from_numpy(ids).view(-1), None, torch.from_numpy(log_mask), pop, max_seq_len=S,
+                                embedding_dim=D, n_heads=2, use_modal=True, item_vecs=E)
+    assert abs(float(loss.detach()) - float(G13["loss"])) < 5e-5
+    loss.backward()
+    for n in names:
+        ref = float(G13[f"grad_norm.{n}"])
+        assert abs(float(p[n].grad.double().norm()) - ref) <= 1e-3 * ref + 1e-7, n
