@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--dedup", action="store_true", help="encode each distinct item of the batch once (SURVEY §8(f)-2; opt-in: with "
+                    "dropout on, duplicates then share a mask). The default run reports it as a secondary measurement only.")
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
@@ -134,7 +136,8 @@ def main():
     model = Model(args, a.item_num, True, tower, pop).to(dev)
     model.train()
     log("model on device; building TrainStep arenas")
-    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool)
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool,
+                   dedup_items=a.dedup)
 
     # host batches in pinned memory: what the reference's DataLoader hands to T/run.py:232-234
     host = []
@@ -212,6 +215,27 @@ def main():
     dt = float(t.item())
     loss_v = float(loss.item())
     log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step")
+    # secondary measurement (never `value`): the same steps with distinct-item dedup on, and the duplicate rate of the batches
+    dedup_info = None
+    if not a.dedup:
+        ts.dedup_items = True
+        for i in range(min(2, a.warmup)):
+            run_step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.warmup, n_batches):
+            run_step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt2 = time.perf_counter() - t1
+        ts.dedup_items = False
+        uniq = float(np.mean([len(np.unique(ids_all[i])) for i in range(n_batches)])) / float(ids_all[0].size)
+        dedup_info = {"ms_per_step": round(dt2 / a.steps * 1e3, 3), "user_seq_per_s_this_rank_clock": round(world * a.batch * a.steps / dt2, 2),
+                      "distinct_item_fraction": round(uniq, 4),
+                      "note": "opt-in (--dedup): each distinct item of the batch encoded once; exact with dropout off, shares dropout masks between duplicates otherwise"}
 
     # roofline of the dominant kernel: algorithmic FLOPs of every GEMM launch / its measured duration
     fl = sum(f for f, _, _, _ in gemm_log)
@@ -237,6 +261,10 @@ def main():
                       "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
                       "dropout": "on (p = 0.1 hidden + attention, SASRec and BERT; counter-based masks fused in the kernels)"},
            "final_loss": round(loss_v, 4), "roofline": roof}
+    if dedup_info is not None:
+        out["with_item_dedup"] = dedup_info
+    if a.dedup:
+        out["config"]["item_dedup"] = True
     if vision:
         out["metric"] = f"user-sequences/sec end-to-end train step, SASRec+{a.tower}"
         out["data"] = (f"synthetic HM-shaped ({a.item_num} items, {vshape.image_size}x{vshape.image_size} fp32 images resident in HBM, "

@@ -106,8 +106,13 @@ def _order_swin(names):
 
 class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
-                 betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True):
+                 betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False):
         self.model = model
+        # encode every DISTINCT item of the batch once (the reference re-encodes duplicates: Zipf-popular
+        # items fill many of the B (S + 1) slots) and gather the vectors back to the slots; the slot gradients are
+        # scatter-added before the encoder's backward.  Exact when dropout is off; with dropout the duplicates of an item
+        # share one mask instead of drawing independent ones (documented deviation, hence opt-in).
+        self.dedup_items = bool(dedup_items)
         self.dtype = model.compute_dtype
         self.device = next(model.parameters()).device
         self.betas, self.eps = betas, eps
@@ -212,6 +217,13 @@ class TrainStep:
                 grads[n] = torch.zeros_like(t)
         ids = sample_items_id.view(-1)
         d_item, d_user = m.dropout_cfgs()
+        dedup = self.dedup_items and m.use_modal
+        if dedup:   # integer bookkeeping only (sort / unique / first-occurrence index); one host sync for the count
+            uniq, inv = torch.unique(ids, return_inverse=True)
+            first = torch.empty(uniq.shape[0], device=ids.device, dtype=torch.long)
+            first.scatter_(0, inv, torch.arange(ids.shape[0], device=ids.device))   # any occurrence: same item, same content
+            slot_items, sample_items = sample_items, sample_items[first].contiguous()
+            inv32 = inv.to(torch.int32).contiguous()
         if self.vision:
             prep_b = swin_engine.swin_prepare(p, self.swin_shape, self.dtype, swin_engine.IN, self.sh)
             E, saved_b = swin_engine.swin_forward(p, prep_b, self.swin_shape, sample_items, self.dtype, True, swin_engine.IN,
@@ -223,6 +235,9 @@ class TrainStep:
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
             E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
+        if dedup:   # distinct-item vectors -> slot vectors (row gather through the fp32 staging the gather kernel reads)
+            E_u = E
+            E = ops.gather_rows(ops.cast(E_u, torch.float32) if E_u.dtype != torch.float32 else E_u, inv32, self.dtype)
         B = log_mask.shape[0]
         x_in = E.view(B, S + 1, D)[:, :-1, :].contiguous()
         prep_s = engine.sasrec_prepare(p, m.args.transformer_block, self.dtype, engine.UE, self.sh)
@@ -241,6 +256,10 @@ class TrainStep:
         dE = _reduce_scatter_sum(dEpool, self.world, self.rank) if (self.world > 1 and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
         dE.view(B, S + 1, D)[:, :-1, :].add_(dx.view(B, S, D))      # the two sources of dE (T/model/model.py:39-41,49)
+        if dedup:   # slot gradients -> distinct-item gradients (fp32 accumulation), back to the compute dtype for the encoder
+            dE_u = torch.zeros((E_u.shape[0], D), device=dE.device, dtype=torch.float32)
+            ops.scatter_add_rows_(dE.contiguous(), inv32, dE_u, -1)
+            dE = dE_u if self.dtype == torch.float32 else ops.cast(dE_u, self.dtype)
         if self.vision:
             swin_engine.swin_backward(p, prep_b, saved_b, dE, grads, swin_engine.IN)
         elif m.use_modal:
