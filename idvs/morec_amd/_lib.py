@@ -79,6 +79,7 @@ _SIGS = {
     "morec_swin_bias_expand": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "morec_swin_bias_reduce": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "morec_swin_patchify": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_swin_patchify_u8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
     "morec_swin_merge": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_swin_pool_fwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_swin_pool_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -321,6 +321,30 @@ __global__ __launch_bounds__(256) void swin_patchify_kernel(const float* __restr
     }
 }
 
+// Same rows straight from decoded uint8 HWC images (what PIL / the LMDB records of V/data_utils/dataset.py:61-99 hold after
+// Resize): ToTensor (x / 255) and Normalize((x - mean) / std) of `:69-73` are applied in flight, in the reference's fp32
+// operation order, so the fp32 rows are bit-identical to patchifying the host-normalised tensor -- at a quarter of the H2D and
+// HBM bytes.  thread = one (row, i) run: ps pixels x 3 interleaved channels.
+template <typename T>
+__global__ __launch_bounds__(256) void swin_patchify_u8_kernel(const uint8_t* __restrict__ px, T* __restrict__ out, int n_img,
+                                                               int Cin, int R, int ps, int ld_out, float mean, float std) {
+    const int G = R / ps;
+    const size_t total = (size_t)n_img * G * G * ps;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / ps;
+        const int i = (int)(e - row * ps);
+        const int n = (int)(row / (G * G)), rr = (int)(row - (size_t)n * G * G);
+        const int py = rr / G, pxx = rr - py * G;
+        const uint8_t* src = px + (((size_t)n * R + (py * ps + i)) * R + pxx * ps) * Cin;
+        T* dst = out + row * ld_out + i * ps;
+        for (int j = 0; j < ps; ++j)
+            for (int c = 0; c < Cin; ++c) {
+                const float v = ((float)src[j * Cin + c] / 255.0f - mean) / std;
+                io<T>::store1(dst + c * ps * ps + j, v);
+            }
+    }
+}
+
 // ---- patch merging gather: merged[(n, y2, x2), q*C + c] = x[(n, 2 y2 + r, 2 x2 + cc), c], q = cc * 2 + r
 // (channel blocks ordered (r0,c0), (r1,c0), (r0,c1), (r1,c1): modeling_swin.py:318-320).  reverse: the inverse copy.
 template <typename T>
@@ -519,6 +543,23 @@ extern "C" int morec_swin_patchify(const float* pixels, void* out, int n_img, in
         hipLaunchKernelGGL((swin_patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, pixels, (float*)out, n_img, channels, R, patch, ld_out);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_patchify_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, pixels, (bf16*)out, n_img, channels, R, patch, ld_out);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+extern "C" int morec_swin_patchify_u8(const uint8_t* pixels_hwc, void* out, int n_img, int channels, int R, int patch, int ld_out,
+                                      float mean, float std, int dtype, void* stream) {
+    if (!pixels_hwc || !out || n_img <= 0 || channels <= 0 || R <= 0 || patch <= 0 || std == 0.f) return MOREC_E_ARG;
+    if (R % patch) return MOREC_E_UNSUPPORTED;
+    if (ld_out < channels * patch * patch) return MOREC_E_ALIGN;
+    const size_t total = (size_t)n_img * (R / patch) * (R / patch) * patch;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((swin_patchify_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, pixels_hwc, (float*)out, n_img, channels, R, patch, ld_out, mean, std);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((swin_patchify_u8_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, pixels_hwc, (bf16*)out, n_img, channels, R, patch, ld_out, mean, std);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();

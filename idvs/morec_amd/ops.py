@@ -300,6 +300,19 @@ def swin_patchify(pixels, patch, dtype):
     return out
 
 
+def swin_patchify_u8(pixels_hwc, patch, dtype, mean=0.5, std=0.5):
+    """uint8 [n, R, R, 3] decoded images -> normalised patch rows (ToTensor + Normalize(0.5, 0.5), V/data_utils/dataset.py:69-73)."""
+    _dev(pixels_hwc)
+    if pixels_hwc.dtype != torch.uint8:
+        raise _lib.MorecError("expected uint8 HWC images")
+    n, R, _, c = pixels_hwc.shape
+    G = R // patch
+    out = torch.empty((n * G * G, c * patch * patch), device=pixels_hwc.device, dtype=dtype)
+    check(_lib.lib().morec_swin_patchify_u8(_p(pixels_hwc), _p(out), n, c, R, patch, out.stride(0), mean, std, code(dtype), _stream()),
+          "morec_swin_patchify_u8")
+    return out
+
+
 def swin_merge(x, n_img, H, W, Cc, reverse=False):
     _dev(x)
     out = torch.empty((n_img * H * W, Cc) if reverse else (n_img * (H // 2) * (W // 2), 4 * Cc), device=x.device, dtype=x.dtype)

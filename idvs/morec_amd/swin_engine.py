@@ -132,12 +132,15 @@ def _window_of(H, W, ws, shift):
 
 def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, need_grad: bool, prefix: str = IN,
                  drop: DropCfg = NO_DROP, training: bool = False):
-    """pixels fp32 [n_img, 3, R, R] -> item vectors [n_img, D] (``GELU(classifier(pool(LN(encoder(embed(x))))))``).
+    """pixels fp32 [n_img, 3, R, R] (normalised, as V/run.py:201-204 uploads) or uint8 [n_img, R, R, 3] (decoded) -> item vectors [n_img, D] (``GELU(classifier(pool(LN(encoder(embed(x))))))``).
     ``training``: apply DropPath with the rates of ``shape.drop_path_rates()`` and the streams of ``drop``."""
     sw = prefix + "swin."
     n_img = pixels.shape[0]
     eps = shape.layer_norm_eps
-    patches = ops.swin_patchify(pixels.contiguous(), shape.patch_size, dtype)
+    if pixels.dtype == torch.uint8:   # decoded HWC images: ToTensor + Normalize(0.5, 0.5) fused into the im2col (§8(f)-3)
+        patches = ops.swin_patchify_u8(pixels.contiguous(), shape.patch_size, dtype)
+    else:
+        patches = ops.swin_patchify(pixels.contiguous(), shape.patch_size, dtype)
     e = ops.gemm_nt(patches, prep["patch"].w, bias=p[sw + "embeddings.patch_embeddings.projection.bias"])
     x, _, mean_e, rstd_e = ops.layernorm_fwd(e, p[sw + "embeddings.norm.weight"], p[sw + "embeddings.norm.bias"], 1e-5,
                                              save_z=False)

@@ -158,6 +158,10 @@ int morec_swin_bias_reduce(const float* dbias_t, float* dtable, int window, int 
  * pixels fp32 NCHW (what V/run.py:201-204 puts on the device), out dtype rows of pitch ld_out. */
 int morec_swin_patchify(const float* pixels, void* out, int n_img, int channels, int R, int patch, int ld_out, int dtype,
                         void* stream);
+/* the same rows from decoded uint8 HWC images [n, R, R, channels]: ToTensor + Normalize(mean, std) of
+ * V/data_utils/dataset.py:69-73 applied in flight (fp32, reference operation order: (x / 255 - mean) / std). */
+int morec_swin_patchify_u8(const uint8_t* pixels_hwc, void* out, int n_img, int channels, int R, int patch, int ld_out,
+                           float mean, float std, int dtype, void* stream);
 /* SwinPatchMerging gather (:309-320): [n,H,W,C] -> [n,H/2,W/2,4C]; reverse != 0 is the inverse copy (backward). */
 int morec_swin_merge(const void* in, void* out, int n_img, int H, int W, int C, int reverse, int dtype, void* stream);
 /* mean over each image's tokens (AdaptiveAvgPool1d(1), :876-879) and its backward */

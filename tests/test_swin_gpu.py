@@ -282,3 +282,19 @@ def test_g13_swin_tiny_full_size_golden(golden_dir, dt):
         worst = max(worst, abs(got - ref) / (ref + 1e-9)) if ref > 1e-6 else worst
         assert abs(got - ref) <= (5e-3 if dt == "fp32" else 1.5e-1) * ref + (1e-6 if dt == "fp32" else 1e-3), (n, got, ref)
     print(f"g13 swin-tiny {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
+
+
+def test_patchify_from_uint8_images_is_bit_exact():
+    """Decoded uint8 HWC images -> patch rows with ToTensor + Normalize(0.5, 0.5) fused (V/data_utils/dataset.py:69-73): the
+    fp32 rows equal patchifying the host-normalised NCHW tensor bit for bit; the encoder accepts either input."""
+    n, R = 3, 56
+    u8 = torch.from_numpy((np.abs(det_normal("u8.img", (n, R, R, 3))) * 97).astype(np.int64) % 256).to(torch.uint8)
+    host = ((u8.permute(0, 3, 1, 2).float() / 255.0) - 0.5) / 0.5
+    a = ops.swin_patchify_u8(u8.to(DEV), 4, torch.float32)
+    b = ops.swin_patchify(host.contiguous().to(DEV), 4, torch.float32)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    shape = SwinShape.named("swin_micro")
+    enc = Vit_Encoder(HipSwinForImageClassification(shape, 32), compute_dtype=torch.float32)
+    load_det(enc, "cv_encoder.").to(DEV).eval()
+    with torch.no_grad():
+        np.testing.assert_array_equal(enc(u8.to(DEV)).cpu().numpy(), enc(host.contiguous().to(DEV)).cpu().numpy())
