@@ -18,9 +18,10 @@ constexpr int ROWB = TC * 2;           // 512 bytes per staged row
 constexpr int OPB = TT * ROWB;         // 32 KiB per operand per stage
 constexpr int STAGE = 2 * OPB;
 constexpr int LDS_TN = 2 * STAGE;      // 128 KiB
-constexpr int NWAVE = 8, NTHREADS = 512;
-constexpr int WN = 2, WK = 4;          // wave grid: 2 (n) x 4 (k); wave tile 128 n x 64 k
-constexpr int NI = 8, KI = 4;
+constexpr int NWAVE = 16, NTHREADS = 1024;
+constexpr int WN = 4, WK = 4;          // wave grid: 4 (n) x 4 (k); wave tile 64 n x 64 k (16 waves = 4 per SIMD cover each
+constexpr int NI = 4, KI = 4;          //   other's LDS / barrier waits: +3..14 % over 8 waves of 128 x 64 on the NT kernel)
+constexpr int DPW = (TT * ROWB / 1024) / NWAVE;   // LDS-DMA instructions per operand per wave per stage
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
@@ -63,20 +64,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
 
     // DMA geometry: instruction q of an operand covers token rows 2q, 2q+1; lane -> (row, 16-byte physical slot)
     const int drow = lane >> 5, pslot = lane & 31;
-    const bf16* ysrc[4];
-    const bf16* xsrc[4];
+    const bf16* ysrc[DPW];
+    const bf16* xsrc[DPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 2 + drow;                       // token row within the stage
+    for (int i = 0; i < DPW; ++i) {
+        const int row = (wave * DPW + i) * 2 + drow;                     // token row within the stage
         const int lslot = (((pslot >> 1) ^ (row & 7)) << 1) | (pslot & 1); // logical 16-byte column slot
         const int yc = min(n0 + lslot * 8, p.N - 8), xc = min(k0 + lslot * 8, p.K - 8);   // clamp: unused output columns
         ysrc[i] = p.DY + (size_t)row * p.ldy + yc;
         xsrc[i] = p.X + (size_t)row * p.ldx + xc;
     }
     auto dma = [&](int stage, int m) {
-        char* base = smem + stage * STAGE + (wave * 4) * 1024;
+        char* base = smem + stage * STAGE + (wave * DPW) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < DPW; ++i) {
             __builtin_amdgcn_global_load_lds((gptr_t)(ysrc[i] + (size_t)m * p.ldy), (lptr_t)(base + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + (size_t)m * p.ldx), (lptr_t)(base + OPB + i * 1024), 16, 0, 0);
         }
