@@ -221,15 +221,16 @@ static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (force < 0) { const char* e = getenv("MOREC_GEMM_TILE"); force = e ? atoi(e) : 0; }   // 128 / 256: tuning override
     if (force == 128) return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
     if (force == 256) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
+    if (force == 129) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 4, 2>, TI, TO>(d, a, s);    // 128 x 128, 8 waves of 64 x 32
     if (force == 1024) return launch_gemm_cfg<GemmTileCfg<TI, 4, 4, 4, 4>, TI, TO>(d, a, s);   // 256 x 256, 16 waves of 64 x 64
     // narrow outputs (N <= 128: the Swin stage-1 projections) and very short K (<= 96) are streaming problems: a 256-wide
     // tile would be mostly padding / a 3-step main loop, and two independent 128 x 128 workgroups per CU overlap one's loads
     // with the other's stores (measured per shape in scripts/swin_gemm_shapes.py)
-    if (d->N <= 128 || d->K <= 96) return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
+    if (d->N <= 128 || d->K <= 96) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 4, 2>, TI, TO>(d, a, s);
     // 256 x 256 as 16 waves of 64 x 64 (4 waves per SIMD, 118 VGPRs): 3 - 14 % faster than 8 waves of 128 x 64 on every encoder
     // shape (scripts/gemm_bench.py) -- the extra waves cover each other's LDS / barrier waits
     if (big_tiles >= 192) return launch_gemm_cfg<GemmTileCfg<TI, 4, 4, 4, 4>, TI, TO>(d, a, s);
-    return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
+    return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 4, 2>, TI, TO>(d, a, s);   // 128 x 128 as 8 waves of 64 x 32 (same reasoning)
 }
 
 extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
