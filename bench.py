@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--dedup", action="store_true", help="encode each distinct item of the batch once (SURVEY §8(f)-2; opt-in: with "
                     "dropout on, duplicates then share a mask). The default run reports it as a secondary measurement only.")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (item-dedup) measurement after the timed region")
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
@@ -217,7 +218,7 @@ def main():
     log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step")
     # secondary measurement (never `value`): the same steps with distinct-item dedup on, and the duplicate rate of the batches
     dedup_info = None
-    if not a.dedup:
+    if not a.dedup and not a.no_secondary:
         ts.dedup_items = True
         for i in range(min(2, a.warmup)):
             run_step(i)
