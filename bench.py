@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--dedup", action="store_true", help="encode each distinct item of the batch once (SURVEY §8(f)-2; opt-in: with "
                     "dropout on, duplicates then share a mask). The default run reports it as a secondary measurement only.")
+    ap.add_argument("--padded", action="store_true", help="text tower: run the encoder layers on all T positions of every title (the "
+                    "reference's shape of compute) instead of the real tokens only; the default run reports it as a secondary line")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (item-dedup) measurement after the timed region")
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
@@ -104,8 +106,11 @@ def main():
         else:
             dist.init_process_group(a.backend)
 
+    from idvs.morec_amd import engine as _engine
     from idvs.morec_amd import ops
     from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    if a.padded:
+        _engine.UNPAD_DEFAULT = False
     from idvs.morec_amd.train_step import TrainStep
 
     vision = a.tower != "text"
@@ -217,6 +222,30 @@ def main():
     loss_v = float(loss.item())
     log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step")
     # secondary measurement (never `value`): the same steps with distinct-item dedup on, and the duplicate rate of the batches
+    def timed_again():
+        for i in range(min(2, a.warmup)):
+            run_step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.warmup, n_batches):
+            run_step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t1
+
+    padded_info = None
+    if not vision and not a.padded and not a.no_secondary and _engine.UNPAD_DEFAULT:
+        _engine.UNPAD_DEFAULT = False
+        dt3 = timed_again()
+        _engine.UNPAD_DEFAULT = True
+        real = float((content[1:, T:] != 0).mean())
+        padded_info = {"ms_per_step": round(dt3 / a.steps * 1e3, 3), "user_seq_per_s_this_rank_clock": round(world * a.batch * a.steps / dt3, 2),
+                       "real_token_fraction": round(real, 4),
+                       "note": "--padded: encoder layers over all 30 positions of every title, as the reference computes them; the default "
+                               "runs them on the real tokens only ([PAD] keys have probability exactly 0 and only hidden[:, 0] is consumed: same item vectors)"}
     dedup_info = None
     if not a.dedup and not a.no_secondary:
         ts.dedup_items = True
@@ -262,6 +291,10 @@ def main():
                       "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
                       "dropout": "on (p = 0.1 hidden + attention, SASRec and BERT; counter-based masks fused in the kernels)"},
            "final_loss": round(loss_v, 4), "roofline": roof}
+    if not vision:
+        out["config"]["token_layout"] = "padded (all T positions)" if (a.padded or not _engine.UNPAD_DEFAULT) else "unpadded (real tokens only; exact)"
+    if padded_info is not None:
+        out["padded_token_layout"] = padded_info
     if dedup_info is not None:
         out["with_item_dedup"] = dedup_info
     if a.dedup:

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("n_seq", C.c_int), ("T", C.c_int), ("n_heads", C.c_int), ("dh", C.c_int), ("causal", C.c_int),
                 ("scale", C.c_float), ("mask_value", C.c_float), ("dtype", C.c_int), ("p_drop", C.c_float),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("cu_seqlens", C.c_void_p)]
 
 
 class CeDesc(C.Structure):
@@ -64,6 +64,7 @@ _SIGS = {
     "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_scatter_add_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_indexed_rows_copy": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_strided_rows_copy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_inbatch_ce_workspace_bytes": (C.c_size_t, [C.POINTER(CeDesc)]),
     "morec_inbatch_ce_fwd": (C.c_int, [C.POINTER(CeDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -26,6 +26,7 @@ struct AttnArgs {
     int causal;
     float scale, mask_value;
     DropRng drop;      // attention-probability dropout (modules.py:30; HF attention_probs_dropout_prob)
+    const int32_t* cu; // packed-row offsets (unpadded layout) or nullptr
 };
 
 // stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to 32 rows
@@ -156,13 +157,15 @@ __device__ __forceinline__ void store_rows(T* __restrict__ dst, size_t row0, int
 template <typename T, int DC>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
     constexpr int P = DC + 4;
+    const int seq_ = blockIdx.x / a.n_heads;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
+    if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
     __shared__ __attribute__((aligned(16))) float sA[TP * P];
     __shared__ __attribute__((aligned(16))) float sB[TP * P];
     __shared__ __attribute__((aligned(16))) float sPt[TP * PP];   // P transposed: [key j][query i]
     const int lane = threadIdx.x;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
-    const size_t row0 = (size_t)seq * a.T;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
 
@@ -209,6 +212,9 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
 template <typename T, int DC>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
     constexpr int P = DC + 4;
+    const int seq_ = blockIdx.x / a.n_heads;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
+    if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
     __shared__ __attribute__((aligned(16))) float sQ[TP * P];
     __shared__ __attribute__((aligned(16))) float sK[TP * P];
     __shared__ __attribute__((aligned(16))) float sV[TP * P];
@@ -219,7 +225,6 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
     const int lane = threadIdx.x;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
-    const size_t row0 = (size_t)seq * a.T;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* dctx = reinterpret_cast<const T*>(a.ctx);
     T* dqkv = reinterpret_cast<T*>(a.dqkv);
@@ -311,7 +316,7 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc) return rc;
     if (!qkv || !key_keep || !ctx) return MOREC_E_ARG;
     AttnArgs a{qkv, key_keep, ctx, nullptr, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
-               make_drop(d->p_drop, d->seed)};
+               make_drop(d->p_drop, d->seed), d->cu_seqlens};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
@@ -332,7 +337,7 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc) return rc;
     if (!qkv || !key_keep || !dctx || !dqkv) return MOREC_E_ARG;
     AttnArgs a{qkv, key_keep, const_cast<void*>(dctx), dqkv, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale,
-               d->mask_value, make_drop(d->p_drop, d->seed)};
+               d->mask_value, make_drop(d->p_drop, d->seed), d->cu_seqlens};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);

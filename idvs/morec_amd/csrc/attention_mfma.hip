@@ -31,6 +31,7 @@ struct AttnMArgs {
     int n_seq, T, n_heads, dh, causal;
     float scale, mask_value;
     DropRng drop;
+    const int32_t* cu;  // packed-row offsets (unpadded layout) or nullptr
 };
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
-    const size_t row0 = (size_t)seq * a.T;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq] : (size_t)seq * a.T;
+    if (a.cu) a.T = a.cu[seq + 1] - a.cu[seq];   // unpadded layout: this sequence's own length
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}};
     const int nch = (a.dh + DCH - 1) / DCH;
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
-    const size_t row0 = (size_t)seq * a.T;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq] : (size_t)seq * a.T;
+    if (a.cu) a.T = a.cu[seq + 1] - a.cu[seq];   // unpadded layout: this sequence's own length
     const bf16* dctx = a.ctx;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}}, dp[2][2] = {{zero, zero}, {zero, zero}};
@@ -306,7 +309,7 @@ int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const floa
     if (d->dtype != MOREC_BF16 || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
     AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
                 reinterpret_cast<bf16*>(dqkv), d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
-                make_drop(d->p_drop, d->seed)};
+                make_drop(d->p_drop, d->seed), d->cu_seqlens};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     if (backward)
         hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, block, 0, s, a);

@@ -260,3 +260,36 @@ extern "C" int morec_strided_rows_copy(const void* in, void* out, int R, int D, 
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
+
+// row gather / scatter by int32 index arrays (either side optional): unpadded token layouts, [CLS] rows of packed sequences
+template <typename T>
+__global__ __launch_bounds__(256) void indexed_rows_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                           const int32_t* __restrict__ in_idx, const int32_t* __restrict__ out_idx,
+                                                           int R, int D) {
+    constexpr int EV = vio<T>::EV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const size_t src = in_idx ? (size_t)in_idx[row] : (size_t)row, dst = out_idx ? (size_t)out_idx[row] : (size_t)row;
+    for (int c = lane * EV; c < D; c += 64 * EV) {
+        float v[EV];
+        vio<T>::load(in + src * D + c, v);
+        vio<T>::store(out + dst * D + c, v);
+    }
+}
+
+extern "C" int morec_indexed_rows_copy(const void* in, void* out, const int32_t* in_idx, const int32_t* out_idx, int R, int D,
+                                       int dtype, void* stream) {
+    if (!in || !out || R <= 0 || D <= 0) return MOREC_E_ARG;
+    if (D % 8) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((R + 3) / 4);
+    if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((indexed_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, in_idx, out_idx, R, D);
+    else if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((indexed_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, in_idx, out_idx, R, D);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

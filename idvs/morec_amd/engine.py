@@ -13,6 +13,7 @@ Weight gradients ``dW = dY^T X`` run as split-K NT GEMMs over transposed activat
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -99,12 +100,12 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
 # one transformer layer
 # ---------------------------------------------------------------------------------------------------------
 def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
-                  drop: DropCfg = NO_DROP, site0: int = 0):
+                  drop: DropCfg = NO_DROP, site0: int = 0, cu=None):
     """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b.
     Dropout sites of a layer: site0 = attention probabilities, site0+1 = attention sub-layer output, site0+2 = FFN output."""
     dh = cfg.H // cfg.heads
     desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
-                         drop.p_attn, drop.site(site0))
+                         drop.p_attn, drop.site(site0), cu)
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
@@ -145,8 +146,22 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     return dx0, dz1
 
 
+def gather_cls(x, n_seq: int, T: int, cu=None):
+    """Rows of the first token of every sequence: stride T in the padded layout, ``cu_seqlens[:-1]`` in the packed one."""
+    out = torch.empty((n_seq, x.shape[1]), device=x.device, dtype=x.dtype)
+    if cu is None:
+        return ops.strided_rows_copy(x, out, n_seq, x.shape[1], T, 1)
+    return ops.indexed_rows_copy(x, out, in_idx=cu, R=n_seq)
+
+
+def scatter_cls(xc, out, n_seq: int, T: int, cu=None):
+    if cu is None:
+        return ops.strided_rows_copy(xc, out, n_seq, xc.shape[1], 1, T)
+    return ops.indexed_rows_copy(xc, out, out_idx=cu, R=n_seq)
+
+
 def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
-                      drop: DropCfg = NO_DROP, site0: int = 0):
+                      drop: DropCfg = NO_DROP, site0: int = 0, cu=None):
     """LAST encoder layer when only token 0 of every sequence is consumed downstream (``hidden[:, 0]``,
     ``T/model/encoders.py:69``): K and V are still needed for every token, but the attention output projection, both
     LayerNorms and the FFN are row-wise, so they run on the n_seq [CLS] rows only -- 9/12 of the layer's GEMM work is
@@ -155,12 +170,12 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     dh = cfg.H // cfg.heads
     H, T = cfg.H, cfg.T
     desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
-                         drop.p_attn, drop.site(site0))
+                         drop.p_attn, drop.site(site0), cu)
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
-    ctx_c = ops.strided_rows_copy(ctx, torch.empty((n_seq, H), device=x0.device, dtype=x0.dtype), n_seq, H, T, 1)
-    x0_c = ops.strided_rows_copy(x0, torch.empty((n_seq, H), device=x0.device, dtype=x0.dtype), n_seq, H, T, 1)
+    ctx_c = gather_cls(ctx, n_seq, T, cu)
+    x0_c = gather_cls(x0, n_seq, T, cu)
     a = ops.gemm_nt(ctx_c, w["o"].w)
     x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
                                              p_in=ph, seed_in=s1)
@@ -169,14 +184,14 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     f = ops.gemm_nt(g, w["f2"].w)
     x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
                                              p_in=ph, seed_in=s2)
-    saved = (desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq) if need_grad else None
+    saved = (desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq, cu) if need_grad else None
     return x2, saved
 
 
 def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: dict):
     """Backward of ``layer_forward_cls``: dx2_c is the gradient at the [CLS] rows [n_seq, H].  Returns (da, db) over ALL
     tokens with dx0 = da + db (db carries the residual-branch gradient, non-zero on the [CLS] rows only)."""
-    desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq = saved
+    desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq, cu = saved
     H, T = cfg.H, cfg.T
     dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
                                   dbias=g.get("b2"))
@@ -190,15 +205,15 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
                                   dbias=g.get("bo"))
     linear_wgrad_(dzd1, ctx_c, g["o"])
     dctx_c = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=H)
-    dctx = torch.zeros((n_seq * T, H), device=dctx_c.device, dtype=dctx_c.dtype)
-    ops.strided_rows_copy(dctx_c, dctx, n_seq, H, 1, T)
+    dctx = torch.zeros((x0.shape[0], H), device=dctx_c.device, dtype=dctx_c.dtype)
+    scatter_cls(dctx_c, dctx, n_seq, T, cu)
     dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
     if g.get("bqkv") is not None:
         ops.colsum_(dqkv, g["bqkv"])
     linear_wgrad_(dqkv, x0, g["qkv"])
     dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=H)
     dres = dctx.zero_()                      # reuse: residual-branch gradient, [CLS] rows only
-    ops.strided_rows_copy(dz1, dres, n_seq, H, 1, T)
+    scatter_cls(dz1, dres, n_seq, T, cu)
     return dx0, dres
 
 
@@ -276,6 +291,8 @@ def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefi
 # BERT text encoder (T/model/encoders.py:53-70 + HF BertModel)
 # ---------------------------------------------------------------------------------------------------------
 TE = "bert_encoder.text_encoders.title."
+# encoder layers on real tokens only (see bert_forward); MOREC_UNPAD=0 / bench.py --padded keep all T positions of every title
+UNPAD_DEFAULT = os.environ.get("MOREC_UNPAD", "1") != "0"
 
 
 def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict | None = None):
@@ -298,8 +315,15 @@ def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict |
 
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
-                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP):
-    """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D]."""
+                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None):
+    """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
+
+    ``unpad``: run the encoder layers on the REAL tokens only (packed rows + ``cu_seqlens``) instead of all T positions of
+    every title.  Exact for what the path consumes (``hidden[:, 0]``, encoders.py:69): [PAD] keys carry the additive
+    ``finfo.min`` mask, i.e. probability exactly 0, so they never reach a real token, and every other operator is row-wise.
+    Requires the mask to be a run of ones followed by zeros (what ``get_doc_input_bert``, preprocess.py:131-172, builds);
+    an all-zero row (the padding item, preprocess.py:135-136) keeps its first token -- its vector reaches nothing
+    (masked columns / keys, dropped rows)."""
     bm = prefix + "bert_model."
     Nc, T2 = text.shape
     T = T2 // 2
@@ -312,26 +336,39 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
                                                 p[bm + "embeddings.position_embeddings.weight"], type0,
                                                 p[bm + "embeddings.LayerNorm.weight"], p[bm + "embeddings.LayerNorm.bias"],
                                                 eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
-    saved_layers = []
+    cu, tok_idx = None, None
     n_layers = len(prep["layers"])
+    if (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
+        # integer bookkeeping (index arithmetic only; one host sync for the token count)
+        lens = text[:, T:].sum(1).clamp_(min=1)
+        cu = torch.zeros(Nc + 1, device=text.device, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0)
+        ar = torch.arange(T, device=text.device)
+        tok_idx = (ar[None, :] < lens[:, None]).view(-1).nonzero().view(-1).to(torch.int32)
+        if tok_idx.numel() == Nc * T:
+            cu, tok_idx = None, None          # nothing to drop
+        else:
+            x = ops.indexed_rows_copy(x, torch.empty((tok_idx.numel(), H), device=x.device, dtype=dtype), in_idx=tok_idx)
+            keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
+    saved_layers = []
     for l, w in enumerate(prep["layers"]):
         if l == n_layers - 1:     # only hidden[:, 0] is consumed (encoders.py:69): row-wise work on the [CLS] rows only
-            cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
+            cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l, cu)
         else:
-            x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l)
+            x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l, cu)
         saved_layers.append(sv)
     if n_layers == 0:
         cls = ops.strided_rows_copy(x, torch.empty((Nc, H), device=x.device, dtype=dtype), Nc, H, T, 1)
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
-    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop) if need_grad else None
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx) if need_grad else None
     return item, saved
 
 
 def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = TE, pad_id: int = 0):
     bm = prefix + "bert_model."
-    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop = saved
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx = saved
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
     linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
@@ -361,6 +398,14 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             for i, n in enumerate(("query", "key", "value")):
                 grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
                 grads[L + f"attention.self.{n}.bias"] = dbqkv[i * H:(i + 1) * H]
+    if tok_idx is not None:   # back to the padded layout the embedding stage (and its dropout stream) lives in: [PAD] rows get zero
+        pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
+        ops.indexed_rows_copy(da, pa, out_idx=tok_idx)
+        if db is not None:
+            pb = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
+            ops.indexed_rows_copy(db, pb, out_idx=tok_idx)
+            db = pb
+        da = pa
     dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
                                 p_out=drop.p_hidden, seed_out=drop.site(0))

@@ -154,8 +154,10 @@ def pos_grad_(dz, dpos, period):
     check(_lib.lib().morec_pos_grad(_p(dz), _p(dpos), M, N, period, code(dz.dtype), _stream()), "morec_pos_grad")
 
 
-def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0):
-    return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype), p_drop, seed)
+def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0, cu_seqlens=None):
+    """``cu_seqlens``: int32 [n_seq + 1] device tensor for the unpadded token layout (the caller keeps it alive)."""
+    return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype), p_drop, seed,
+                    None if cu_seqlens is None else cu_seqlens.data_ptr())
 
 
 def attn_fwd(desc, qkv, key_keep):
@@ -202,6 +204,15 @@ def scatter_add_rows_(d, idx32, dtable, pad_id):
     R, D = d.shape
     check(_lib.lib().morec_scatter_add_rows(_p(_dev(d)), _p(idx32), _p(dtable), R, D, pad_id, code(d.dtype), _stream()),
           "morec_scatter_add_rows")
+
+
+def indexed_rows_copy(src, out, in_idx=None, out_idx=None, R=None):
+    """out[out_idx[r]] = src[in_idx[r]] (int32 device index vectors; None = identity)."""
+    _dev(src), _dev(out)
+    R = (in_idx if in_idx is not None else out_idx).numel() if R is None else R
+    check(_lib.lib().morec_indexed_rows_copy(_p(src), _p(out), _p(in_idx), _p(out_idx), R, src.shape[1], code(src.dtype), _stream()),
+          "morec_indexed_rows_copy")
+    return out
 
 
 def strided_rows_copy(src, out, R, D, in_stride, out_stride):

@@ -125,6 +125,9 @@ typedef struct {
     int dtype;
     float p_drop;      /* dropout on the attention probabilities (0 = off) */
     uint64_t seed;     /* element index = ((seq * n_heads + head) * 32 + i) * 32 + j */
+    const int32_t* cu_seqlens;   /* NULL: every sequence owns T rows.  Otherwise int32[n_seq + 1] (device): sequence s owns rows
+                                    cu_seqlens[s] .. cu_seqlens[s+1]-1 (<= T of them) -- the unpadded ("varlen") token layout in
+                                    which [PAD] positions are not materialised at all; key_keep is then indexed by packed row */
 } morec_attn_desc;
 
 int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx, void* stream);
@@ -190,6 +193,9 @@ int morec_scatter_add_rows(const void* d, const int32_t* idx, float* dtable, int
                            void* stream);
 /* strided row copy: out[r, :] = in[r*stride_rows, :]  (hidden[:, 0], T/model/encoders.py:69) and its
  * backward (scatter into a zero-filled [R*stride_rows, D]) */
+/* out[out_idx ? out_idx[r] : r, :] = in[in_idx ? in_idx[r] : r, :] for r < R (row gather / scatter; indices int32, device) */
+int morec_indexed_rows_copy(const void* in, void* out, const int32_t* in_idx, const int32_t* out_idx, int R, int D, int dtype,
+                            void* stream);
 int morec_strided_rows_copy(const void* in, void* out, int R, int D, int in_row_stride, int out_row_stride,
                             int dtype, void* stream);
 
