@@ -250,6 +250,7 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
 #define LN_FWD(V) LN_FWD_L(V, 64)
     if (N <= 16 * vio<T>::EV) LN_FWD_L(1, 16);
     else if (N <= 32 * vio<T>::EV) LN_FWD_L(1, 32);
+    else if (N == 96 * vio<T>::EV) LN_FWD_L(3, 32);   // H = 768 in bf16: 96 vectors = 32 lanes x 3, two rows per wave, no idle lanes
     else if (vpl <= 1) LN_FWD(1);
     else if (vpl <= 2) LN_FWD(2);
     else if (vpl <= 3) LN_FWD(3);
@@ -304,6 +305,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
 #define LN_BWD(V) LN_BWD_L(V, 64)
     if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16);
     else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32);
+    else if (N == 96 * vio<T>::EV) LN_BWD_L(3, 32);
     else if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
     else if (vpl <= 3) LN_BWD(3);
