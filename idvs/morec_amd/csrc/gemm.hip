@@ -222,6 +222,7 @@ static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (force == 128) return launch_gemm_cfg<GemmTile<TI, 2>, TI, TO>(d, a, s);
     if (force == 256) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 8, 4>, TI, TO>(d, a, s);
     if (force == 129) return launch_gemm_cfg<GemmTileCfg<TI, 2, 4, 4, 2>, TI, TO>(d, a, s);    // 128 x 128, 8 waves of 64 x 32
+    if (force == 2128) return launch_gemm_cfg<GemmTileCfg<TI, 4, 2, 4, 4, 1>, TI, TO>(d, a, s);  // 256 x 128, 8 waves, 2 workgroups per CU
     if (force == 1024) return launch_gemm_cfg<GemmTileCfg<TI, 4, 4, 4, 4>, TI, TO>(d, a, s);   // 256 x 256, 16 waves of 64 x 64
     // narrow outputs (N <= 128: the Swin stage-1 projections) and very short K (<= 96) are streaming problems: a 256-wide
     // tile would be mostly padding / a 3-step main loop, and two independent 128 x 128 workgroups per CU overlap one's loads

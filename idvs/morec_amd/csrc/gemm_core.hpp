@@ -20,11 +20,13 @@
 // Tile configuration: WM x WN waves, each owning MI x NI MFMA 16x16 tiles.
 //   GemmTile<T, 2>                 128 x 128, 4 waves  (small problems, fused CE / eval tiles)
 //   GemmTileCfg<T, 2, 4, 8, 4>     256 x 256, 8 waves  (the encoder GEMMs: twice the MFMA work per staged byte)
-template <typename T, int WM_, int WN_, int MI_, int NI_>
+//   GemmTileCfg<T, 4, 2, 4, 4, 1>  256 x 128, 8 waves, 64-byte K stages: 48 KiB of LDS and 64 accumulator registers per wave, so TWO
+//                                  workgroups fit a CU and one's main loop covers the other's tile turnover
+template <typename T, int WM_, int WN_, int MI_, int NI_, int KSUB_ = 2>
 struct GemmTileCfg {
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_;
     static constexpr int TM = WM * MI * 16, TN = WN * NI * 16, NWAVES = WM * WN, THREADS = 64 * NWAVES;
-    static constexpr int KSUB = 2;
+    static constexpr int KSUB = KSUB_;                 // MFMA k-steps (64 bytes of K each) per stage: 2 or 1
     static constexpr int KB = 64 * KSUB;               // bytes of K per row per stage
     static constexpr int KE = KB / (int)sizeof(T);     // elements of K per stage
     static constexpr int EPV = 16 / (int)sizeof(T);    // elements per 16-byte vector
@@ -36,6 +38,10 @@ struct GemmTileCfg {
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static_assert(TM % (ROWS_PER_DMA * NWAVES) == 0 && TN % (ROWS_PER_DMA * NWAVES) == 0, "DMA split");
+    static_assert(KSUB == 1 || KSUB == 2, "stage = one or two MFMA k-steps");
+    // XOR key that spreads the 16 rows of a fragment read over the 16-byte slots of a row: 8 slots (128-byte rows) -> row & 7;
+    // 4 slots (64-byte rows: rows r, r+4, r+8, r+12 start in the same 256-byte bank window) -> (row >> 2) & 3
+    __host__ __device__ static constexpr int swz(int row) { return KSUB == 2 ? (row & 7) : ((row >> 2) & 3); }
 };
 template <typename T, int KSUB>
 using GemmTile = GemmTileCfg<T, 2, 2, 4, 4>;
@@ -95,12 +101,12 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
 #pragma unroll
     for (int i = 0; i < G::ADMA_PER_WAVE; ++i) {
         const int row = (wave * G::ADMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
-        asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + (pslot ^ (row & 7)) * G::EPV;
+        asrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + (pslot ^ G::swz(row)) * G::EPV;
     }
 #pragma unroll
     for (int i = 0; i < G::BDMA_PER_WAVE; ++i) {
         const int row = (wave * G::BDMA_PER_WAVE + i) * G::ROWS_PER_DMA + drow;
-        bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + (pslot ^ (row & 7)) * G::EPV;
+        bsrc[i] = B + (size_t)min(n0 + row, N - 1) * ldb + (pslot ^ G::swz(row)) * G::EPV;
     }
     auto dma = [&](int stage, int k0) {
         char* abase = smem + stage * G::STAGE_BYTES + (wave * G::ADMA_PER_WAVE) * 1024;
@@ -121,7 +127,7 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
             const int row = v / G::SLOTS, lslot = v % G::SLOTS;
             const int k = k0 + lslot * G::EPV, am = m0 + row;
             const uint4 ra = (k < kend && am < M) ? *reinterpret_cast<const uint4*>(A + (size_t)am * lda + k) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(base + row * G::KB + ((lslot ^ (row & 7)) * 16)) = ra;
+            *reinterpret_cast<uint4*>(base + row * G::KB + ((lslot ^ G::swz(row)) * 16)) = ra;
         }
 #pragma unroll
         for (int i = 0; i < (G::TN * G::SLOTS) / G::THREADS; ++i) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
             const int row = v / G::SLOTS, lslot = v % G::SLOTS;
             const int k = k0 + lslot * G::EPV, bn = n0 + row;
             const uint4 rb = (k < kend && bn < N) ? *reinterpret_cast<const uint4*>(B + (size_t)bn * ldb + k) : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(base + G::A_BYTES + row * G::KB + ((lslot ^ (row & 7)) * 16)) = rb;
+            *reinterpret_cast<uint4*>(base + G::A_BYTES + row * G::KB + ((lslot ^ G::swz(row)) * 16)) = rb;
         }
     };
     auto stage = [&](int st, int t) {
@@ -148,7 +154,7 @@ __device__ __forceinline__ void gemm_mainloop_cfg(const T* __restrict__ A, const
         const char* bs = smem + cur * G::STAGE_BYTES + G::A_BYTES + (wn * G::NI * 16 + frow) * G::KB;
 #pragma unroll
         for (int ks = 0; ks < G::KSUB; ++ks) {
-            const int phys = ((ks * 4 + (lane >> 4)) ^ (frow & 7)) * 16;
+            const int phys = ((ks * 4 + (lane >> 4)) ^ G::swz(frow)) * 16;
             uint4 fa[G::MI], fb[G::NI];
 #pragma unroll
             for (int i = 0; i < G::MI; ++i) fa[i] = *reinterpret_cast<const uint4*>(as + i * 16 * G::KB + phys);

@@ -314,6 +314,20 @@ def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict |
     return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype, sh.get(prefix + "fc.weight")))
 
 
+def token_packing(mask: torch.Tensor):
+    """Integer bookkeeping of the unpadded layout (index arithmetic only; one host sync for the token count).
+    mask int [Nc, T], a run of ones followed by zeros per row -> (cu_seqlens int32 [Nc + 1], tok_idx int32 [n_tokens]):
+    sequence s owns packed rows cu[s] .. cu[s+1]-1, packed row r is padded row tok_idx[r] = s * T + t.  A row without any
+    real token keeps its first position."""
+    Nc, T = mask.shape
+    lens = mask.sum(1).clamp_(min=1)
+    cu = torch.zeros(Nc + 1, device=mask.device, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    ar = torch.arange(T, device=mask.device)
+    tok_idx = (ar[None, :] < lens[:, None]).view(-1).nonzero().view(-1).to(torch.int32)
+    return cu, tok_idx
+
+
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
                  mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
@@ -339,12 +353,7 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
     if (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
-        # integer bookkeeping (index arithmetic only; one host sync for the token count)
-        lens = text[:, T:].sum(1).clamp_(min=1)
-        cu = torch.zeros(Nc + 1, device=text.device, dtype=torch.int32)
-        cu[1:] = torch.cumsum(lens, 0)
-        ar = torch.arange(T, device=text.device)
-        tok_idx = (ar[None, :] < lens[:, None]).view(-1).nonzero().view(-1).to(torch.int32)
+        cu, tok_idx = token_packing(text[:, T:])
         if tok_idx.numel() == Nc * T:
             cu, tok_idx = None, None          # nothing to drop
         else:

@@ -40,3 +40,24 @@ def test_train_dataset_and_vector_collate(golden_dir):
         table = np.arange((int(g[f"{case}.item_num"]) + 1) * 4).reshape(-1, 4)
         _, bit2, _ = collate_train_batch(u2seq, list(range(ids.shape[0])), table, S, True)
         assert np.array_equal(bit2.numpy(), table[ids])
+
+
+def test_token_packing_matches_python_loop():
+    """Unpadded-layout bookkeeping (engine.token_packing) against an explicit loop: ragged titles, a full-length title and the
+    all-[PAD] padding item (keeps its first position)."""
+    import numpy as np
+    import torch
+    from idvs.morec_amd.engine import token_packing
+    rng = np.random.default_rng(5)
+    Nc, T = 37, 30
+    lens = rng.integers(0, T + 1, Nc)
+    lens[0], lens[1], lens[2] = 0, T, 1
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    cu, tok = token_packing(torch.from_numpy(mask))
+    ref_cu, ref_tok = [0], []
+    for s in range(Nc):
+        L = max(int(lens[s]), 1)
+        ref_tok += [s * T + t for t in range(L)]
+        ref_cu.append(ref_cu[-1] + L)
+    assert cu.dtype == torch.int32 and tok.dtype == torch.int32
+    assert cu.tolist() == ref_cu and tok.tolist() == ref_tok
