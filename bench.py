@@ -113,7 +113,8 @@ def main():
         _engine.UNPAD_DEFAULT = False
     from idvs.morec_amd.train_step import TrainStep
 
-    vision = a.tower != "text"
+    id_tower = a.tower == "id"      # BASELINE.json configs[0]: IDRec SASRec (embedding table, no modality encoder), T/train_id.py
+    vision = a.tower not in ("text", "id")
     log(f"rank {rank}/{world} on {torch.cuda.get_device_name(local_rank)}; building synthetic data")
     rng = np.random.default_rng(12345)
     if vision:   # V/train_swin_tiny.py:22-41, V/parameters.py:34-39: B=64/GPU, S=10, D=2048, 224 x 224 images
@@ -138,8 +139,8 @@ def main():
     pop = counts / counts[1:].sum()
     pop[0] = 1.0
     torch.manual_seed(12345)
-    tower = HipSwinForImageClassification(vshape, D) if vision else HipBertModel(shape)
-    model = Model(args, a.item_num, True, tower, pop).to(dev)
+    tower = None if id_tower else (HipSwinForImageClassification(vshape, D) if vision else HipBertModel(shape))
+    model = Model(args, a.item_num, not id_tower, tower, pop).to(dev)
     model.train()
     log("model on device; building TrainStep arenas")
     ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool,
@@ -149,7 +150,8 @@ def main():
     host = []
     for i in range(n_batches):
         ids = torch.from_numpy(ids_all[i]).pin_memory()
-        items = None if vision else torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory()
+        items = None if vision else (torch.from_numpy(ids_all[i].reshape(-1).copy()).pin_memory() if id_tower
+                                     else torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory())
         lm = torch.ones(a.batch, S).pin_memory()
         host.append((ids, items, lm))
     if vision:
@@ -237,7 +239,7 @@ def main():
         return time.perf_counter() - t1
 
     padded_info = None
-    if not vision and not a.padded and not a.no_secondary and _engine.UNPAD_DEFAULT:
+    if not vision and not id_tower and not a.padded and not a.no_secondary and _engine.UNPAD_DEFAULT:
         _engine.UNPAD_DEFAULT = False
         dt3 = timed_again()
         _engine.UNPAD_DEFAULT = True
@@ -247,7 +249,7 @@ def main():
                        "note": "--padded: encoder layers over all 30 positions of every title, as the reference computes them; the default "
                                "runs them on the real tokens only ([PAD] keys have probability exactly 0 and only hidden[:, 0] is consumed: same item vectors)"}
     dedup_info = None
-    if not a.dedup and not a.no_secondary:
+    if not a.dedup and not a.no_secondary and not id_tower:
         ts.dedup_items = True
         for i in range(min(2, a.warmup)):
             run_step(i)
@@ -291,7 +293,11 @@ def main():
                       "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
                       "dropout": "on (p = 0.1 hidden + attention, SASRec and BERT; counter-based masks fused in the kernels)"},
            "final_loss": round(loss_v, 4), "roofline": roof}
-    if not vision:
+    if id_tower:
+        out["metric"] = "user-sequences/sec end-to-end train step, IDRec SASRec (embedding table)"
+        out["config"]["workload"] = (f"SASRec(2 blocks, 2 heads, D=512) + ID embedding table ({a.item_num} items, dense AdamW over the table), "
+                                     f"in-batch debiased CE, B={a.batch}/GPU, S=20")
+    if not vision and not id_tower:
         out["config"]["token_layout"] = "padded (all T positions)" if (a.padded or not _engine.UNPAD_DEFAULT) else "unpadded (real tokens only; exact)"
     if padded_info is not None:
         out["padded_token_layout"] = padded_info
@@ -308,7 +314,7 @@ def main():
                          "seq_len": S + 1, "parallelism": out["config"]["parallelism"],
                          "dropout": "on (SASRec p = 0.1; Swin DropPath 0 -> 0.1 linear, per-image scales from the counter-based RNG)"}
 
-    if rank == 0 and not a.no_cpu_baseline and vision:
+    if rank == 0 and not a.no_cpu_baseline and (vision or id_tower):
         out["cpu_baseline"] = {"value": None, "unit": "user-seq/s", "cores": None, "kind": "port",
                                "sample": "not measured for the vision tower (the BASELINE.json metric is the text tower)"}
     elif rank == 0 and not a.no_cpu_baseline:
