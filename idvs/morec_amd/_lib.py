@@ -70,6 +70,8 @@ _SIGS = {
     "morec_inbatch_ce_fwd": (C.c_int, [C.POINTER(CeDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "morec_inbatch_ce_bwd": (C.c_int, [C.POINTER(CeDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P,
                                        _P]),
+    "morec_bce_fwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_bce_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_adamw": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                               C.c_int, C.c_float, _P]),
     "morec_eval_rank": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

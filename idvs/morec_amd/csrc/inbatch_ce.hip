@@ -329,3 +329,110 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
     g.M = a.Nc; g.N = a.D; g.K = ldr; g.lda = ldr; g.ldb = ldr; g.ldc = a.D;
     return morec_gemm_nt(&g, dlt, Pt, dE, nullptr, nullptr, nullptr, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BCE variant (bce_text/main-end2end/model/model.py:30-51): one sampled negative per position.
+//   E [B, S+1, 2, D]: item vectors, pos at [:, :, 0], neg at [:, :, 1];  P [B, S, D] user states.
+//   row (b, j): pos = P . E[b, j+1, 0], neg = P . E[b, j, 1];
+//   loss = mean_valid(softplus(-pos)) + mean_valid(softplus(neg))          (two BCEWithLogitsLoss means over the same rows)
+// One wavefront per row; HBM-bound (reads P, two E rows; backward writes dP and every dE row exactly once, no atomics).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const T* __restrict__ P, const T* __restrict__ E,
+                                                      const uint8_t* __restrict__ row_valid, float* __restrict__ scores,
+                                                      float* __restrict__ loss_sum, int B, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * S) return;
+    const int b = row / S, j = row - b * S;
+    const T* p = P + (size_t)row * D;
+    const T* ep = E + ((size_t)(b * (S + 1) + j + 1) * 2 + 0) * D;
+    const T* en = E + ((size_t)(b * (S + 1) + j) * 2 + 1) * D;
+    float sp = 0.f, sn = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float x[4], y[4], z[4];
+        io<T>::load4(p + c, x); io<T>::load4(ep + c, y); io<T>::load4(en + c, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sp = fmaf(x[k], y[k], sp); sn = fmaf(x[k], z[k], sn); }
+    }
+    sp = wave_sum(sp); sn = wave_sum(sn);
+    if (lane == 0) {
+        scores[row] = sp;
+        scores[B * S + row] = sn;
+        if (row_valid[row]) atomicAdd(loss_sum, softplus_f(-sp) + softplus_f(sn));
+    }
+}
+
+// dpos = -sigmoid(-pos) g, dneg = sigmoid(neg) g on valid rows (g = dloss / n_valid), 0 elsewhere
+__device__ __forceinline__ void bce_coeffs(const float* scores, const uint8_t* row_valid, int BS, int row, float g, float& dpos, float& dneg) {
+    if (row < 0 || !row_valid[row]) { dpos = 0.f; dneg = 0.f; return; }
+    dpos = -g / (1.f + expf(scores[row]));
+    dneg = g / (1.f + expf(-scores[BS + row]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const T* __restrict__ P, const T* __restrict__ E, const uint8_t* __restrict__ row_valid,
+                                                      const float* __restrict__ scores, const float* __restrict__ gscale,
+                                                      T* __restrict__ dP, T* __restrict__ dE, int B, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (b, slot j in 0..S): writes dE[b, j, 0], dE[b, j, 1] and dP[b, j]
+    if (w >= B * (S + 1)) return;
+    const int b = w / (S + 1), j = w - b * (S + 1);
+    const float g = gscale[0];
+    const int BS = B * S;
+    float dp_prev, dn_prev, dp_cur, dn_cur;
+    bce_coeffs(scores, row_valid, BS, j >= 1 ? b * S + j - 1 : -1, g, dp_prev, dn_prev);   // row (b, j-1) scores E[b, j, 0] as its positive
+    bce_coeffs(scores, row_valid, BS, j < S ? b * S + j : -1, g, dp_cur, dn_cur);          // row (b, j) scores E[b, j, 1] as its negative
+    T* de_pos = dE + ((size_t)w * 2 + 0) * D;
+    T* de_neg = dE + ((size_t)w * 2 + 1) * D;
+    const T* p_prev = P + (size_t)(b * S + (j >= 1 ? j - 1 : 0)) * D;
+    const T* p_cur = P + (size_t)(b * S + (j < S ? j : 0)) * D;
+    const T* ep = E + ((size_t)(b * (S + 1) + (j < S ? j + 1 : 0)) * 2 + 0) * D;           // positive of row (b, j)
+    const T* en = E + ((size_t)w * 2 + 1) * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float a[4], q[4], y[4], z[4], o[4];
+        io<T>::load4(p_prev + c, a); io<T>::load4(p_cur + c, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = dp_prev * a[k];
+        io<T>::store4(de_pos + c, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = dn_cur * q[k];
+        io<T>::store4(de_neg + c, o);
+        if (j < S) {
+            io<T>::load4(ep + c, y); io<T>::load4(en + c, z);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = dp_cur * y[k] + dn_cur * z[k];
+            io<T>::store4(dP + (size_t)(b * S + j) * D + c, o);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int morec_bce_fwd(const void* P, const void* E, const uint8_t* row_valid, float* scores, float* loss_sum, int B, int S, int D,
+                             int dtype, void* stream) {
+    if (!P || !E || !row_valid || !scores || !loss_sum || B <= 0 || S <= 0 || D <= 0) return MOREC_E_ARG;
+    if (D % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((B * S + 3) / 4);
+    if (dtype == MOREC_F32) hipLaunchKernelGGL((bce_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)P, (const float*)E, row_valid, scores, loss_sum, B, S, D);
+    else if (dtype == MOREC_BF16) hipLaunchKernelGGL((bce_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)P, (const bf16*)E, row_valid, scores, loss_sum, B, S, D);
+    else return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+extern "C" int morec_bce_bwd(const void* P, const void* E, const uint8_t* row_valid, const float* scores, const float* gscale, void* dP,
+                             void* dE, int B, int S, int D, int dtype, void* stream) {
+    if (!P || !E || !row_valid || !scores || !gscale || !dP || !dE || B <= 0 || S <= 0 || D <= 0) return MOREC_E_ARG;
+    if (D % 4) return MOREC_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((B * (S + 1) + 3) / 4);
+    if (dtype == MOREC_F32) hipLaunchKernelGGL((bce_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)P, (const float*)E, row_valid, scores, gscale, (float*)dP, (float*)dE, B, S, D);
+    else if (dtype == MOREC_BF16) hipLaunchKernelGGL((bce_bwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)P, (const bf16*)E, row_valid, scores, gscale, (bf16*)dP, (bf16*)dE, B, S, D);
+    else return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

@@ -251,6 +251,23 @@ def inbatch_ce_bwd(desc, P, E, row_ids, col_ids, col_logpop, col_valid, row_vali
     return dP, dE
 
 
+def bce_fwd(P, E, row_valid, B, S):
+    """BCE variant scoring (``morec_bce_fwd``): returns (loss_sum fp32[1], scores fp32[2, B*S])."""
+    _dev(P), _dev(E)
+    scores = torch.empty((2, B * S), device=P.device, dtype=torch.float32)
+    loss_sum = torch.zeros(1, device=P.device, dtype=torch.float32)
+    check(_lib.lib().morec_bce_fwd(_p(P), _p(E), _p(row_valid), _p(scores), _p(loss_sum), B, S, P.shape[-1], code(P.dtype), _stream()),
+          "morec_bce_fwd")
+    return loss_sum, scores
+
+
+def bce_bwd(P, E, row_valid, scores, gscale_dev, B, S):
+    dP, dE = torch.empty_like(P), torch.empty_like(E)
+    check(_lib.lib().morec_bce_bwd(_p(P), _p(E), _p(row_valid), _p(scores), _p(gscale_dev), _p(dP), _p(dE), B, S, P.shape[-1],
+                                   code(P.dtype), _stream()), "morec_bce_bwd")
+    return dP, dE
+
+
 def adamw_(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(_lib.lib().morec_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(), lr, beta1,
                                  beta2, eps, wd, step, grad_scale, _stream()), "morec_adamw")

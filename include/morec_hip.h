@@ -177,6 +177,17 @@ int morec_bias_residual(const void* a, const float* bias, const void* res, const
 int morec_droppath_scale(float* out, int n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BCE variant, one sampled negative per position (bce_text/main-end2end/model/model.py:30-51).
+ * E [B, S+1, 2, D] item vectors (pos at [:, :, 0], neg at [:, :, 1]), P [B, S, D] user states, row_valid u8 [B*S].
+ * scores fp32 [2][B*S] (pos | neg) are saved for the backward; loss_sum[0] += sum_valid softplus(-pos) + softplus(neg).
+ * Backward: gscale[0] = dloss / n_valid on the device; writes dP [B, S, D] and EVERY row of dE [B, S+1, 2, D] (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int morec_bce_fwd(const void* P, const void* E, const uint8_t* row_valid, float* scores, float* loss_sum, int B, int S, int D,
+                  int dtype, void* stream);
+int morec_bce_bwd(const void* P, const void* E, const uint8_t* row_valid, const float* scores, const float* gscale, void* dP,
+                  void* dE, int B, int S, int D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Embeddings
  * ------------------------------------------------------------------------------------------ */
 /* BERT embeddings: z = word[ids[m]] + pos[m % T] + type0;  y = LN(z)  (HF BertEmbeddings). */

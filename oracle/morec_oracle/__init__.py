@@ -33,3 +33,4 @@ from .optim_ref import adamw_step  # noqa: F401
 from .data_ref import read_behaviors_ref, read_news_ref  # noqa: F401
 from .eval_ref import eval_ranks, hit_ndcg_at_k  # noqa: F401
 from .swin_ref import SwinCfg, swin_forward, vit_encoder_forward  # noqa: F401
+from .bce_ref import bce_loss, bce_model_forward  # noqa: F401
