@@ -107,10 +107,12 @@ __device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, 
 // dropout keep-mask of the lane's 4 x 4 block: element index ((tile * 32 + i) * 32 + j)
 __device__ __forceinline__ void block_drop_mask(const DropRng& d, uint64_t tile, int i0, int j0, float (&m)[4][4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+        bool kp[4];
+        drop_keep_vec<4>(d, (tile * 32 + (uint64_t)(i0 + r)) * 32 + (uint64_t)j0, kp);   // j0 is a multiple of 4: even start
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            m[r][c] = drop_keep(d, (tile * 32 + (uint64_t)(i0 + r)) * 32 + (uint64_t)(j0 + c)) ? d.inv_keep : 0.f;
+        for (int c = 0; c < 4; ++c) m[r][c] = kp[c] ? d.inv_keep : 0.f;
+    }
 }
 
 // o[r][0..CW-1] = sum_k W[k][w0 + r] * V[k][c0 .. c0+CW-1]   (W stored [k][32 + pad]: "weights by row k");

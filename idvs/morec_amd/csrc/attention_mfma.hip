@@ -127,10 +127,12 @@ __device__ __forceinline__ void drop_mask_regs(const DropRng& d, uint64_t tile, 
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
+        {
+            bool kp[4];
+            drop_keep_vec<4>(d, (tile * 32 + (uint64_t)(qb * 16 + c)) * 32 + (uint64_t)(kb * 16 + 4 * g), kp);   // even start
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                m[qb][kb][r] = drop_keep(d, (tile * 32 + (uint64_t)(qb * 16 + c)) * 32 + (uint64_t)(kb * 16 + 4 * g + r))
-                                   ? d.inv_keep : 0.f;
+            for (int r = 0; r < 4; ++r) m[qb][kb][r] = kp[r] ? d.inv_keep : 0.f;
+        }
 }
 
 // store the 4 consecutive d values of one (row, 16-col block) held by the lane

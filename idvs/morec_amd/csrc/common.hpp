@@ -145,29 +145,44 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 // ---- counter-based dropout RNG: a pure function of (seed, element index), so the backward pass regenerates
-// the forward mask instead of storing it.  Two rounds of a 32-bit avalanche mixer over (index, seed).
+// the forward mask instead of storing it.  One 32-bit avalanche hash (lowbias32 round, seed folded in twice) serves a PAIR
+// of consecutive elements: its two 16-bit halves are compared with p * 2^16.  (Round 1 hashed every element with six
+// 32-bit multiplies -- quarter-rate v_mul_lo_u32 -- which was ~25 % of the LayerNorm-backward and a visible part of the
+// attention kernels; this is 1.5 multiplies per element.)
 struct DropRng {
-    uint32_t s0, s1, thresh;   // keep iff hash >= thresh, thresh = p * 2^32
-    float inv_keep;            // 1 / (1 - p)
+    uint32_t s0, s1, thresh;   // keep iff 16-bit draw >= thresh, thresh = round-down(p * 2^16)
+    float inv_keep;            // 1 / (1 - thresh / 2^16): exactly unbiased for the probability actually applied
 };
 __host__ __device__ inline DropRng make_drop(float p, uint64_t seed) {
     DropRng d;
     d.s0 = (uint32_t)seed;
     d.s1 = (uint32_t)(seed >> 32);
-    const double t = (double)p * 4294967296.0;
-    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
-    d.inv_keep = p <= 0.f ? 1.0f : 1.0f / (1.0f - p);
+    const double t = (double)p * 65536.0;
+    d.thresh = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (uint32_t)t));
+    d.inv_keep = 1.0f / (1.0f - (float)d.thresh / 65536.0f);
     return d;
 }
-__host__ __device__ inline uint32_t drop_hash(const DropRng& d, uint64_t idx) {
-    uint32_t h = ((uint32_t)idx * 0x9E3779B1u) ^ d.s0;
-    h ^= ((uint32_t)(idx >> 32) * 0x85EBCA77u) + d.s1;
-    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
-    h += d.s1;
-    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+// hash of element pair `pair` (= element index >> 1)
+__host__ __device__ inline uint32_t drop_hash(const DropRng& d, uint64_t pair) {
+    const uint32_t hi = (uint32_t)(pair >> 32);
+    uint32_t h = ((uint32_t)pair * 0x9E3779B1u) ^ d.s0 ^ (hi + ((hi << 16) | (hi >> 16)));
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h += d.s1; h *= 0x846ca68bu; h ^= h >> 16;
     return h;
 }
-__host__ __device__ inline bool drop_keep(const DropRng& d, uint64_t idx) { return drop_hash(d, idx) >= d.thresh; }
+__host__ __device__ inline bool drop_keep(const DropRng& d, uint64_t idx) {
+    const uint32_t h = drop_hash(d, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= d.thresh;
+}
+// keep flags of EV consecutive elements starting at an EVEN index: one hash per pair
+template <int EV>
+__device__ __forceinline__ void drop_keep_vec(const DropRng& d, uint64_t idx0, bool (&keep)[EV]) {
+#pragma unroll
+    for (int k = 0; k < EV; k += 2) {
+        const uint32_t h = drop_hash(d, (idx0 + k) >> 1);
+        keep[k] = (h & 0xffffu) >= d.thresh;
+        keep[k + 1] = (h >> 16) >= d.thresh;
+    }
+}
 
 // ---- host-side argument checks -------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

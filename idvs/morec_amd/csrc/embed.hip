@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
             for (int k = 0; k < EV; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
             if (dout.thresh) {   // HF BertEmbeddings: dropout after the LayerNorm
 #pragma unroll
-                for (int k = 0; k < EV; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) o[k] *= dout.inv_keep;
+                bool kp[EV];
+                drop_keep_vec<EV>(dout, base + c, kp);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) o[k] = kp[k] ? o[k] : 0.f;
             }
             vio<T>::store(y + base + c, o);
         }

@@ -50,7 +50,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
             if (din.thresh) {   // dropout on the sub-layer output BEFORE the residual add (modules.py:16,62; HF Bert*Output)
 #pragma unroll
-                for (int k = 0; k < EV; ++k) v[i][k] = drop_keep(din, base + c + k) ? v[i][k] * din.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) v[i][k] *= din.inv_keep;
+                bool kp[EV];
+                drop_keep_vec<EV>(din, base + c, kp);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) v[i][k] = kp[k] ? v[i][k] : 0.f;
             }
             if (res) {
                 float r[EV];
@@ -107,7 +111,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             for (int k = 0; k < EV; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + b[k];
             if (dout.thresh) {  // dropout on the LayerNorm output (embedding stages: modules.py:93-94, HF BertEmbeddings)
 #pragma unroll
-                for (int k = 0; k < EV; ++k) o[k] = drop_keep(dout, base + c + k) ? o[k] * dout.inv_keep : 0.f;
+                for (int k = 0; k < EV; ++k) o[k] *= dout.inv_keep;
+                bool kp[EV];
+                drop_keep_vec<EV>(dout, base + c, kp);
+#pragma unroll
+                for (int k = 0; k < EV; ++k) o[k] = kp[k] ? o[k] : 0.f;
             }
             vio<T>::store(y + base + c, o);
         }
@@ -161,7 +169,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 }
                 if (dout.thresh) {
 #pragma unroll
-                    for (int k = 0; k < EV; ++k) d[k] = drop_keep(dout, base + c + k) ? d[k] * dout.inv_keep : 0.f;
+                    for (int k = 0; k < EV; ++k) d[k] *= dout.inv_keep;
+                    bool kp[EV];
+                    drop_keep_vec<EV>(dout, base + c, kp);
+#pragma unroll
+                    for (int k = 0; k < EV; ++k) d[k] = kp[k] ? d[k] : 0.f;
                 }
                 vio<T>::load(z + base + c, zz);
 #pragma unroll
@@ -197,7 +209,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
                     const float rsc = rowscale ? rowscale[row / rps] : 1.0f;
 #pragma unroll
-                    for (int k = 0; k < EV; ++k) o[k] = (!din.thresh || drop_keep(din, base + c + k)) ? o[k] * din.inv_keep * rsc : 0.f;
+                    for (int k = 0; k < EV; ++k) o[k] *= din.inv_keep * rsc;
+                    if (din.thresh) {
+                        bool kp[EV];
+                        drop_keep_vec<EV>(din, base + c, kp);
+#pragma unroll
+                        for (int k = 0; k < EV; ++k) o[k] = kp[k] ? o[k] : 0.f;
+                    }
                     vio<T>::store(dzd + base + c, o);
                 }
                 if (dbias) {

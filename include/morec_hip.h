@@ -90,7 +90,8 @@ int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, vo
  * LayerNorm with fused pre-add:  z = drop_in(x (+ bias[n])) (+ res[m,n]) (+ pos[m % pos_period, n]);
  * y = drop_out((z - mean) * rstd * gamma + beta).   (T/model/modules.py:14-17,61-63,93-94; HF BertSelfOutput /
  * BertOutput / BertEmbeddings).  z_out may be NULL (not needed) or alias x.
- * Dropout is counter-based: element kept iff hash(seed, m*N + n) >= p * 2^32, scaled by 1/(1-p); p = 0 disables.
+ * Dropout is counter-based: element e = m*N + n is kept iff the (e & 1)-th 16-bit half of hash(seed, e >> 1) >= floor(p * 2^16),
+ * kept values scaled by 1 / (1 - floor(p * 2^16) / 2^16); p = 0 disables.  morec_dropout_keep_mask exports the same stream.
  * drop_in  = the Dropout the reference applies to the sub-layer output before the residual add;
  * drop_out = the Dropout applied to the LayerNorm output of the embedding stages.
  * rowscale (may be NULL): per-sample DropPath scale of the sub-layer branch (HF SwinDropPath, modeling_swin.py:42-60):
