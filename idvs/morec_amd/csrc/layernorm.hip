@@ -16,7 +16,8 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <typename T, int VPL, int LPR = 64>
+// FULL: N == VPL * LPR * EV exactly -- no column bounds checks, so the loads of a row are issued back to back
+template <typename T, int VPL, int LPR = 64, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                      const T* __restrict__ res, const float* __restrict__ pos,
                                                      int pos_period, const float* __restrict__ gamma,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * LPR + lane) * EV;
-        if (c < N) {
+        if (FULL || c < N) {
             vio<T>::load(x + base + c, v[i]);
             if (bias) {
                 float b[EV];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * LPR + lane) * EV;
-        if (c < N) {
+        if (FULL || c < N) {
 #pragma unroll
             for (int k = 0; k < EV; ++k) {
                 const float d = v[i][k] - mean;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * LPR + lane) * EV;
-        if (c < N) {
+        if (FULL || c < N) {
             float g[EV], b[EV], o[EV];
             load_f32v<EV>(gamma + c, g);
             load_f32v<EV>(beta + c, b);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // Backward.  Each block owns RPB consecutive rows, one row per wave per trip.  Per-column dgamma / dbeta (and the
 // sub-layer bias gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave
 // as ONE atomicAdd per column per block.
-template <typename T, int VPL, int LPR = 64>
+template <typename T, int VPL, int LPR = 64, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
         const int c = (i * LPR + lane) * EV;
 #pragma unroll
         for (int k = 0; k < EV; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
-        if (c < N) load_f32v<EV>(gamma + c, gm[i]);
+        if (FULL || c < N) load_f32v<EV>(gamma + c, gm[i]);
     }
     for (int row = r0 + wave; row < r1; row += NP) {
         const size_t base = (size_t)row * N;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * LPR + lane) * EV;
-            if (c < N) {
+            if (FULL || c < N) {
                 float d[EV], zz[EV];
                 vio<T>::load(dy_a + base + c, d);
                 if (dy_b) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * LPR + lane) * EV;
-            if (c < N) {
+            if (FULL || c < N) {
                 float o[EV];
 #pragma unroll
                 for (int k = 0; k < EV; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * LPR + lane) * EV;
-            if (c < N) {
+            if (FULL || c < N) {
                 store_f32v<EV>(sg + (size_t)wave * N + c, ag[i]);
                 store_f32v<EV>(sb + (size_t)wave * N + c, ab[i]);
                 if (dbias) store_f32v<EV>(sd + (size_t)wave * N + c, ad[i]);
@@ -268,7 +269,9 @@ static int ln_fwd_dispatch(const void* x, const float* bias, const void* res, co
 #define LN_FWD(V) LN_FWD_L(V, 64)
     if (N <= 16 * vio<T>::EV) LN_FWD_L(1, 16);
     else if (N <= 32 * vio<T>::EV) LN_FWD_L(1, 32);
-    else if (N == 96 * vio<T>::EV) LN_FWD_L(3, 32);   // H = 768 in bf16: 96 vectors = 32 lanes x 3, two rows per wave, no idle lanes
+    else if (N == 96 * vio<T>::EV)   // H = 768 in bf16: 96 vectors = 32 lanes x 3, two rows per wave, no idle lanes, no bounds checks
+        hipLaunchKernelGGL((ln_fwd_kernel<T, 3, 32, true>), dim3((M + 7) / 8), block, 0, s, (const T*)x, bias, (const T*)res, pos, pos_period,
+                           gamma, beta, eps, (T*)z_out, (T*)y, mean, rstd, M, N, din, dout, rowscale, rps);
     else if (vpl <= 1) LN_FWD(1);
     else if (vpl <= 2) LN_FWD(2);
     else if (vpl <= 3) LN_FWD(3);
@@ -323,7 +326,13 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
 #define LN_BWD(V) LN_BWD_L(V, 64)
     if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16);
     else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32);
-    else if (N == 96 * vio<T>::EV) LN_BWD_L(3, 32);
+    else if (N == 96 * vio<T>::EV) {
+        const size_t lds = (dgamma || dbias) ? (size_t)12 * 2 * N * sizeof(float) : 0;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, 3, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 32, true>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b, (const T*)z, mean, rstd, gamma,
+                           (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, dout, (const T*)dres, rowscale, rps);
+    }
     else if (vpl <= 1) LN_BWD(1);
     else if (vpl <= 2) LN_BWD(2);
     else if (vpl <= 3) LN_BWD(3);
