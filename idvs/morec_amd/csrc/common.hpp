@@ -143,6 +143,44 @@ __device__ __forceinline__ float dgelu_f(float x) {
     gelu_parts(x, cdf, e);
     return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
+// Two elements at a time: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (half the VALU issue slots of the scalar form);
+// v_rcp / v_exp stay per element.  Same arithmetic as gelu_parts, element for element.
+__device__ __forceinline__ void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& pdf_unnorm) {
+    const f32x2_t ax = {fabsf(x[0]) * 0.70710678118654752440f, fabsf(x[1]) * 0.70710678118654752440f};
+    const f32x2_t den = ax * 0.3275911f + 1.0f;
+    const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2_t y = t * 1.061405429f + (-1.453152027f);
+    y = y * t + 1.421413741f;
+    y = y * t + (-0.284496736f);
+    y = y * t + 0.254829592f;
+    y = y * t;
+    const f32x2_t na = -(ax * ax);
+    const f32x2_t e = {__expf(na[0]), __expf(na[1])};
+    const f32x2_t erf_abs = 1.0f - y * e;
+    cdf = f32x2_t{copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])} * 0.5f + 0.5f;
+    pdf_unnorm = e;
+}
+__device__ __forceinline__ void gelu4(float (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2_t x = {v[2 * q], v[2 * q + 1]};
+        f32x2_t cdf, e;
+        gelu_parts2(x, cdf, e);
+        const f32x2_t r = x * cdf;
+        v[2 * q] = r[0]; v[2 * q + 1] = r[1];
+    }
+}
+// v[k] *= gelu'(u[k])
+__device__ __forceinline__ void dgelu4_mul(float (&v)[4], const float (&u)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2_t x = {u[2 * q], u[2 * q + 1]};
+        f32x2_t cdf, e;
+        gelu_parts2(x, cdf, e);
+        const f32x2_t d = (x * 0.39894228040143267794f) * e + cdf;
+        v[2 * q] *= d[0]; v[2 * q + 1] *= d[1];
+    }
+}
 
 // ---- counter-based dropout RNG: a pure function of (seed, element index), so the backward pass regenerates
 // the forward mask instead of storing it.  One 32-bit avalanche hash (lowbias32 round, seed folded in twice) serves a PAIR

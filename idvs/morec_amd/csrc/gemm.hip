@@ -59,8 +59,7 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pre[r] = v[r];
         if constexpr (ACT == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+            gelu4(v);
         } else if constexpr (ACT == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -68,8 +67,7 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
             float u[4];
             io<TO>::load4(din + (size_t)m * p.ldc + n, u);
             if constexpr (ACT == 3) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= dgelu_f(u[r]);
+                dgelu4_mul(v, u);
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
