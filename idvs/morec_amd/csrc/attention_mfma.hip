@@ -56,6 +56,17 @@ __device__ __forceinline__ bf16x8_t frag_nt(const char* tile, int blk, int ks) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// NT fragment straight from global memory (no LDS tile): 8 consecutive d of row (blk*16 + lane&15), rows >= Tlen read as zero.
+// Used for the operands that are only ever consumed d-contiguous (Q / K in the forward scores, V in the backward dP):
+// every LDS tile dropped raises the number of resident wavefronts of this latency-bound kernel.
+__device__ __forceinline__ bf16x8_t frag_nt_global(const bf16* __restrict__ src, size_t row0, int pitch, int col, int blk, int Tlen) {
+    const int lane = threadIdx.x;
+    const int r = blk * 16 + (lane & 15);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < Tlen) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * (size_t)pitch + col + (lane >> 4) * 8);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // transposed fragment of a row-major tile: lane (c = lane&15, g = lane>>4) receives, for column col0 + c, the rows
 // 4g .. 4g+3 (elements 0..3) and 16+4g .. 16+4g+3 (elements 4..7)
 __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int pitch_bytes, int col0) {
@@ -144,8 +155,6 @@ __device__ __forceinline__ void store4d(bf16* dst, size_t row, int pitch, int co
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
-    __shared__ __attribute__((aligned(16))) char sQ[TILE];
-    __shared__ __attribute__((aligned(16))) char sK[TILE];
     __shared__ __attribute__((aligned(16))) char sV[TILE];
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
@@ -155,22 +164,16 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}};
     const int nch = (a.dh + DCH - 1) / DCH;
-    for (int ch = 0; ch < nch; ++ch) {
-        const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
-        stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
-        stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
-        if (nch == 1) stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh, nc, a.T, sV);
-        __syncthreads();
-        for (int ks = 0; ks < nc / 32; ++ks) {
-            bf16x8_t qf[2] = {frag_nt(sQ, 0, ks), frag_nt(sQ, 1, ks)};
-            bf16x8_t kf[2] = {frag_nt(sK, 0, ks), frag_nt(sK, 1, ks)};
+    if (nch == 1) stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh, a.dh, a.T, sV);
+    for (int d = 0; d < a.dh; d += 32) {     // one MFMA k-step per 32 head columns, operands straight from global memory
+        const bf16x8_t qf[2] = {frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 1, a.T)};
+        const bf16x8_t kf[2] = {frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 1, a.T)};
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
-        }
-        __syncthreads();
+            for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
     }
+    __syncthreads();
     softmax_regs(s, a, a.key_keep + row0);
     if (a.drop.thresh) {
         float m[2][2][4];
@@ -205,7 +208,6 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
     __shared__ __attribute__((aligned(16))) char sQ[TILE];
     __shared__ __attribute__((aligned(16))) char sK[TILE];
-    __shared__ __attribute__((aligned(16))) char sV[TILE];
     __shared__ __attribute__((aligned(16))) char sO[TILE];
     __shared__ __attribute__((aligned(16))) char sP[32 * PP];    // dropped probabilities  [query][key] bf16
     __shared__ __attribute__((aligned(16))) char sS[32 * PP];    // dS                     [query][key] bf16
@@ -222,13 +224,13 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
         const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
         stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
         stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
-        stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh + d0, nc, a.T, sV);
         stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
         __syncthreads();
         for (int ks = 0; ks < nc / 32; ++ks) {
             bf16x8_t qf[2] = {frag_nt(sQ, 0, ks), frag_nt(sQ, 1, ks)};
             bf16x8_t kf[2] = {frag_nt(sK, 0, ks), frag_nt(sK, 1, ks)};
-            bf16x8_t vf[2] = {frag_nt(sV, 0, ks), frag_nt(sV, 1, ks)};
+            const int vcol = 2 * H + head * a.dh + d0 + ks * 32;     // V is only consumed d-contiguous: no LDS tile
+            bf16x8_t vf[2] = {frag_nt_global(a.qkv, row0, pitch, vcol, 0, a.T), frag_nt_global(a.qkv, row0, pitch, vcol, 1, a.T)};
             bf16x8_t of[2] = {frag_nt(sO, 0, ks), frag_nt(sO, 1, ks)};
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
