@@ -61,7 +61,7 @@ _SIGS = {
     "morec_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
     "morec_bert_embed_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_float, C.c_uint64, _P]),
-    "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "morec_gather_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_scatter_add_rows": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_indexed_rows_copy": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -138,6 +138,57 @@ __global__ __launch_bounds__(256) void word_scatter_kernel(const int32_t* __rest
     }
 }
 
+// Same scatter over rows visited in token-id order (`order` = argsort of ids): equal ids are adjacent, so a wave sums a run of
+// rows in registers and issues ONE atomic per element per run instead of one per row -- the [CLS] / [SEP] rows that every title
+// contributes to (2688 colliding rows at B = 128) made the plain scatter 0.76 ms per step.
+template <typename T, int CPL>   // CPL = float4 column groups per lane: H <= 256 * CPL
+__global__ __launch_bounds__(256) void word_scatter_sorted_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ order,
+                                                                  const T* __restrict__ dz, float* __restrict__ dword, int pad_id,
+                                                                  int M, int H, int rows_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i0 = w * rows_per_wave, i1 = min(M, i0 + rows_per_wave);
+    if (i0 >= M) return;
+    float acc[CPL][4];
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0 || cur == pad_id) return;
+        float* dst = dword + (size_t)cur * H;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            if (c < H) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) atomicAdd(dst + c + k, acc[q][k]);
+            }
+        }
+    };
+    for (int i = i0; i < i1; ++i) {
+        const int row = order[i];
+        const int id = ids[row];
+        if (id != cur) {
+            flush();
+            cur = id;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[q][k] = 0.f;
+        }
+        if (id == pad_id) continue;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = (q * 64 + lane) * 4;
+            if (c < H) {
+                float v[4];
+                io<T>::load4(dz + (size_t)row * H + c, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[q][k] += v[k];
+            }
+        }
+    }
+    flush();
+}
+
 // dpos[t] = sum over sequences of dz[seq*T + t]; dtype0 = sum over all rows: block (t, chunk of sequences)
 template <typename T>
 __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
@@ -154,17 +205,22 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict_
 }
 
 extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0,
-                                    int pad_id, int M, int T, int H, int dtype, void* stream) {
+                                    int pad_id, int M, int T, int H, int dtype, const int32_t* order, void* stream) {
     if (!ids || !dz || !dword || !dpos || M <= 0 || T <= 0 || H <= 0 || M % T) return MOREC_E_ARG;
     if (H % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int spb = 64;
     dim3 g1((M + 3) / 4), g2(T, (M / T + spb - 1) / spb);
+    const int rpw = 32;                                   // sorted rows per wave
+    dim3 g3((((M + rpw - 1) / rpw) + 3) / 4);
+    const bool sorted = order != nullptr && H <= 1024;
     if (dtype == MOREC_F32) {
-        hipLaunchKernelGGL((word_scatter_kernel<float>), g1, dim3(256), 0, s, ids, (const float*)dz, dword, pad_id, M, H);
+        if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<float, 4>), g3, dim3(256), 0, s, ids, order, (const float*)dz, dword, pad_id, M, H, rpw);
+        else hipLaunchKernelGGL((word_scatter_kernel<float>), g1, dim3(256), 0, s, ids, (const float*)dz, dword, pad_id, M, H);
         hipLaunchKernelGGL((pos_type_grad_kernel<float>), g2, dim3(256), 0, s, (const float*)dz, dpos, dtype0, M / T, T, H, spb);
     } else if (dtype == MOREC_BF16) {
-        hipLaunchKernelGGL((word_scatter_kernel<bf16>), g1, dim3(256), 0, s, ids, (const bf16*)dz, dword, pad_id, M, H);
+        if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<bf16, 4>), g3, dim3(256), 0, s, ids, order, (const bf16*)dz, dword, pad_id, M, H, rpw);
+        else hipLaunchKernelGGL((word_scatter_kernel<bf16>), g1, dim3(256), 0, s, ids, (const bf16*)dz, dword, pad_id, M, H);
         hipLaunchKernelGGL((pos_type_grad_kernel<bf16>), g2, dim3(256), 0, s, (const bf16*)dz, dpos, dtype0, M / T, T, H, spb);
     } else {
         return MOREC_E_DTYPE;

@@ -418,9 +418,10 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
                                 p_out=drop.p_hidden, seed_out=drop.site(0))
+    order = torch.argsort(ids32).to(torch.int32)      # integer bookkeeping: rows in token-id order for the run-length scatter
     ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],
                         grads[bm + "embeddings.position_embeddings.weight"],
-                        grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T)
+                        grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T, order)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -187,10 +187,11 @@ def bert_embed_fwd(ids32, word, pos, type0, gamma, beta, eps, T, dtype, p_out=0.
     return y, z, mean, rstd
 
 
-def bert_embed_bwd_(ids32, dz, dword, dpos, dtype0, pad_id, T):
+def bert_embed_bwd_(ids32, dz, dword, dpos, dtype0, pad_id, T, order=None):
+    """``order``: int32 argsort of ``ids32`` (integer bookkeeping done by the caller) -- enables the run-length scatter."""
     M, H = dz.shape
     check(_lib.lib().morec_bert_embed_bwd(_p(ids32), _p(dz), _p(dword), _p(dpos), _p(dtype0), pad_id, M, T, H,
-                                          code(dz.dtype), _stream()), "morec_bert_embed_bwd")
+                                          code(dz.dtype), _p(order), _stream()), "morec_bert_embed_bwd")
 
 
 def gather_rows(table, idx32, dtype):

@@ -195,9 +195,11 @@ int morec_bce_bwd(const void* P, const void* E, const uint8_t* row_valid, const 
 int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos, const float* type0,
                          const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
                          float* rstd, int M, int T, int H, int dtype, float p_out, uint64_t seed_out, void* stream);
-/* scatter dz into dword[ids[m]] (skipping pad_id: nn.Embedding padding_idx), dpos[m % T], dtype0 */
+/* scatter dz into dword[ids[m]] (skipping pad_id: nn.Embedding padding_idx), dpos[m % T], dtype0.
+ * order (may be NULL): int32[M] permutation visiting the rows in ascending token id (argsort of ids); with it equal ids are
+ * summed in registers before the atomic (one atomic per run instead of one per row). */
 int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0, int pad_id,
-                         int M, int T, int H, int dtype, void* stream);
+                         int M, int T, int H, int dtype, const int32_t* order, void* stream);
 /* out[r, :] = table[idx[r], :]  (fp32 table -> dtype out).  T/model/model.py:37 nn.Embedding lookup. */
 int morec_gather_rows(const float* table, const int32_t* idx, void* out, int R, int D, int dtype, void* stream);
 /* dtable[idx[r], :] += d[r, :] unless idx[r] == pad_id (padding_idx=0, T/model/model.py:27) */

@@ -232,6 +232,15 @@ def test_bert_embed(dt):
     assert rel(dword, ref) < 1e-5
     assert rel(dpos[:T], dz.double().view(n_seq, T, H).sum(0)) < 1e-5 and (dpos[T:] == 0).all()
     assert rel(dtyp, dz.double().sum(0)) < 1e-5
+    # run-length scatter over token-id order (hot tokens: every 5th row is the same id, like [CLS] / [SEP])
+    ids2 = ids.clone()
+    ids2[::5] = 101
+    dword2, dpos2, dtyp2 = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros(H, device=DEV)
+    ops.bert_embed_bwd_(ids2, dz, dword2, dpos2, dtyp2, 0, T, torch.argsort(ids2).to(torch.int32))
+    ref2 = torch.zeros_like(word, dtype=torch.float64)
+    ref2.index_add_(0, ids2.long(), dz.double())
+    ref2[0] = 0
+    assert rel(dword2, ref2) < 1e-5
 
 
 @pytest.mark.parametrize("dt", DT)
