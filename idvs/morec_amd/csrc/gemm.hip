@@ -17,6 +17,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     float alpha;
     int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
+    int wave_epilogue;
 };
 
 // ACT is a compile-time epilogue selector (0 linear, 1 GELU, 2 ReLU, 3 x GELU'(dact_in), 4 x ReLU'(dact_in)): with the
@@ -79,6 +80,51 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     // full 16-byte lane write along a row -- the direct form (8-byte pieces, 16 different rows per wave
     // instruction) is store-issue bound and cost more than the K = 768 main loop itself.
     constexpr int EPV_O = 16 / (int)sizeof(TO);
+    if (p.accumulate == 0 && p.vec_store && p.wave_epilogue) {
+        // Wave-local form of the same idea: every wave transposes its own 16-row blocks through a private LDS slice (no
+        // workgroup barriers in the epilogue) and stores 16-byte lanes along rows of its NI * 16 columns.
+        constexpr int WROWB = G::NI * 16 * (int)sizeof(TO) + 16;
+        constexpr int VPRW = G::NI * 16 * (int)sizeof(TO) / 16;
+        static_assert(G::NWAVES * 16 * WROWB <= G::LDS_BYTES, "wave slices do not fit");
+        char* ws = smem + wave * 16 * WROWB;
+        auto wfence = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto flushw = [&](TO* dst, int mi) {
+            wfence();
+#pragma unroll
+            for (int v = lane; v < 16 * VPRW; v += 64) {
+                const int lrow = v / VPRW, cv = v % VPRW;
+                const int m = m0 + wm * G::MI * 16 + mi * 16 + lrow;
+                const int n = n0 + wn * G::NI * 16 + cv * EPV_O;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = *reinterpret_cast<const uint4*>(ws + lrow * WROWB + cv * 16);
+            }
+            wfence();
+        };
+#pragma unroll
+        for (int mi = 0; mi < G::MI; ++mi) {
+            const int m = acc_row_cfg<G>(m0, mi);
+            float vv[G::NI][4];
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni) {
+                const int n = acc_col_cfg<G>(n0, ni);
+                float pre[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[ni][r] = 0.f;
+                if (m < p.M && n < p.N) finish(mi, ni, m, n, vv[ni], pre);
+                if (aux) io<TO>::store4(reinterpret_cast<TO*>(ws + c16 * WROWB + (ni * 16 + g4 * 4) * (int)sizeof(TO)), pre);
+            }
+            if (aux) flushw(aux, mi);
+#pragma unroll
+            for (int ni = 0; ni < G::NI; ++ni)
+                io<TO>::store4(reinterpret_cast<TO*>(ws + c16 * WROWB + (ni * 16 + g4 * 4) * (int)sizeof(TO)), vv[ni]);
+            flushw(C, mi);
+        }
+        return;
+    }
     if (p.accumulate == 0 && p.vec_store) {
         constexpr int ROWB = G::TN * (int)sizeof(TO) + 16;                    // LDS pitch of a staged output row
         constexpr int NP = (G::TM * ROWB + G::LDS_BYTES - 1) / G::LDS_BYTES;  // passes needed
@@ -248,6 +294,12 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
+    {   // epilogue form: per-wave LDS slices without workgroup barriers pay off where the epilogue is heavy (GELU + the second
+        // output) or the tile row is short (N <= 1024); measured per shape with scripts/gemm_bench.py.  MOREC_GEMM_EPI=w|b forces one.
+        static int we = -1;
+        if (we < 0) { const char* e = getenv("MOREC_GEMM_EPI"); we = !e ? 2 : (e[0] == 'w' ? 1 : 0); }
+        a.wave_epilogue = we == 2 ? ((aux_out != nullptr || d->N <= 1024) ? 1 : 0) : we;
+    }
     a.vec_store = ((d->N * os) % 16 == 0) && ((d->ldc * os) % 16 == 0) && (!aux_out || aligned16(aux_out));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float>(d, a, s);
