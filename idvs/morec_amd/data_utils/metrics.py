@@ -3,7 +3,6 @@
 replaced by the count-greater HIP kernel (``morec_eval_rank``), the score matrix is never materialised."""
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch

@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+from ._lib import ACT_GELU, ACT_RELU
 
 
 @dataclass

@@ -17,7 +17,7 @@ import torch
 
 from . import ops
 from ._lib import ACT_GELU
-from .engine import NO_DROP, DropCfg, PreparedLinear, linear_wgrad_, prepare_linear
+from .engine import NO_DROP, DropCfg, linear_wgrad_, prepare_linear
 
 IN = "cv_encoder.image_net."
 

@@ -1,7 +1,6 @@
 """Evaluation restatement (HR@10 / nDCG@10) -- TEST INFRASTRUCTURE ONLY."""
 from __future__ import annotations
 
-import math
 
 import numpy as np
 
