@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It has to be the one already mapped when libmorec_hip.so
+# is loaded, otherwise the kernels would be launched through a second, uninitialised runtime ("no ROCm-capable device") while
+# the streams and buffers they are handed belong to PyTorch's.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmorec_hip.so")
 
