@@ -353,8 +353,10 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
     if (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
-        cu, tok_idx = token_packing(text[:, T:])
-        if tok_idx.numel() == Nc * T:
+        mask = text[:, T:]
+        run_of_ones = bool((mask[:, :-1] >= mask[:, 1:]).all()) if T > 1 else True   # ones, then zeros (joins the sync below)
+        cu, tok_idx = token_packing(mask) if run_of_ones else (None, torch.empty(Nc * T, dtype=torch.int32))
+        if tok_idx.numel() == Nc * T:        # nothing to drop -- or a mask with holes, which keeps the padded layout
             cu, tok_idx = None, None          # nothing to drop
         else:
             x = ops.indexed_rows_copy(x, torch.empty((tok_idx.numel(), H), device=x.device, dtype=dtype), in_idx=tok_idx)

@@ -240,3 +240,22 @@ def test_oracle_midsize_all_grads():
             assert v.grad.abs().max().item() < 1e-5, k
             continue
         assert relerr(v.grad.cpu().numpy(), gref.numpy()) < 5e-4, k
+
+
+def test_mask_with_holes_keeps_the_padded_layout(golden_dir):
+    """The unpadded token layout needs run-of-ones masks (what the reference's tokenizer path builds); any other mask silently
+    stays on the padded layout, so the two settings must agree bit for bit there."""
+    from idvs.morec_amd import engine as _engine
+    gd = g(golden_dir, "g5_g8_bert_micro.npz")
+    m, ids, items, lm, (S, D, T, item_num, B) = _modal(gd, "", "micro", "fp32")
+    items = items.clone()
+    items[3, T + 2] = 0          # punch a hole into one attention mask
+    saved = _engine.UNPAD_DEFAULT
+    try:
+        _engine.UNPAD_DEFAULT = True
+        a = m.bert_encoder(items)
+        _engine.UNPAD_DEFAULT = False
+        b = m.bert_encoder(items)
+    finally:
+        _engine.UNPAD_DEFAULT = saved
+    assert torch.equal(a, b)
