@@ -40,7 +40,10 @@ def collate_train_batch(u2seq, users, item_content, max_seq_len, use_modal):
         ids[r, L - len(seq):] = seq
         log_mask[r, L - len(seq):] = 1.0
     items = np.asarray(item_content)[ids] if use_modal else ids
-    return torch.from_numpy(ids), torch.from_numpy(np.ascontiguousarray(items)).long(), torch.from_numpy(log_mask)
+    items = torch.from_numpy(np.ascontiguousarray(items))
+    if items.dtype != torch.uint8:          # uint8 = decoded images of the vision variant (normalised on the device)
+        items = items.long()
+    return torch.from_numpy(ids), items, torch.from_numpy(log_mask)
 
 
 class BuildEvalDataset(Dataset):

@@ -28,7 +28,11 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     vision = bool(use_modal and getattr(m, "vision", False))
     # vision (``get_itemLMDB_embeddings``, V/data_utils/metrics.py:63-76): ``item_content`` is the decoded image tensor
     # f32[item_num+1, 3, R, R] (the LMDB / PIL decode of V/data_utils/dataset.py is host-side I/O outside this library)
-    content = torch.as_tensor(np.asarray(item_content)).float() if vision else torch.as_tensor(np.asarray(item_content)).long()
+    content = torch.as_tensor(np.asarray(item_content))
+    if not vision:
+        content = content.long()
+    elif content.dtype != torch.uint8:      # uint8 HWC images are normalised on the device (morec_swin_patchify_u8)
+        content = content.float()
     outs = []
     with torch.no_grad():
         for s in range(0, content.shape[0], test_batch_size):

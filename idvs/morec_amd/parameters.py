@@ -43,6 +43,12 @@ def build_parser():
     p.add_argument("--num_words_abstract", type=int, default=50)
     p.add_argument("--num_words_body", type=int, default=50)
     p.add_argument("--news_attributes", type=str, default="title")
+    # ============== vision variant (V/parameters.py:34-39) ==============
+    p.add_argument("--CV_model_load", type=str, default="None", help="swin_tiny | swin_small | swin_base (vision item tower)")
+    p.add_argument("--CV_resize", type=int, default=224)
+    p.add_argument("--images_npy", type=str, default="None",
+                   help="uint8 array [item_num + 1, R, R, 3] of decoded, resized item images (row 0 = padding item); stands in for the "
+                        "LMDB reader of V/data_utils/dataset.py, whose lmdb / torchvision dependencies are not part of this package")
     # ============== MI355X path ==============
     p.add_argument("--compute_dtype", type=str, default="bf16", choices=["bf16", "fp32"],
                    help="bf16 MFMA operands / fp32 accumulate (default) or exact-fp32 MFMA parity mode")

@@ -21,6 +21,8 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 
 from .data_utils import collate_train_batch, eval_model, get_item_embeddings, read_behaviors, read_news
 from .model import BertShape, HipBertModel, Model
+from .model.swin import HipSwinForImageClassification
+from .swin_engine import SwinShape
 from .parameters import parse_args
 from .train_step import TrainStep
 
@@ -74,10 +76,18 @@ def train(args, use_modal, local_rank):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     S, T = args.max_seq_len, args.num_words_title
+    vision = use_modal and args.CV_model_load != "None"
+    if not vision and hasattr(args, "CV_model_load"):
+        del args.CV_model_load                # `Model` picks the vision tower by the presence of this attribute (V/model/model.py:24-29)
     if args.synthetic > 0:
         item_num, content, users_train, users_valid, users_test, hist_valid, hist_test, pop = synthetic_dataset(
             args.synthetic, args.synthetic_items, S, T)
         item_content = content if use_modal else np.arange(item_num + 1)
+        if vision:      # decoded uint8 images; a real run passes --images_npy (what the LMDB of V/data_utils holds after Resize)
+            R = args.CV_resize
+            item_content = (np.load(args.images_npy, mmap_mode="r") if args.images_npy != "None" else
+                            np.random.default_rng(4321).integers(0, 256, (item_num + 1, R, R, 3), dtype=np.uint8))
+            assert item_content.shape == (item_num + 1, R, R, 3) and item_content.dtype == np.uint8
     else:
         a, b, c = read_news(os.path.join(args.root_data_dir, args.dataset, args.news))
         item_num, _, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(
@@ -87,7 +97,12 @@ def train(args, use_modal, local_rank):
                              "(read_news_bert + get_doc_input_bert are provided in data_utils.preprocess)")
         item_content = np.arange(item_num + 1)
     bert = None
-    if use_modal:
+    if vision:
+        bert = HipSwinForImageClassification(SwinShape.named(args.CV_model_load), args.embedding_dim)   # V/run.py:47-54
+        for index, (name, param) in enumerate(bert.named_parameters()):   # V/run.py:58-60
+            if index < args.freeze_paras_before:
+                param.requires_grad = False
+    elif use_modal:
         shape = BertShape.named(args.bert_model_load)
         args.word_embedding_dim = shape.hidden_size              # T/run.py:55-72
         bert = HipBertModel(shape)
@@ -105,8 +120,12 @@ def train(args, use_modal, local_rank):
     else:
         wrapped = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True) if world > 1 else model
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        groups = [{"params": [p for n, p in named if "bert_model" in n], "lr": args.fine_tune_lr, "weight_decay": args.fine_tune_l2_weight},
-                  {"params": [p for n, p in named if "bert_model" not in n], "lr": args.lr, "weight_decay": args.l2_weight}]
+        if vision:   # V/run.py:121-135
+            tower = lambda n: "image_net" in n and not ("fc" in n or "classifier" in n)
+        else:        # T/run.py:150-162
+            tower = lambda n: "bert_model" in n
+        groups = [{"params": [p for n, p in named if tower(n)], "lr": args.fine_tune_lr, "weight_decay": args.fine_tune_l2_weight},
+                  {"params": [p for n, p in named if not tower(n)], "lr": args.lr, "weight_decay": args.l2_weight}]
         optimizer = optim.AdamW([g for g in groups if g["params"]])   # T/run.py:159-162
     best, step = 0.0, 0
     for ep in range(1, args.epoch + 1):
@@ -118,7 +137,10 @@ def train(args, use_modal, local_rank):
             batch_users = [users[i] for i in order[b * args.batch_size:(b + 1) * args.batch_size]]
             ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
             ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
-            items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
+            if vision:
+                items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)
+            else:
+                items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
             if args.fused_step:
                 loss = stepper.step(ids.view(-1), items, log_mask)
             else:

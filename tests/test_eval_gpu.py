@@ -63,3 +63,18 @@ def test_run_driver_modal_tiny_steps():
     run.setup_seed(12345)
     best = run.train(args, True, 0)
     assert 0.0 <= best <= 1.0
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_run_driver_vision_micro_steps(fused):
+    """The driver in vision mode (V/run.py shape): uint8 image catalogue, on-device normalisation, Swin micro tower, the
+    optimizer grouping of V/run.py:121-135, eval over the image catalogue."""
+    from idvs.morec_amd import run
+    from idvs.morec_amd.parameters import parse_args
+    args = parse_args(["--synthetic", "300", "--synthetic_items", "120", "--item_tower", "modal", "--CV_model_load", "swin_micro",
+                       "--CV_resize", "56", "--freeze_paras_before", "0", "--batch_size", "16", "--max_seq_len", "6",
+                       "--embedding_dim", "64", "--lr", "1e-3", "--fine_tune_lr", "1e-4", "--epoch", "1", "--max_steps", "4",
+                       "--local_rank", "0"] + (["--fused_step"] if fused else []))
+    run.setup_seed(12345)
+    best = run.train(args, True, 0)
+    assert 0.0 <= best <= 1.0
