@@ -1,3 +1,3 @@
 from .preprocess import read_news, read_news_bert, get_doc_input_bert, read_behaviors  # noqa: F401
-from .dataset import BuildTrainDataset, BuildEvalDataset, SequentialDistributedSampler, collate_train_batch  # noqa: F401
+from .dataset import BuildTrainDataset, BuildEvalDataset, SequentialDistributedSampler, collate_train_batch, collate_bce_batch  # noqa: F401
 from .metrics import eval_model, get_item_embeddings  # noqa: F401

@@ -46,6 +46,28 @@ def collate_train_batch(u2seq, users, item_content, max_seq_len, use_modal):
     return torch.from_numpy(ids), items, torch.from_numpy(log_mask)
 
 
+def collate_bce_batch(u2seq, users, item_content, max_seq_len, item_num, use_modal, rng):
+    """Batch of the BCE variant (``bce_text/main-end2end/data_utils/dataset.py:25-49``): per user the left-padded sequence and,
+    for every input position, one negative drawn uniformly from the items the user has not interacted with (rejection
+    sampling, as the reference does); returns (sample_items [B, S+1, 2(, 2T)], log_mask [B, S])."""
+    B, L = len(users), max_seq_len + 1
+    items = np.zeros((B, L, 2), dtype=np.int64)
+    log_mask = np.zeros((B, max_seq_len), dtype=np.float32)
+    for r, u in enumerate(users):
+        seq = u2seq[u]
+        n = len(seq)
+        items[r, L - n:, 0] = seq
+        log_mask[r, L - n:] = 1.0
+        seen = set(seq)
+        for j in range(n - 1):
+            neg = int(rng.integers(1, item_num + 1))
+            while neg in seen:
+                neg = int(rng.integers(1, item_num + 1))
+            items[r, L - n + j, 1] = neg
+    out = np.asarray(item_content)[items] if use_modal else items
+    return torch.from_numpy(np.ascontiguousarray(out)).long(), torch.from_numpy(log_mask)
+
+
 class BuildEvalDataset(Dataset):
     """``T/data_utils/dataset.py:39-65`` (inputs are pre-computed item EMBEDDINGS; label is one-hot over items)."""
 

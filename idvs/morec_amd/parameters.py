@@ -55,6 +55,9 @@ def build_parser():
     p.add_argument("--pool_negatives", action="store_true", help="pool in-batch negatives over ranks (RCCL all-gather)")
     p.add_argument("--fused_step", action="store_true",
                    help="flat-arena TrainStep (fused AdamW, one gradient all-reduce) instead of DDP + torch.optim.AdamW")
+    p.add_argument("--loss", type=str, default="inbatch", choices=["inbatch", "bce"],
+                   help="inbatch = debiased in-batch softmax CE (inbatch_sasrec_e2e_*); bce = one sampled negative per position "
+                        "(bce_text/main-end2end; drop-in autograd path only)")
     p.add_argument("--synthetic", type=int, default=0, help="N > 0: train on N synthetic MIND-shaped users (no data files)")
     p.add_argument("--synthetic_items", type=int, default=20000)
     p.add_argument("--max_steps", type=int, default=0)

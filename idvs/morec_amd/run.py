@@ -19,8 +19,8 @@ import torch.distributed as dist
 import torch.optim as optim
 from torch.nn.parallel import DistributedDataParallel as DDP
 
-from .data_utils import collate_train_batch, eval_model, get_item_embeddings, read_behaviors, read_news
-from .model import BertShape, HipBertModel, Model
+from .data_utils import collate_bce_batch, collate_train_batch, eval_model, get_item_embeddings, read_behaviors, read_news
+from .model import BceModel, BertShape, HipBertModel, Model
 from .model.swin import HipSwinForImageClassification
 from .swin_engine import SwinShape
 from .parameters import parse_args
@@ -110,7 +110,11 @@ def train(args, use_modal, local_rank):
         for index, (name, param) in enumerate(bert.named_parameters()):   # T/run.py:73-75
             if index < args.freeze_paras_before or name in pooler:
                 param.requires_grad = False
-    model = Model(args, item_num, use_modal, bert, pop).to(local_rank)
+    bce = args.loss == "bce"
+    if bce and (args.fused_step or vision):
+        raise SystemExit("--loss bce runs on the drop-in autograd path with the text / ID towers (bce_text/main-end2end)")
+    model = (BceModel(args, item_num, use_modal, bert) if bce else Model(args, item_num, use_modal, bert, pop)).to(local_rank)
+    neg_rng = np.random.default_rng(777 + rank)
     users = list(users_train.keys())
     steps_per_epoch = len(users) // (args.batch_size * world)
     if args.fused_step:
@@ -135,6 +139,19 @@ def train(args, use_modal, local_rank):
         t0, loss_acc = time.time(), None
         for b in range(steps_per_epoch):
             batch_users = [users[i] for i in order[b * args.batch_size:(b + 1) * args.batch_size]]
+            if bce:      # bce_text/main-end2end/run.py:224-237
+                items, log_mask = collate_bce_batch(users_train, batch_users, item_content, S, item_num, use_modal, neg_rng)
+                items, log_mask = items.to(local_rank), log_mask.to(local_rank)
+                items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
+                optimizer.zero_grad()
+                loss = wrapped(items, log_mask, local_rank)
+                loss.backward()
+                optimizer.step()
+                loss_acc = loss.detach() if loss_acc is None else loss_acc + loss.detach()
+                step += 1
+                if args.max_steps and step >= args.max_steps:
+                    break
+                continue
             ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
             ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
             if vision:

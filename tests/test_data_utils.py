@@ -61,3 +61,22 @@ def test_token_packing_matches_python_loop():
         ref_cu.append(ref_cu[-1] + L)
     assert cu.dtype == torch.int32 and tok.dtype == torch.int32
     assert cu.tolist() == ref_cu and tok.tolist() == ref_tok
+
+
+def test_collate_bce_batch_bookkeeping():
+    """BCE-variant batch (bce_text/main-end2end/data_utils/dataset.py:25-49): left padding, one negative per INPUT position, never
+    an item of the user's own sequence, zeros on the padding and on the last slot; log_mask has len(seq) - 1 ones."""
+    import numpy as np
+    from idvs.morec_amd.data_utils import collate_bce_batch
+    u2seq = {0: [3, 4, 5], 1: [7, 8, 9, 10, 11], 2: [2, 6, 2, 6, 9, 1]}
+    S, item_num = 5, 12
+    items, lm = collate_bce_batch(u2seq, [0, 1, 2], np.arange(item_num + 1), S, item_num, False, np.random.default_rng(3))
+    assert items.shape == (3, S + 1, 2) and lm.shape == (3, S)
+    for r, u in enumerate([0, 1, 2]):
+        seq = u2seq[u]
+        n = len(seq)
+        assert items[r, :, 0].tolist() == [0] * (S + 1 - n) + seq
+        neg = items[r, :, 1].tolist()
+        assert neg[:S + 1 - n] == [0] * (S + 1 - n) and neg[-1] == 0
+        assert all(1 <= v <= item_num and v not in seq for v in neg[S + 1 - n:-1])
+        assert lm[r].tolist() == [0.0] * (S + 1 - n) + [1.0] * (n - 1)

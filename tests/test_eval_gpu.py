@@ -78,3 +78,14 @@ def test_run_driver_vision_micro_steps(fused):
     run.setup_seed(12345)
     best = run.train(args, True, 0)
     assert 0.0 <= best <= 1.0
+
+
+def test_run_driver_bce_loss_learns():
+    """The driver with the one-negative BCE loss of bce_text/main-end2end (ID tower): runs, evaluates, loss is finite."""
+    from idvs.morec_amd import run
+    from idvs.morec_amd.parameters import parse_args
+    args = parse_args(["--synthetic", "1200", "--synthetic_items", "300", "--item_tower", "id", "--loss", "bce", "--batch_size", "64",
+                       "--embedding_dim", "64", "--lr", "3e-3", "--epoch", "2", "--compute_dtype", "fp32", "--local_rank", "0"])
+    run.setup_seed(12345)
+    best = run.train(args, False, 0)
+    assert 0.0 <= best <= 1.0
