@@ -377,13 +377,18 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     return item, saved
 
 
-def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = TE, pad_id: int = 0):
+def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = TE, pad_id: int = 0, on_ready=None):
+    """``on_ready(key)`` (optional) is called as soon as a set of gradients is final -- ``"head"`` once everything outside
+    ``bert_model`` is, ``("layer", l)`` after layer ``l`` -- so a data-parallel driver can start reducing them while the
+    rest of the backward pass still runs."""
     bm = prefix + "bert_model."
     cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx = saved
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
     linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
     dcls = ops.gemm_nt(dv, prep["fc"].wt, K=dv.shape[1], N=H)
+    if on_ready is not None:
+        on_ready("head")
     n_layers = len(prep["layers"])
     da, db = None, None
     if n_layers == 0:
@@ -409,6 +414,8 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             for i, n in enumerate(("query", "key", "value")):
                 grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
                 grads[L + f"attention.self.{n}.bias"] = dbqkv[i * H:(i + 1) * H]
+        if on_ready is not None:
+            on_ready(("layer", l))
     if tok_idx is not None:   # back to the padded layout the embedding stage (and its dropout stream) lives in: [PAD] rows get zero
         pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
         ops.indexed_rows_copy(da, pa, out_idx=tok_idx)

@@ -202,9 +202,11 @@ def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, n
     return item, saved
 
 
-def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = IN):
+def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefix: str = IN, on_ready=None):
     """grads: name -> fp32 buffer (accumulated into); q/k/v projections either as ``attention.qkv_fused.{weight,bias}`` blocks
-    (arena) or handed out as row views of a fresh fused buffer."""
+    (arena) or handed out as row views of a fresh fused buffer.  ``on_ready(("stage", s))`` (optional) is called once the
+    norm / attention / downsample gradients of stage ``s`` are final (its ``mlp.fc2.bias`` entries are not: the first block's
+    successor writes them), so a data-parallel driver can reduce them under the remaining stages."""
     sw = prefix + "swin."
     shape, n_img, saved_embed, saved_stages, saved_merges, z_last, mean_f, rstd_f, pooled, pre_c = saved
     geom = shape.stage_geometry()
@@ -266,6 +268,8 @@ def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             dout, _ = ops.layernorm_bwd(dxn, None, x, mean1, rstd1, p[L + "layernorm_before.weight"],
                                         grads[L + "layernorm_before.weight"], grads[L + "layernorm_before.bias"], dbias=prev_b2,
                                         dres=dh)
+        if on_ready is not None:
+            on_ready(("stage", s))
     patches, e, mean_e, rstd_e = saved_embed
     de, _ = ops.layernorm_bwd(dout, None, e, mean_e, rstd_e, p[sw + "embeddings.norm.weight"], grads[sw + "embeddings.norm.weight"],
                               grads[sw + "embeddings.norm.bias"], dbias=grads[sw + "embeddings.patch_embeddings.projection.bias"])

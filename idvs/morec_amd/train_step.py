@@ -6,7 +6,10 @@ no per-parameter launches and no host synchronisation inside the step.
   names containing ``bert_model`` vs the rest); ``nn.Parameter.data`` of the drop-in ``Model`` are re-pointed
   at views of it, so ``state_dict()`` / checkpoints stay reference-compatible.  Q/K/V projections are laid
   out adjacently, so the fused ``[3H, H]`` QKV weight (and its gradient) is a zero-copy view.
-* Gradients live in a matching flat fp32 arena (zeroed by one memset per step, reduced by ONE collective).
+* Gradients live in a matching flat fp32 arena (zeroed by one memset per step).  Under data parallelism the arena is
+  reduced in buckets that follow the backward pass -- everything outside the tower as soon as the tower's backward starts,
+  then one contiguous slice per encoder layer (Swin: per stage) as it completes -- issued asynchronously on RCCL's stream
+  so the ring runs under the remaining backward kernels; one sweep at the end reduces what is left (the embeddings).
 * AdamW is one kernel launch per group over the flat arena and refreshes the bf16 shadow in the same pass.
 * Data parallel (one process per GPU, RCCL): negatives pooled with an all-gather of the encoded item
   vectors, dE reduce-scattered back to the owning rank, valid-row count and gradients all-reduced (SUM);
@@ -14,6 +17,8 @@ no per-parameter launches and no host synchronisation inside the step.
 """
 from __future__ import annotations
 
+import os
+import re
 from collections import OrderedDict
 
 import torch
@@ -142,6 +147,27 @@ class TrainStep:
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
+        self.overlap_reduce = os.environ.get("MOREC_OVERLAP_REDUCE", "1") != "0"
+        self.buckets = self._bucket_plan()
+        self._pending, self._reduced = [], []
+
+    def _bucket_plan(self):
+        """Contiguous slices of the tower arena whose gradients become final together: ``("layer", l)`` for the text
+        encoder, ``("stage", s)`` for Swin (keys of the engines' ``on_ready`` callback).  Parameters outside any slice
+        (embeddings, final norm) are reduced by the closing sweep of ``reduce_gradients``."""
+        if len(self.groups) < 2:
+            return {}
+        a0 = self.groups[0]["arena"]
+        pat = re.compile(r"\.encoder\.layers\.(\d+)\." if self.vision else r"\.encoder\.layer\.(\d+)\.")
+        tag = "stage" if self.vision else "layer"
+        spans = {}
+        for n, (o, cnt, _) in a0.offsets.items():
+            mt = pat.search(n)
+            if mt:
+                lo, hi, tot = spans.get(int(mt.group(1)), (o, o, 0))
+                spans[int(mt.group(1))] = (min(lo, o), max(hi, o + _round8(cnt)), tot + _round8(cnt))
+        # a slice is only usable if nothing else sits inside it
+        return {(tag, k): (lo, hi) for k, (lo, hi, tot) in spans.items() if hi - lo == tot}
 
     # -----------------------------------------------------------------------------------------------
     def _build_views(self):
@@ -210,6 +236,7 @@ class TrainStep:
         D, S = m.args.embedding_dim, m.max_seq_len
         for grp in self.groups:
             grp["arena"].grad.zero_()
+        self._pending, self._reduced = [], []
         # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
         grads = dict(g)
         for n, t in self.frozen.items():
@@ -261,9 +288,9 @@ class TrainStep:
             ops.scatter_add_rows_(dE.contiguous(), inv32, dE_u, -1)
             dE = dE_u if self.dtype == torch.float32 else ops.cast(dE_u, self.dtype)
         if self.vision:
-            swin_engine.swin_backward(p, prep_b, saved_b, dE, grads, swin_engine.IN)
+            swin_engine.swin_backward(p, prep_b, saved_b, dE, grads, swin_engine.IN, on_ready=self._on_ready)
         elif m.use_modal:
-            engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE)
+            engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE, on_ready=self._on_ready)
         else:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
         return loss_sum[0] / n_valid
@@ -277,12 +304,41 @@ class TrainStep:
         else:
             dist.all_reduce(t)
 
+    def _reduce_slice(self, gi, lo, hi):
+        t = self.groups[gi]["arena"].grad[lo:hi]
+        if dist.get_backend() == "gloo":
+            self._all_reduce(t)
+        else:   # RCCL: enqueued behind the kernels already on this stream, runs on the communicator's own stream
+            self._pending.append(dist.all_reduce(t, async_op=True))
+        self._reduced.append((gi, lo, hi))
+
+    def _on_ready(self, key):
+        """Backward-pass callback of the engines: start reducing the gradients that have just become final."""
+        if self.world == 1 or not self.overlap_reduce:
+            return
+        if key == "head":      # the recommender group (SASRec, fc, id table) is complete once the tower's backward is under way
+            gi = len(self.groups) - 1
+            self._reduce_slice(gi, 0, self.groups[gi]["arena"].numel)
+        elif key in self.buckets:
+            self._reduce_slice(0, *self.buckets[key])
+
     def reduce_gradients(self):
-        """SUM over ranks (the 1/n_valid_global factor is already inside the loss gradient)."""
+        """SUM over ranks (the 1/n_valid_global factor is already inside the loss gradient): closes the bucketed
+        reduction started during the backward pass -- reduces every slice not yet issued, then joins the async work."""
         if self.world > 1:
-            for grp in self.groups:
-                self._all_reduce(grp["arena"].grad)
-                if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
+            for gi, grp in enumerate(self.groups):
+                done = sorted((lo, hi) for g_, lo, hi in self._reduced if g_ == gi)
+                pos = 0
+                for lo, hi in done + [(grp["arena"].numel, grp["arena"].numel)]:
+                    assert lo >= pos, "overlapping gradient buckets"
+                    if lo > pos:
+                        self._reduce_slice(gi, pos, lo)
+                    pos = hi
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
+                for grp in self.groups:
                     grp["arena"].grad.mul_(1.0 / self.world)
 
     def optimizer_step(self):
