@@ -18,13 +18,17 @@ struct GemmArgs {
     float alpha;
     int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
     int wave_epilogue;
+    float* colsum_dst;   // host side only: fp32 [N] the partial rows are folded into after the launch
+    float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
 };
 
 // ACT is a compile-time epilogue selector (0 linear, 1 GELU, 2 ReLU, 3 x GELU'(dact_in), 4 x ReLU'(dact_in)): with the
 // activation chosen at run time every unrolled accumulator block carried the erf / exp expansions and the kernel grew
 // to ~42k instructions (330 KB of code against a 64 KB instruction cache) -- the epilogue then took as long as the
 // K = 768 main loop purely on instruction fetch.
-template <typename G, typename TI, typename TO, int ACT>
+// CS: also leave the column sums of the finished tile in p.colsum (only instantiated for the activation-derivative
+// epilogues: d(bias) of the layer whose pre-activation gradient this GEMM produces).
+template <typename G, typename TI, typename TO, int ACT, bool CS = false>
 __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -76,6 +80,10 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         }
     };
 
+    // CS: column sums of the finished tile, taken from the LDS staging of the output (no extra accumulator registers per
+    // block): one partial row of p.colsum per 64-row wave block (wave epilogue) or per tile (block epilogue), each written
+    // by exactly one wave / workgroup -- the launcher folds the partial rows with one small column-sum launch.
+    float csum0 = 0.f, csum1 = 0.f;
     // Fast path: the output tile goes through LDS (free after the main loop) so that every global store is a
     // full 16-byte lane write along a row -- the direct form (8-byte pieces, 16 different rows per wave
     // instruction) is store-issue bound and cost more than the K = 768 main loop itself.
@@ -92,8 +100,16 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
+        constexpr int WCOLS = G::NI * 16, LG = 64 / WCOLS;      // the wave's columns; lane groups sharing a column
         auto flushw = [&](TO* dst, int mi) {
             wfence();
+            if constexpr (CS) {
+                if (dst == C) {
+#pragma unroll
+                    for (int r = lane / WCOLS; r < 16; r += LG)
+                        csum0 += io<TO>::load1(reinterpret_cast<const TO*>(ws + r * WROWB) + (lane % WCOLS));
+                }
+            }
 #pragma unroll
             for (int v = lane; v < 16 * VPRW; v += 64) {
                 const int lrow = v / VPRW, cv = v % VPRW;
@@ -123,6 +139,11 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
                 io<TO>::store4(reinterpret_cast<TO*>(ws + c16 * WROWB + (ni * 16 + g4 * 4) * (int)sizeof(TO)), vv[ni]);
             flushw(C, mi);
         }
+        if constexpr (CS) {
+            if constexpr (LG == 2) csum0 += __shfl_xor(csum0, 32, 64);
+            const int n = n0 + wn * WCOLS + lane;
+            if (lane < WCOLS && n < p.N) p.colsum[(size_t)(tm * G::WM + wm) * p.N + n] = csum0;
+        }
         return;
     }
     if (p.accumulate == 0 && p.vec_store) {
@@ -133,8 +154,19 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         static_assert(MIP >= 1 && G::WM * MIP * 16 * ROWB <= G::LDS_BYTES, "output staging does not fit");
         constexpr int RPP = G::WM * MIP * 16;                                 // rows per pass
         constexpr int VPR = G::TN * (int)sizeof(TO) / 16;                     // 16-byte vectors per row
+        constexpr int NCP = G::TN / 2, NRG = G::THREADS / NCP;                // column pairs; row groups of the column-sum pass
+        const int cp = threadIdx.x % NCP, rg = threadIdx.x / NCP;
         auto flush = [&](TO* dst, int pass) {          // staged rows -> global, full 16-byte lanes along each row
             __syncthreads();
+            if constexpr (CS) {
+                if (dst == C) {
+                    for (int r = rg; r < RPP; r += NRG) {
+                        const TO* q = reinterpret_cast<const TO*>(smem + r * ROWB) + cp * 2;
+                        csum0 += io<TO>::load1(q);
+                        csum1 += io<TO>::load1(q + 1);
+                    }
+                }
+            }
             for (int v = threadIdx.x; v < RPP * VPR; v += G::THREADS) {
                 const int lrow = v / VPR, cv = v % VPR;
                 const int m = m0 + (lrow / (MIP * 16)) * (G::MI * 16) + pass * MIP * 16 + (lrow % (MIP * 16));
@@ -185,6 +217,20 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
             }
             flush(C, pass);
         }
+        if constexpr (CS) {      // fold the NRG row groups through LDS (free again after the last flush's barrier)
+            static_assert(NRG * G::TN * 4 <= G::LDS_BYTES, "column-sum scratch does not fit");
+            float* red = reinterpret_cast<float*>(smem);
+            red[rg * G::TN + cp * 2] = csum0;
+            red[rg * G::TN + cp * 2 + 1] = csum1;
+            __syncthreads();
+            const int n = n0 + threadIdx.x;
+            if (threadIdx.x < G::TN && n < p.N) {
+                float t = 0.f;
+#pragma unroll
+                for (int g = 0; g < NRG; ++g) t += red[g * G::TN + threadIdx.x];
+                p.colsum[(size_t)tm * p.N + n] = t;
+            }
+        }
         return;
     }
 #pragma unroll
@@ -218,7 +264,9 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <typename G, typename TI, typename TO, int ACT>
+static int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
+
+template <typename G, typename TI, typename TO, int ACT, bool CS = false>
 static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const int split = d->split_k < 1 ? 1 : d->split_k;
     int kchunk = (d->K + split - 1) / split;
@@ -229,13 +277,17 @@ static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
     a.tiles_n = (d->N + G::TN - 1) / G::TN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO, ACT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO, ACT, CS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         attr_set = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, 1, zs);
-    hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO, ACT>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO, ACT, CS>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     MOREC_CHECK_LAUNCH();
+    if constexpr (CS) {   // fold the partial rows: [tiles_m * WM (wave epilogue) | tiles_m (block epilogue)] x N -> colsum_dst +=
+        const int rows = a.wave_epilogue ? a.tiles_m * G::WM : a.tiles_m;
+        return colsum_f32_launch(a.colsum, a.colsum_dst, rows, d->N, s);
+    }
     return MOREC_OK;
 }
 
@@ -244,9 +296,14 @@ static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->act == MOREC_ACT_GELU ? 1
                      : d->act == MOREC_ACT_RELU ? 2 : 0;
     if constexpr (sizeof(TI) != sizeof(TO)) {     // bf16 operands -> fp32 output: only the linear epilogue is used
-        if (mode != 0) return MOREC_E_UNSUPPORTED;
+        if (mode != 0 || a.colsum) return MOREC_E_UNSUPPORTED;
         return launch_gemm_act<G, TI, TO, 0>(d, a, s);
     } else {
+        if (a.colsum) {     // fused bias gradient: only behind the activation-derivative epilogues
+            if (mode == 3) return launch_gemm_act<G, TI, TO, 3, true>(d, a, s);
+            if (mode == 4) return launch_gemm_act<G, TI, TO, 4, true>(d, a, s);
+            return MOREC_E_UNSUPPORTED;
+        }
         switch (mode) {
             case 1: return launch_gemm_act<G, TI, TO, 1>(d, a, s);
             case 2: return launch_gemm_act<G, TI, TO, 2>(d, a, s);
@@ -280,7 +337,22 @@ static int launch_gemm(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
 
 extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                              void* aux_out, const void* dact_in, void* stream) {
+    return morec_gemm_nt_colsum(d, A, B, C, bias, aux_out, dact_in, nullptr, nullptr, stream);
+}
+
+extern "C" size_t morec_gemm_colsum_workspace_bytes(int M, int N) {
+    return (size_t)((M + 63) / 64) * (size_t)N * sizeof(float);      // one partial row per 64-row wave block at most
+}
+
+extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                                    void* aux_out, const void* dact_in, float* colsum_out, float* workspace, void* stream) {
     if (!d || !A || !B || !C) return MOREC_E_ARG;
+    if (colsum_out) {
+        if (!workspace) return MOREC_E_ARG;
+        if (d->dact == MOREC_ACT_NONE || d->accumulate != 0 || d->split_k > 1) return MOREC_E_UNSUPPORTED;
+        const int os_ = elt_size(d->out_dtype);
+        if ((d->N * os_) % 16 || (d->ldc * os_) % 16) return MOREC_E_UNSUPPORTED;     // needs the LDS-staged epilogues
+    }
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return MOREC_E_ARG;
     const int es = elt_size(d->in_dtype), os = elt_size(d->out_dtype);
     if (!aligned16(A) || !aligned16(B) || !aligned16(C) || (bias && !aligned16(bias))) return MOREC_E_ALIGN;
@@ -294,6 +366,8 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
+    a.colsum = colsum_out ? workspace : nullptr;
+    a.colsum_dst = colsum_out;
     {   // epilogue form: per-wave LDS slices without workgroup barriers pay off where the epilogue is heavy (GELU + the second
         // output) or the tile row is short (N <= 1024); measured per shape with scripts/gemm_bench.py.  MOREC_GEMM_EPI=w|b forces one.
         static int we = -1;
@@ -451,6 +525,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
             atomicAdd(out + c, t);
         }
     }
+}
+
+static int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s) {
+    const int rpb = 512;
+    dim3 grid((N + 63) / 64, (rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, in, out, rows, N, N, rpb);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
 }
 
 extern "C" int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream) {

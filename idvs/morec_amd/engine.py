@@ -129,9 +129,7 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
                                   dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
-    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
-    if g.get("b1") is not None:
-        ops.colsum_(du, g["b1"])
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # + d(b1)
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=x1.shape[1])
     dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,
@@ -196,9 +194,7 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
                                   dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
-    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1])
-    if g.get("b1") is not None:
-        ops.colsum_(du, g["b1"])
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # + d(b1)
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=H)
     dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,

@@ -43,9 +43,13 @@ def pad8(n: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------------
+_CS_WS = {}      # per-device fp32 scratch of the fused column sums (stream-ordered reuse, like _TN_WS)
+
+
 def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=None, dact=ACT_NONE, dact_in=None,
-            accumulate=0, split_k=1, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
-    """out[M,N] (+)= alpha * a[M,K] @ b[N,K]^T with the fused epilogues of ``morec_gemm_nt``."""
+            accumulate=0, split_k=1, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, colsum_out=None):
+    """out[M,N] (+)= alpha * a[M,K] @ b[N,K]^T with the fused epilogues of ``morec_gemm_nt``; ``colsum_out`` (fp32 [N],
+    ``dact`` epilogues only) additionally receives ``+= out.sum(0)``: the bias gradient of the layer below."""
     _dev(a), _dev(b)
     M = a.shape[0] if M is None else M
     K = a.shape[1] if K is None else K
@@ -56,6 +60,15 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
         out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     ldc = out.stride(0) if ldc is None else ldc
     d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha)
+    if colsum_out is not None:
+        need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4
+        ws = _CS_WS.get(a.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 2 * 1024 * 1024), device=a.device, dtype=torch.float32)
+            _CS_WS[a.device] = ws
+        check(_lib.lib().morec_gemm_nt_colsum(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux_out), _p(dact_in),
+                                              _p(colsum_out), _p(ws), _stream()), "morec_gemm_nt_colsum")
+        return out
     check(_lib.lib().morec_gemm_nt(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux_out), _p(dact_in), _stream()),
           "morec_gemm_nt")
     return out

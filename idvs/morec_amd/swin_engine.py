@@ -239,8 +239,8 @@ def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             desc, bias_t, x, xn, mean1, rstd1, qkv, ctx, h, hn, mean2, rstd2, pre, g, scale, tokens = saved_stages[s][b]
             # MLP branch: out = h + fc2(gelu(fc1(LN2(h)))) + b2
             linear_wgrad_(dout, g, grads[L + "mlp.fc2.weight"])
-            du = ops.gemm_nt(dout, w["f2"].wt, dact=ACT_GELU, dact_in=pre, K=dout.shape[1], N=pre.shape[1])
-            ops.colsum_(du, grads[L + "mlp.fc1.bias"])
+            du = ops.gemm_nt(dout, w["f2"].wt, dact=ACT_GELU, dact_in=pre, K=dout.shape[1], N=pre.shape[1],
+                             colsum_out=grads[L + "mlp.fc1.bias"])
             linear_wgrad_(du, hn, grads[L + "mlp.fc1.weight"])
             dhn = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=C)
             # h = x + droppath * (o_proj(ctx) + bo): dh = LN2'(dhn) + dout; da = droppath * dh

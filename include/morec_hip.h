@@ -66,6 +66,16 @@ typedef struct {
 int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                   void* aux_out, const void* dact_in, void* stream);
 
+/* Same, and colsum_out[n] += sum_m C[m, n]: with a dact epilogue C is the pre-activation gradient of the layer below, so
+ * this is that layer's bias gradient (autograd of nn.Linear: db = dY.sum(0)) without a second pass over C.  The sums are
+ * taken from the output tile while it is staged in LDS (the values as rounded to the output dtype), one partial row per
+ * 64-row block into `workspace` (morec_gemm_colsum_workspace_bytes(M, N) bytes, fp32), folded by a second small launch.
+ * colsum_out == NULL: plain morec_gemm_nt.  MOREC_E_UNSUPPORTED unless dact != NONE, accumulate == 0, split_k <= 1 and
+ * the output rows are 16-byte addressable. */
+size_t morec_gemm_colsum_workspace_bytes(int M, int N);
+int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                         void* aux_out, const void* dact_in, float* colsum_out, float* workspace, void* stream);
+
 /* Weight-gradient GEMM without transposed copies (bf16 only; MOREC_E_UNSUPPORTED otherwise):
  * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z and requires
  * accumulate != 0 (fp32 atomicAdd into a caller-zeroed C).  Autograd backward of nn.Linear: dW = dY^T X. */

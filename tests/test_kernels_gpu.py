@@ -82,6 +82,27 @@ def test_gemm_epilogues(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(260, 384, 256), (77, 96, 64), (3000, 3072, 768), (5000, 136, 96), (2100, 1536, 384)])
+def test_gemm_dact_fused_colsum(dt, shape):
+    """``morec_gemm_nt_colsum``: same C as the plain call (bit for bit), and colsum_out += C.sum(0) -- the bias gradient that
+    autograd's ``dY.sum(0)`` gives for the layer below -- on both epilogue forms (wave slices N <= 1024, block staging above),
+    ragged M / N tiles included.  Accumulates into the caller's buffer."""
+    M, N, K = shape
+    a, b = rnd(M, K, dt=dt, scale=0.2), rnd(N, K, dt=dt, scale=0.2, seed=1)
+    u = rnd(M, N, dt=dt, seed=3)
+    for act in (ACT_GELU, ACT_RELU):
+        c0 = ops.gemm_nt(a, b, dact=act, dact_in=u)
+        init = rnd(N, seed=5)
+        cs = init.clone()
+        c1 = ops.gemm_nt(a, b, dact=act, dact_in=u, colsum_out=cs)
+        assert torch.equal(c0, c1)
+        ref = init.double() + c0.double().sum(0)
+        assert float((cs.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-6 * M ** 0.5
+    with pytest.raises(RuntimeError):       # only behind an activation-derivative epilogue
+        ops.gemm_nt(a, b, colsum_out=torch.zeros(N, device=DEV))
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gemm_splitk_atomic(dt):
     M, N, K = 768, 768, 20160
     a, b = rnd(M, K, dt=dt, scale=0.1), rnd(N, K, dt=dt, scale=0.1, seed=1)
