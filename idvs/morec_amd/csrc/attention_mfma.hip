@@ -36,17 +36,38 @@ struct AttnMArgs {
 
 __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
-// stage rows [0, T) x columns [col0, col0 + DCH) of a row-major global matrix into an LDS tile (rows >= T zeroed)
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, size_t row0, int pitch, int col0, int ncols,
-                                           int Tlen, char* __restrict__ tile) {
+// No guarded loads in these kernels.  `if (row < T) v = *p;` -- and equally `ok ? *p : 0`, which the compiler turns back into a
+// branch -- makes every load its own basic block that ends in s_waitcnt vmcnt(0): the 12 tile loads, 4 fragment loads and 8
+// padding-flag loads of a wavefront then run as two dozen SERIAL memory round trips.  Instead every address is clamped to
+// the last valid row of the sequence (T >= 1 is checked at kernel entry) and the duplicate rows are left in place: a row
+// >= T is only ever multiplied by a probability / dS entry that is exactly 0 (masked key, or query row with inv = 0), and
+// rows >= T of the outputs are never stored.  Columns past the head width (dh = 32 in a 64-wide tile) are never read.
+__device__ __forceinline__ uint4 load16(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// Rows [0, T) x columns [col0, col0 + ncols) of a row-major global matrix -> registers -> LDS tile (rows >= T repeat row T - 1), in two
+// halves: ALL global loads of a kernel phase are issued before the first LDS write.  (Interleaved load / ds_write pairs are
+// kept in program order -- the generic LDS pointer may alias the source as far as the compiler knows -- and every pair then
+// costs a full memory round trip.)
+__device__ __forceinline__ void load_tile_regs(const bf16* __restrict__ src, size_t row0, int pitch, int col0, int ncols,
+                                               int Tlen, uint4 (&v)[4]) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = i * 8 + (lane >> 3), s = lane & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < Tlen && s * 8 < ncols) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * (size_t)pitch + col0 + s * 8);
-        *reinterpret_cast<uint4*>(tile + r * PITCH + s * 16) = v;
+        v[i] = load16(src + (row0 + min(r, Tlen - 1)) * (size_t)pitch + col0 + (s * 8 < ncols ? s * 8 : 0));
     }
+}
+__device__ __forceinline__ void write_tile_lds(char* __restrict__ tile, const uint4 (&v)[4]) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tile + (i * 8 + (lane >> 3)) * PITCH + (lane & 7) * 16) = v[i];
+}
+
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ src, size_t row0, int pitch, int col0, int ncols,
+                                           int Tlen, char* __restrict__ tile) {
+    uint4 v[4];
+    load_tile_regs(src, row0, pitch, col0, ncols, Tlen, v);
+    write_tile_lds(tile, v);
 }
 
 // NT fragment: 8 consecutive d of row (blk*16 + lane&15), d offset ks*32 + (lane>>4)*8
@@ -56,14 +77,13 @@ __device__ __forceinline__ bf16x8_t frag_nt(const char* tile, int blk, int ks) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// NT fragment straight from global memory (no LDS tile): 8 consecutive d of row (blk*16 + lane&15), rows >= Tlen read as zero.
+// NT fragment straight from global memory (no LDS tile): 8 consecutive d of row (blk*16 + lane&15), rows >= Tlen repeat row Tlen - 1.
 // Used for the operands that are only ever consumed d-contiguous (Q / K in the forward scores, V in the backward dP):
 // every LDS tile dropped raises the number of resident wavefronts of this latency-bound kernel.
 __device__ __forceinline__ bf16x8_t frag_nt_global(const bf16* __restrict__ src, size_t row0, int pitch, int col, int blk, int Tlen) {
     const int lane = threadIdx.x;
     const int r = blk * 16 + (lane & 15);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < Tlen) v = *reinterpret_cast<const uint4*>(src + (row0 + r) * (size_t)pitch + col + (lane >> 4) * 8);
+    const uint4 v = load16(src + (row0 + min(r, Tlen - 1)) * (size_t)pitch + col + (lane >> 4) * 8);
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
@@ -80,23 +100,61 @@ __device__ __forceinline__ bf16x8_t frag_tr(const char* tile, int pitch_bytes, i
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// Same read with the 16 columns of the block spread as 4 groups of 4: lane c receives column col0 + qstride * (c >> 2) + (c & 3).
+// With col0 = 4 * db and qstride = 4 * NB the MFMA outputs of NB consecutive blocks land d-CONTIGUOUS in a lane
+// (d = 4 NB g + 4 db + r): a row is then written as 4 lanes x 8 NB bytes (one full 128-byte line at NB = 4) instead of
+// NB separate 32-byte pieces -- the partial-line stores were what bound these kernels (writes at ~1 TB/s).
+__device__ __forceinline__ bf16x8_t frag_tr_spread(const char* tile, int pitch_bytes, int col0, int qstride) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, g = lane >> 4;
+    const char* p0 = tile + (4 * g + (c >> 2)) * pitch_bytes + (col0 + qstride * (c & 3)) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * pitch_bytes));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// store the 4 * NB consecutive d values of one row held by the lane (NB accumulator blocks, 16-byte pieces)
+template <int NB>
+__device__ __forceinline__ void store_row_d(bf16* dst, size_t row, int pitch, int col, const f32x4_t (&o)[NB]) {
+    static_assert(NB % 2 == 0, "pairs of blocks");
+    bf16* p = dst + row * (size_t)pitch + col;
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+        uint4 v;
+        v.x = pack_bf16x2(o[2 * h][0], o[2 * h][1]);
+        v.y = pack_bf16x2(o[2 * h][2], o[2 * h][3]);
+        v.z = pack_bf16x2(o[2 * h + 1][0], o[2 * h + 1][1]);
+        v.w = pack_bf16x2(o[2 * h + 1][2], o[2 * h + 1][3]);
+        *reinterpret_cast<uint4*>(p + 8 * h) = v;
+    }
+}
+
 // register fragment of a [query][key] quantity held as x[qb][kb][r]: k-slots (g, e) = keys 4g+e | 16+4g+(e-4)
 __device__ __forceinline__ bf16x8_t frag_regs(const f32x4_t (&x)[2]) {
     const uint4 v = make_uint4(pack2(x[0][0], x[0][1]), pack2(x[0][2], x[0][3]), pack2(x[1][0], x[1][1]), pack2(x[1][2], x[1][3]));
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// masked, scaled softmax (+ optional dropout mask out) of the lane's scores s[qb][kb][r]
-__device__ __forceinline__ void softmax_regs(f32x4_t (&s)[2][2], const AttnMArgs& a, const float* keep_row) {
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    float keep[2][4];
+// the lane's 8 key-padding flags (keys kb*16 + 4g + r), zero past T
+__device__ __forceinline__ void load_keep(const AttnMArgs& a, const float* keep_row, float (&keep)[2][4]) {
+    const int g = threadIdx.x >> 4;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // branch-free (clamped index, then select): a guarded load becomes its own basic block with an immediate
+            // s_waitcnt vmcnt(0) -- eight serialised memory round trips per wavefront
             const int j = kb * 16 + 4 * g + r;
-            keep[kb][r] = (j < a.T) ? keep_row[j] : 0.f;
+            const float v = keep_row[min(j, a.T - 1)];
+            keep[kb][r] = (j < a.T) ? v : 0.f;
         }
+}
+
+// masked, scaled softmax (+ optional dropout mask out) of the lane's scores s[qb][kb][r]
+__device__ __forceinline__ void softmax_regs(f32x4_t (&s)[2][2], const AttnMArgs& a, const float (&keep)[2][4]) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int i = qb * 16 + c;
@@ -146,12 +204,57 @@ __device__ __forceinline__ void drop_mask_regs(const DropRng& d, uint64_t tile, 
         }
 }
 
-// store the 4 consecutive d values of one (row, 16-col block) held by the lane
-__device__ __forceinline__ void store4d(bf16* dst, size_t row, int pitch, int col, const f32x4_t& o) {
-    uint2 v;
-    v.x = pack2(o[0], o[1]);
-    v.y = pack2(o[2], o[3]);
-    *reinterpret_cast<uint2*>(dst + row * (size_t)pitch + col) = v;
+// ctx[query][d0 .. d0 + 16 NB) = P_d V for both query blocks; every lane writes 8 NB contiguous bytes of its row
+template <int NB>
+__device__ __forceinline__ void fwd_pv(const AttnMArgs& a, const char* sV, const bf16x8_t (&pf)[2], size_t row0, int H, int col0) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t vf[NB];
+#pragma unroll
+    for (int db = 0; db < NB; ++db) vf[db] = frag_tr_spread(sV, PITCH, 4 * db, 4 * NB);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        f32x4_t o[NB];
+#pragma unroll
+        for (int db = 0; db < NB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db], pf[qb], zero, 0, 0, 0);
+        const int q = qb * 16 + c;
+        if (q < a.T) store_row_d<NB>(a.ctx, row0 + q, H, col0 + 4 * NB * g, o);
+    }
+}
+
+// dQ = dS K, dK = dS^T Q, dV = P_d^T dO for one head-width chunk of 16 NB columns (same d-contiguous output layout)
+template <int NB>
+__device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ, const char* sK, const char* sO,
+                                             const bf16x8_t (&dsf)[2], const bf16x8_t (&dsT)[2], const bf16x8_t (&pT)[2],
+                                             size_t row0, int pitch, int H, int col0) {
+    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t kt[NB], qt[NB], ot[NB];
+#pragma unroll
+    for (int db = 0; db < NB; ++db) {
+        kt[db] = frag_tr_spread(sK, PITCH, 4 * db, 4 * NB);   // K [key slots][d]
+        qt[db] = frag_tr_spread(sQ, PITCH, 4 * db, 4 * NB);   // Q [query slots][d]
+        ot[db] = frag_tr_spread(sO, PITCH, 4 * db, 4 * NB);   // dO [query slots][d]
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int r = b * 16 + c;
+        f32x4_t dq[NB], dk[NB], dv[NB];
+#pragma unroll
+        for (int db = 0; db < NB; ++db) {
+            // dQ[query r][d] = sum_key dS[r][key] K[key][d]
+            dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[db], dsf[b], zero, 0, 0, 0);
+            // dK[key r][d] = sum_query dS[query][r] Q[query][d];  dV[key r][d] = sum_query P_d[query][r] dO[query][d]
+            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[db], dsT[b], zero, 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot[db], pT[b], zero, 0, 0, 0);
+        }
+        if (r < a.T) {
+            const int dcol = col0 + 4 * NB * g;
+            store_row_d<NB>(a.dqkv, row0 + r, pitch, dcol, dq);
+            store_row_d<NB>(a.dqkv, row0 + r, pitch, H + dcol, dk);
+            store_row_d<NB>(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
@@ -161,20 +264,51 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
     const int H = a.n_heads * a.dh, pitch = 3 * H;
     const size_t row0 = a.cu ? (size_t)a.cu[seq] : (size_t)seq * a.T;
     if (a.cu) a.T = a.cu[seq + 1] - a.cu[seq];   // unpadded layout: this sequence's own length
+    if (a.T <= 0) return;                         // nothing to read or write (and the clamped loads need a valid last row)
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}};
     const int nch = (a.dh + DCH - 1) / DCH;
-    if (nch == 1) stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh, a.dh, a.T, sV);
-    for (int d = 0; d < a.dh; d += 32) {     // one MFMA k-step per 32 head columns, operands straight from global memory
-        const bf16x8_t qf[2] = {frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 1, a.T)};
-        const bf16x8_t kf[2] = {frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 1, a.T)};
+    float keep[2][4];
+    load_keep(a, a.key_keep + row0, keep);
+    if (nch == 1) {
+        // ONE memory round trip per wavefront: the V tile, the Q / K fragments of both k-steps and the padding flags are all
+        // requested before the first of them is used (a missing second k-step, dh = 32, re-reads the first and is not multiplied)
+        uint4 pv[4];
+        load_tile_regs(a.qkv, row0, pitch, 2 * H + head * a.dh, a.dh, a.T, pv);
+        bf16x8_t qf[2][2], kf[2][2];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int ks = 0; ks < 2; ++ks) {
+            const bool ok = ks * 32 < a.dh;
+            const int dcol = head * a.dh + (ok ? ks * 32 : 0);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+            for (int b = 0; b < 2; ++b) {
+                qf[ks][b] = frag_nt_global(a.qkv, row0, pitch, dcol, b, a.T);
+                kf[ks][b] = frag_nt_global(a.qkv, row0, pitch, H + dcol, b, a.T);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the whole load group ahead of the first use (the scheduler otherwise sinks the V loads)
+        write_tile_lds(sV, pv);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks * 32 < a.dh) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks][kb], qf[ks][qb], s[qb][kb], 0, 0, 0);
+            }
+        }
+    } else {
+        for (int d = 0; d < a.dh; d += 32) {     // one MFMA k-step per 32 head columns, operands straight from global memory
+            const bf16x8_t qf[2] = {frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, head * a.dh + d, 1, a.T)};
+            const bf16x8_t kf[2] = {frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 0, a.T), frag_nt_global(a.qkv, row0, pitch, H + head * a.dh + d, 1, a.T)};
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+        }
     }
     __syncthreads();
-    softmax_regs(s, a, a.key_keep + row0);
+    softmax_regs(s, a, keep);
     if (a.drop.thresh) {
         float m[2][2][4];
         drop_mask_regs(a.drop, blockIdx.x, m);
@@ -192,15 +326,8 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
             stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh + d0, nc, a.T, sV);
             __syncthreads();
         }
-        for (int db = 0; db < nc / 16; ++db) {
-            const bf16x8_t vf = frag_tr(sV, PITCH, db * 16);
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const f32x4_t o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], zero, 0, 0, 0);
-                const int q = qb * 16 + c;
-                if (q < a.T) store4d(a.ctx, row0 + q, H, head * a.dh + d0 + db * 16 + 4 * g, o);
-            }
-        }
+        if (nc == 64) fwd_pv<4>(a, sV, pf, row0, H, head * a.dh + d0);
+        else fwd_pv<2>(a, sV, pf, row0, H, head * a.dh + d0);
         if (nch > 1) __syncthreads();
     }
 }
@@ -216,11 +343,49 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
     const int H = a.n_heads * a.dh, pitch = 3 * H;
     const size_t row0 = a.cu ? (size_t)a.cu[seq] : (size_t)seq * a.T;
     if (a.cu) a.T = a.cu[seq + 1] - a.cu[seq];   // unpadded layout: this sequence's own length
+    if (a.T <= 0) return;                         // nothing to read or write (and the clamped loads need a valid last row)
     const bf16* dctx = a.ctx;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}}, dp[2][2] = {{zero, zero}, {zero, zero}};
     const int nch = (a.dh + DCH - 1) / DCH;
-    for (int ch = 0; ch < nch; ++ch) {
+    float keep[2][4];
+    load_keep(a, a.key_keep + row0, keep);
+    if (nch == 1) {
+        // ONE memory round trip: the Q / K / dO tiles, the V fragments of both k-steps and the padding flags are requested together
+        uint4 pq[4], pk[4], po[4];
+        load_tile_regs(a.qkv, row0, pitch, head * a.dh, a.dh, a.T, pq);
+        load_tile_regs(a.qkv, row0, pitch, H + head * a.dh, a.dh, a.T, pk);
+        load_tile_regs(dctx, row0, H, head * a.dh, a.dh, a.T, po);
+        bf16x8_t vf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bool ok = ks * 32 < a.dh;
+            const int vcol = 2 * H + head * a.dh + (ok ? ks * 32 : 0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) vf[ks][b] = frag_nt_global(a.qkv, row0, pitch, vcol, b, a.T);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        write_tile_lds(sQ, pq);
+        write_tile_lds(sK, pk);
+        write_tile_lds(sO, po);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks * 32 < a.dh) {
+                const bf16x8_t qf[2] = {frag_nt(sQ, 0, ks), frag_nt(sQ, 1, ks)};
+                const bf16x8_t kf[2] = {frag_nt(sK, 0, ks), frag_nt(sK, 1, ks)};
+                const bf16x8_t of[2] = {frag_nt(sO, 0, ks), frag_nt(sO, 1, ks)};
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+                        dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][kb], of[qb], dp[qb][kb], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    for (int ch = 0; nch > 1 && ch < nch; ++ch) {
         const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
         stage_tile(a.qkv, row0, pitch, head * a.dh + d0, nc, a.T, sQ);
         stage_tile(a.qkv, row0, pitch, H + head * a.dh + d0, nc, a.T, sK);
@@ -242,7 +407,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
         }
         if (nch > 1) __syncthreads();
     }
-    softmax_regs(s, a, a.key_keep + row0);
+    softmax_regs(s, a, keep);
     float msk[2][2][4];
     if (a.drop.thresh) drop_mask_regs(a.drop, blockIdx.x, msk);
 #pragma unroll
@@ -283,28 +448,11 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
             stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
             __syncthreads();
         }
-        for (int db = 0; db < nc / 16; ++db) {
-            const bf16x8_t kt = frag_tr(sK, PITCH, db * 16);   // K [key slots][d]
-            const bf16x8_t qt = frag_tr(sQ, PITCH, db * 16);   // Q [query slots][d]
-            const bf16x8_t ot = frag_tr(sO, PITCH, db * 16);   // dO [query slots][d]
-            const int dcol = head * a.dh + d0 + db * 16 + 4 * g;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int r = b * 16 + c;
-                // dQ[query r][d] = sum_key dS[r][key] K[key][d]
-                const f32x4_t dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[b], zero, 0, 0, 0);
-                // dK[key r][d] = sum_query dS[query][r] Q[query][d];  dV[key r][d] = sum_query P_d[query][r] dO[query][d]
-                const f32x4_t dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsT[b], zero, 0, 0, 0);
-                const f32x4_t dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pT[b], zero, 0, 0, 0);
-                if (r < a.T) {
-                    store4d(a.dqkv, row0 + r, pitch, dcol, dq);
-                    store4d(a.dqkv, row0 + r, pitch, H + dcol, dk);
-                    store4d(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
-                }
-            }
-        }
+        if (nc == 64) bwd_products<4>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0);
+        else bwd_products<2>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0);
     }
 }
+
 }  // namespace
 
 // returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)

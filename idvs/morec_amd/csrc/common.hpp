@@ -230,3 +230,13 @@ static inline int elt_size(int dtype) { return dtype == MOREC_BF16 ? 2 : 4; }
         hipError_t e__ = hipGetLastError();         \
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
+
+// XCD-aware workgroup -> tile mapping: the dispatcher round-robins consecutive workgroup ids over
+// the 8 XCDs (private L2 each); remap so that each XCD walks a CONTIGUOUS run of tiles, i.e. the
+// tiles that share an A row-panel hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+

@@ -64,15 +64,6 @@ __device__ __forceinline__ void mfma_step<float>(f32x4_t& acc, const uint4& fn, 
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fn.w), __uint_as_float(fm.w), acc, 0, 0, 0);
 }
 
-// XCD-aware workgroup -> tile mapping: the dispatcher round-robins consecutive workgroup ids over
-// the 8 XCDs (private L2 each); remap so that each XCD walks a CONTIGUOUS run of tiles, i.e. the
-// tiles that share an A row-panel hit the same L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
 // acc += A[m0.., kbeg:kend] . B[n0.., kbeg:kend]^T.   kbeg/kend in elements, multiples of EPV.
 //
 // Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave-instruction, no
