@@ -71,17 +71,23 @@ struct vio;
 template <>
 struct vio<float> {
     static constexpr int EV = 4;
+    // load_raw / unpack: the two halves of load, for kernels that issue every load of a row before converting any
+    __device__ __forceinline__ static uint4 load_raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ static void unpack(const uint4& v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
     __device__ __forceinline__ static void load(const float* p, float (&o)[4]) { io<float>::load4(p, o); }
     __device__ __forceinline__ static void store(float* p, const float (&o)[4]) { io<float>::store4(p, o); }
 };
 template <>
 struct vio<bf16> {
     static constexpr int EV = 8;
-    __device__ __forceinline__ static void load(const bf16* p, float (&o)[8]) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p);
+    __device__ __forceinline__ static uint4 load_raw(const bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ static void unpack(const uint4& v, float (&o)[8]) {
         o[0] = bfbits2f(v.x & 0xffffu); o[1] = bfbits2f(v.x >> 16); o[2] = bfbits2f(v.y & 0xffffu); o[3] = bfbits2f(v.y >> 16);
         o[4] = bfbits2f(v.z & 0xffffu); o[5] = bfbits2f(v.z >> 16); o[6] = bfbits2f(v.w & 0xffffu); o[7] = bfbits2f(v.w >> 16);
     }
+    __device__ __forceinline__ static void load(const bf16* p, float (&o)[8]) { unpack(load_raw(p), o); }
     __device__ __forceinline__ static void store(bf16* p, const float (&o)[8]) {
         uint4 v;
         v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // sub-layer bias gradient dbias = column sums of dzd) partials are reduced across the block's waves in LDS and leave
 // as ONE atomicAdd per column per block.
 template <typename T, int VPL, int LPR = 64, bool FULL = false>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
+__global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_kernel(const T* __restrict__ dy_a, const T* __restrict__ dy_b,
                                                      const T* __restrict__ z, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
@@ -153,7 +153,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
     }
     for (int row = r0 + wave; row < r1; row += NP) {
         const size_t base = (size_t)row * N;
+        // Every load of the row is issued before the first one is consumed, from unguarded (clamped) addresses: a load inside
+        // `if (c < N)` / `if (dy_b)` next to its use is its own basic block ending in s_waitcnt vmcnt(0), and the row then
+        // costs one memory round trip per vector per operand instead of one in total.
+        uint4 ra[VPL], rz[VPL], rb[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+            ra[i] = vio<T>::load_raw(dy_a + base + cl);
+            rz[i] = vio<T>::load_raw(z + base + cl);
+        }
+        if (dy_b) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+                rb[i] = vio<T>::load_raw(dy_b + base + cl);
+            }
+        }
         const float mu = mean[row], rs = rstd[row];
+        const float rsc = (dzd && rowscale) ? rowscale[row / rps] : 1.0f;
         float g[VPL][EV], xh[VPL][EV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -161,10 +179,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
             const int c = (i * LPR + lane) * EV;
             if (FULL || c < N) {
                 float d[EV], zz[EV];
-                vio<T>::load(dy_a + base + c, d);
+                vio<T>::unpack(ra[i], d);
                 if (dy_b) {
                     float e[EV];
-                    vio<T>::load(dy_b + base + c, e);
+                    vio<T>::unpack(rb[i], e);
 #pragma unroll
                     for (int k = 0; k < EV; ++k) d[k] += e[k];
                 }
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
 #pragma unroll
                     for (int k = 0; k < EV; ++k) d[k] = kp[k] ? d[k] : 0.f;
                 }
-                vio<T>::load(z + base + c, zz);
+                vio<T>::unpack(rz[i], zz);
 #pragma unroll
                 for (int k = 0; k < EV; ++k) {
                     xh[i][k] = (zz[k] - mu) * rs;
@@ -191,6 +209,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 for (int k = 0; k < EV; ++k) { g[i][k] = 0.f; xh[i][k] = 0.f; }
             }
         }
+        uint4 rd[VPL];
+        if (dres) {      // pre-LN blocks only; requested together, in flight during the two row reductions
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+                rd[i] = vio<T>::load_raw(dres + base + cl);
+            }
+        }
         s1 = group_sum<LPR>(s1) / (float)N;
         s2 = group_sum<LPR>(s2) / (float)N;
 #pragma unroll
@@ -202,13 +228,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy_a,
                 for (int k = 0; k < EV; ++k) o[k] = rs * (g[i][k] - s1 - xh[i][k] * s2);
                 if (dres) {   // pre-LN blocks: the residual stream's own gradient joins the LayerNorm-input gradient
                     float e[EV];
-                    vio<T>::load(dres + base + c, e);
+                    vio<T>::unpack(rd[i], e);
 #pragma unroll
                     for (int k = 0; k < EV; ++k) o[k] += e[k];
                 }
                 vio<T>::store(dz + base + c, o);
                 if (dzd) {   // gradient w.r.t. the dropped-out sub-layer output (the residual branch takes dz itself)
-                    const float rsc = rowscale ? rowscale[row / rps] : 1.0f;
 #pragma unroll
                     for (int k = 0; k < EV; ++k) o[k] *= din.inv_keep * rsc;
                     if (din.thresh) {

@@ -9,7 +9,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (M, N) in [(51000, 768), (80640, 768), (2207744, 96)]:
+for (M, N) in [(29312, 768), (51000, 768), (80640, 768), (2207744, 96), (137984, 384)]:
     dt = torch.bfloat16
     dy = torch.randn(M, N, device="cuda").to(dt); dy2 = torch.randn(M, N, device="cuda").to(dt); z = torch.randn(M, N, device="cuda").to(dt)
     mean = torch.zeros(M, device="cuda"); rstd = torch.ones(M, device="cuda"); gam = torch.ones(N, device="cuda")
