@@ -32,13 +32,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     if (row >= M) return;
     const size_t base = (size_t)row * N;
     const float rsc = rowscale ? rowscale[row / rps] : 1.0f;   // DropPath: per-sample scale of the sub-layer branch
+    // every row-sized load first, from unguarded (clamped) addresses, then the arithmetic: see the note in ln_bwd_kernel
+    uint4 rx[VPL], rr[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+        rx[i] = vio<T>::load_raw(x + base + cl);
+    }
+    if (res) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+            rr[i] = vio<T>::load_raw(res + base + cl);
+        }
+    }
     float v[VPL][EV];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * LPR + lane) * EV;
         if (FULL || c < N) {
-            vio<T>::load(x + base + c, v[i]);
+            vio<T>::unpack(rx[i], v[i]);
             if (bias) {
                 float b[EV];
                 load_f32v<EV>(bias + c, b);
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
             if (res) {
                 float r[EV];
-                vio<T>::load(res + base + c, r);
+                vio<T>::unpack(rr[i], r);
 #pragma unroll
                 for (int k = 0; k < EV; ++k) v[i][k] += r[k];
             }
