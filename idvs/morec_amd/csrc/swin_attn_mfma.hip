@@ -153,7 +153,9 @@ __device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, Bi
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        // padded query rows (token >= NT) get probability 0 everywhere: their q / dO fragments are unguarded re-reads of token
+        // 0's rows (see the load note in the kernels), and a zero P row keeps them out of dS, dK, dV and dbias
+        const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -205,16 +207,20 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
-        uint4 qf[4], kf[4];
+        // No guarded loads: `valid ? *p : 0` compiles to one basic block per load (each ending in a full s_waitcnt) and a load
+        // next to an LDS store stays in program order.  Padded tokens re-read token 0's rows (G.row is clamped); a padded key has
+        // bias -inf (probability exactly 0), a padded query row is zeroed in softmax_rows and never stored.  All twelve loads of
+        // the window are issued before the first LDS write.
+        uint4 qf[4], kf[4], vf[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
-            const uint4 z = make_uint4(0, 0, 0, 0);
-            qf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base) : z;
-            kf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + C) : z;
-            const uint4 vf = G.valid[k] ? *reinterpret_cast<const uint4*>(base + 2 * C) : z;
-            *reinterpret_cast<uint4*>(sV + (c + 16 * k) * TROW + 16 * g4) = vf;
+            qf[k] = *reinterpret_cast<const uint4*>(base);
+            kf[k] = *reinterpret_cast<const uint4*>(base + C);
+            vf[k] = *reinterpret_cast<const uint4*>(base + 2 * C);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sV + (c + 16 * k) * TROW + 16 * g4) = vf[k];
         f32x4_t s[4][4];
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -277,17 +283,17 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
     const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
-        const uint4 z = make_uint4(0, 0, 0, 0);
         f32x4_t s[4][4], dp[4][4];
-        {
+        {   // unguarded loads (padded tokens re-read token 0's rows, see the forward kernel), all issued before the LDS writes
             uint4 qf[4], kf[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
-                qf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base) : z;
-                kf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(base + C) : z;
-                *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = kf[k];
+                qf[k] = *reinterpret_cast<const uint4*>(base);
+                kf[k] = *reinterpret_cast<const uint4*>(base + C);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = kf[k];
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -298,20 +304,21 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
             uint4 vf[4], of[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                vf[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + 2 * C + head * DH + 8 * g4) : z;
-                of[k] = G.valid[k] ? *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4) : z;
-                *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
+                vf[k] = *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + 2 * C + head * DH + 8 * g4);
+                of[k] = *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) dp[tj][ti] = mfma(vf[tj], of[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
         }
-        // padded query rows (i >= NT) read the last real row: their probabilities stay finite and are never stored
+        // padded query rows (i >= NT) read the last real bias row; softmax_rows zeroes their probabilities
         softmax_rows(s, a.scale, [&](int tj, int ti) {
             return *reinterpret_cast<const f32x4_t*>(sBias + min(16 * ti + c, NT - 1) * BP + 16 * tj + 4 * g4);
         }, G, mb);
-        // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys (P = 0) and padded queries (dO = 0).
+        // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys and padded queries (P = 0 on both).
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             float delta = 0.f;
@@ -396,10 +403,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
         }
         wave_lds_fence();
         // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]
+        {
+            uint4 qk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint4 qk = G.valid[k] ? *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4) : z;
-            *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qk;
+            for (int k = 0; k < 4; ++k) qk[k] = *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qk[k];
         }
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
