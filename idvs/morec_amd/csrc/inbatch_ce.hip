@@ -50,9 +50,22 @@ __device__ __forceinline__ void masked_logits(const CeArgs& p, int m0, int n0, c
     const int nu = u_hi - u_lo + 1;
     int32_t* s_cid = s_uid + ((nu * S1 + 3) & ~3);                           // [128]
     uint8_t* s_mem = reinterpret_cast<uint8_t*>(s_cid + 128);               // [nu][128]
+    // the tile's 128 columns' log-popularity and validity, staged once (coalesced) instead of two guarded global loads
+    // per logit element -- 128 dependent L2 round trips per lane, most of this kernel's time at these sizes
+    float* s_lp = reinterpret_cast<float*>(s_mem + ((nu * 128 + 15) & ~15));   // [128]
+    uint8_t* s_cv = reinterpret_cast<uint8_t*>(s_lp + 128);                   // [128]
     const int tid = threadIdx.x;
     for (int i = tid; i < nu * S1; i += 256) s_uid[i] = p.row_ids[u_lo * S1 + i];
-    if (tid < 128) s_cid[tid] = (n0 + tid < p.Nc) ? p.col_ids[n0 + tid] : -1;
+    if (tid < 128) {
+        const int c = min(n0 + tid, p.Nc - 1);          // clamped: the three loads need no guard
+        const bool in = n0 + tid < p.Nc;
+        const int32_t id = p.col_ids[c];
+        const float lp = p.col_logpop[c];
+        const uint8_t cv = p.col_valid[c];
+        s_cid[tid] = in ? id : -1;
+        s_lp[tid] = in ? lp : 0.f;
+        s_cv[tid] = in ? cv : 0;
+    }
     __syncthreads();
     for (int i = tid; i < nu * 128; i += 256) {
         const int u = i >> 7, c = i & 127;
@@ -73,13 +86,16 @@ __device__ __forceinline__ void masked_logits(const CeArgs& p, int m0, int n0, c
         for (int ni = 0; ni < 4; ++ni) {
             const int n = acc_col(n0, ni);
             const uint32_t mem4 = *reinterpret_cast<const uint32_t*>(s_mem + (u - u_lo) * 128 + (n - n0));
+            const uint32_t cv4 = *reinterpret_cast<const uint32_t*>(s_cv + (n - n0));
+            const float4 lp4 = *reinterpret_cast<const float4*>(s_lp + (n - n0));
+            const float lpr[4] = {lp4.x, lp4.y, lp4.z, lp4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = n + r;
                 float v = -INFINITY;   // columns past the pool do not exist
                 if (c < p.Nc) {
                     const bool rejected = ((mem4 >> (8 * r)) & 1u) && (c != lab[mi]);
-                    v = (p.col_valid[c] == 0 || rejected) ? MASKED_LOGIT : acc[mi][ni][r] - p.col_logpop[c];
+                    v = (((cv4 >> (8 * r)) & 0xffu) == 0 || rejected) ? MASKED_LOGIT : acc[mi][ni][r] - lpr[r];
                 }
                 acc[mi][ni][r] = v;
             }
