@@ -231,7 +231,9 @@ class TrainStep:
 
     # -----------------------------------------------------------------------------------------------
     def forward_backward(self, sample_items_id, sample_items, log_mask):
-        """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync)."""
+        """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync).  Under data
+        parallelism the bucketed gradient reduction is STARTED here (async collectives issued from the backward pass);
+        ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
         for grp in self.groups:
