@@ -3,24 +3,8 @@
 // Reference arithmetic replaced: see include/morec_hip.h (morec_gemm_nt).
 #include <stdlib.h>
 #include "gemm_core.hpp"
+#include "gemm_args.hpp"
 
-struct GemmArgs {
-    const void* A;
-    const void* B;
-    void* C;
-    const float* bias;
-    void* aux_out;
-    const void* dact_in;
-    int M, N, K, lda, ldb, ldc;
-    int act, dact, accumulate;
-    int kchunk;
-    int tiles_m, tiles_n;
-    float alpha;
-    int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
-    int wave_epilogue;
-    float* colsum_dst;   // host side only: fp32 [N] the partial rows are folded into after the launch
-    float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
-};
 
 // ACT is a compile-time epilogue selector (0 linear, 1 GELU, 2 ReLU, 3 x GELU'(dact_in), 4 x ReLU'(dact_in)): with the
 // activation chosen at run time every unrolled accumulator block carried the erf / exp expansions and the kernel grew
@@ -264,7 +248,6 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-static int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
 
 template <typename G, typename TI, typename TO, int ACT, bool CS = false>
 static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
@@ -376,6 +359,10 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
     }
     a.vec_store = ((d->N * os) % 16 == 0) && ((d->ldc * os) % 16 == 0) && (!aux_out || aligned16(aux_out));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    {   // bf16, large: the 256 x 256 eight-phase kernel (gemm8p.hip)
+        const int r8 = gemm8p_try_launch(d, a, s);
+        if (r8 != G8_NOT_TAKEN) return r8;
+    }
     if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float>(d, a, s);
     if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16>(d, a, s);
     if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_F32) return launch_gemm<bf16, float>(d, a, s);
@@ -527,7 +514,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
     }
 }
 
-static int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s) {
+int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s) {
     const int rpb = 512;
     dim3 grid((N + 63) / 64, (rows + rpb - 1) / rpb);
     hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, in, out, rows, N, N, rpb);

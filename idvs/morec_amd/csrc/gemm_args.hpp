@@ -1,0 +1,28 @@
+// gemm_args.hpp -- kernel argument block shared by the NT GEMM kernels (gemm.hip: two-buffer main loop;
+// gemm8p.hip: the 256 x 256 eight-phase main loop).
+#pragma once
+#include "common.hpp"
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;
+    void* aux_out;
+    const void* dact_in;
+    int M, N, K, lda, ldb, ldc;
+    int act, dact, accumulate;
+    int kchunk;
+    int tiles_m, tiles_n;
+    float alpha;
+    int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
+    int wave_epilogue;
+    float* colsum_dst;   // host side only: fp32 [N] the partial rows are folded into after the launch
+    float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
+};
+
+// gemm8p.hip: runs the launch on the eight-phase kernel when the problem is eligible (returns MOREC_OK / an error) or
+// reports "not eligible" with G8_NOT_TAKEN so that the caller falls through to the generic kernels.
+#define G8_NOT_TAKEN 0x7fff0001
+int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);
+int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);

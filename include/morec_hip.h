@@ -43,6 +43,10 @@ extern "C" {
 
 const char* morec_strerror(int code);
 int morec_version(void);
+/* Process-wide kernel-selection knobs (measurement / A-B aid, no arithmetic meaning: every selectable kernel computes the same
+ * function).  key "gemm8p": 0 = automatic, 1 = never use the 256 x 256 eight-phase GEMM, 2 = use it wherever it is eligible.
+ * Returns MOREC_E_UNSUPPORTED for an unknown key.  No reference counterpart (the reference has no kernels). */
+int morec_tuning_set(const char* key, int value);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T  (both operands K-contiguous, "NT")
