@@ -30,6 +30,7 @@
 
 namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr int TM = 256, TN = 256, KE = 64;      // tile; K elements per K-tile
 constexpr int KB = 128;                          // bytes of K per row per K-tile
@@ -83,14 +84,18 @@ __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4
 
 // vmcnt left in flight after a phase's issue: 8 in the steady state (the refills of the last four phases); the last two
 // K-tiles issue fewer, so fewer may be left.  REM = K-tiles after this one, capped at 2 (compile time: no branches in the loop).
-template <int REM, int W1, int W0>
+// SLACK: VMEM operations YOUNGER than the tile's prologue and OLDER than its in-loop refills that may also stay in flight -- the
+// global stores of the previous tile's epilogue.  Vector memory operations complete in execution order, so "at most 8 + SLACK
+// outstanding" still means "everything up to the 8 newest refills has landed" as long as SLACK does not exceed their number.
+template <int REM, int W1, int W0, int SLACK = 0>
 __device__ __forceinline__ void vm_wait_tail() {
-    vm_wait<(REM >= 2 ? 8 : (REM == 1 ? W1 : W0))>();
+    vm_wait<(REM >= 2 ? 8 + SLACK : (REM == 1 ? W1 : W0))>();
 }
 
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
-template <int REM>
+template <int REM, int SLACK = 0>
 __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2]) {
+    static_assert(SLACK == 0 || REM == 2, "slack only on a steady K-tile");
     char* cur = smem + cb;
     char* oth = smem + (cb ^ BUF_BYTES);
     uint4 fa[2][4], fb0[4], fb1[4];
@@ -109,7 +114,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
     if constexpr (REM >= 1) dma2(c.rb, c.b2[0], c.b2[1], kb + KB, oth + OP_BYTES + c.dB2);
     pin();
-    vm_wait_tail<REM, 8, 2>();
+    vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
     mfma_quadrant<0, 0>(acc, fa, fb0);
     bar();
@@ -118,7 +123,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     for (int ks = 0; ks < 4; ++ks) fb1[ks] = lds16(smem + adb[ks] + 32 * KB);
     if constexpr (REM >= 1) dma2(c.ra, c.a2[0], c.a2[1], kb + KB, oth + c.dA2);
     pin();
-    vm_wait_tail<REM, 8, 0>();
+    vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
     mfma_quadrant<0, 1>(acc, fa, fb1);
     bar();
@@ -129,53 +134,54 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + (64 + mi * 32) * KB);
     if constexpr (REM >= 2) dma2(c.ra, c.a1[0], c.a1[1], kb + 2 * KB, cur + c.dA1);
     pin();
-    vm_wait_tail<REM, 6, 0>();
+    vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
     mfma_quadrant<2, 1>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2(c.rb, c.b1[0], c.b1[1], kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
-    vm_wait_tail<REM, 4, 0>();
+    vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
     mfma_quadrant<2, 0>(acc, fa, fb0);
     bar();
 }
 
-// acc += A[m0 .. m0+255, :] . B[n0 .. n0+255, :]^T over K (K % 64 == 0, K >= 128).  Rows past M / N are clamped to the last valid
-// row (their products land in accumulator rows / columns that are never stored).  On return every DMA has landed and
-// every wave has passed the last barrier: LDS is free.
-__device__ __forceinline__ void mainloop8p(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda, int ldb,
-                                           int m0, int n0, char* smem, f32x16_t (&acc)[4][2]) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// ---- DMA / fragment context of one tile.  At, Bt = first row of the tile's A / B panel; rows_a, rows_b = rows that exist from
+// there on (M - m0, N - n0; rows past them are clamped to the last valid one).  `tid` is an opaque copy of threadIdx.x: the
+// context is recomputed per tile (a few dozen integer ops) instead of being kept alive across the epilogue.
+__device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const bf16* Bt, int rows_a, int rows_b, int lda, int ldb) {
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = K / KE;
-    Ctx c;
-    {   // DMA geometry: piece j of a half-tile = 8 rows; lane -> row (lane >> 3) of the piece, physical slot lane & 7
-        const int ra = wr * 128 + wc * 16;                       // this wave's 16 rows of A-first (A-second: + 64)
-        const int rb = (wave >> 1) * 64 + (wave & 1) * 16;       // this wave's 16 rows of B-first (B-second: + 32)
+    // DMA geometry: piece j of a half-tile = 8 rows; lane -> row (lane >> 3) of the piece, physical slot lane & 7
+    const int ra = wr * 128 + wc * 16;                       // this wave's 16 rows of A-first (A-second: + 64)
+    const int rb = (wave >> 1) * 64 + (wave & 1) * 16;       // this wave's 16 rows of B-first (B-second: + 32)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rl = j * 8 + (lane >> 3);
-            const int slot = (lane & 7) ^ ((rl >> 1) & 7);       // (row >> 1) & 7 with row = 16-aligned base + rl
-            c.a1[j] = (uint32_t)min(ra + rl, M - 1 - m0) * (uint32_t)(lda * 2) + slot * 16;
-            c.a2[j] = (uint32_t)min(ra + 64 + rl, M - 1 - m0) * (uint32_t)(lda * 2) + slot * 16;
-            c.b1[j] = (uint32_t)min(rb + rl, N - 1 - n0) * (uint32_t)(ldb * 2) + slot * 16;
-            c.b2[j] = (uint32_t)min(rb + 32 + rl, N - 1 - n0) * (uint32_t)(ldb * 2) + slot * 16;
-        }
-        // descriptors: raw (stride 0), extent = the rows of this tile that exist (every offset above stays inside it)
-        const long abytes = (long)min(256, M - m0) * lda * 2, bbytes = (long)min(256, N - n0) * ldb * 2;
-        c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, (int)min(abytes, 0x7fffffffL), 0x00020000);
-        c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * ldb), 0, (int)min(bbytes, 0x7fffffffL), 0x00020000);
-        c.dA1 = ra * KB; c.dA2 = (ra + 64) * KB; c.dB1 = rb * KB; c.dB2 = (rb + 32) * KB;
-        c.aoff = wr * 128 * KB;
-        c.boff = wc * 64 * KB;
-        const int r5 = lane & 31, fr = (r5 >> 1) & 7;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) c.loff[ks] = r5 * KB + (((2 * ks + (lane >> 5)) ^ fr) << 4);
+    for (int j = 0; j < 2; ++j) {
+        const int rl = j * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((rl >> 1) & 7);       // (row >> 1) & 7 with row = 16-aligned base + rl
+        c.a1[j] = (uint32_t)min(ra + rl, rows_a - 1) * (uint32_t)(lda * 2) + slot * 16;
+        c.a2[j] = (uint32_t)min(ra + 64 + rl, rows_a - 1) * (uint32_t)(lda * 2) + slot * 16;
+        c.b1[j] = (uint32_t)min(rb + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
+        c.b2[j] = (uint32_t)min(rb + 32 + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
     }
-    // prologue: K-tile 0 entirely, the first halves of K-tile 1
+    // descriptors: raw (stride 0), extent = the rows of this tile that exist (every offset above stays inside it)
+    const long abytes = (long)min(256, rows_a) * lda * 2, bbytes = (long)min(256, rows_b) * ldb * 2;
+    c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)At, 0, (int)min(abytes, 0x7fffffffL), 0x00020000);
+    c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, 0, (int)min(bbytes, 0x7fffffffL), 0x00020000);
+    c.dA1 = ra * KB; c.dA2 = (ra + 64) * KB; c.dB1 = rb * KB; c.dB2 = (rb + 32) * KB;
+    c.aoff = wr * 128 * KB;
+    c.boff = wc * 64 * KB;
+    const int r5 = lane & 31, fr = (r5 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) c.loff[ks] = r5 * KB + (((2 * ks + (lane >> 5)) ^ fr) << 4);
+}
+
+// Prologue of a tile: K-tile 0 entirely, the first halves of K-tile 1 (12 LDS-DMA instructions per lane).  LDS must be free
+// of readers: called before the first tile and, for the NEXT tile, right after a main loop (every wave is past its last barrier)
+// -- i.e. ahead of the finished tile's epilogue, whose slices live outside the two K-tile buffers.
+__device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem) {
     dma2(c.ra, c.a1[0], c.a1[1], 0, smem + c.dA1);
     dma2(c.rb, c.b1[0], c.b1[1], 0, smem + OP_BYTES + c.dB1);
     dma2(c.rb, c.b2[0], c.b2[1], 0, smem + OP_BYTES + c.dB2);
@@ -183,169 +189,339 @@ __device__ __forceinline__ void mainloop8p(const bf16* __restrict__ A, const bf1
     dma2(c.ra, c.a1[0], c.a1[1], KB, smem + BUF_BYTES + c.dA1);
     dma2(c.rb, c.b1[0], c.b1[1], KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
     pin();
-    vm_wait<8>();            // A-first, B-first of K-tile 0 (this wave's pieces)
+}
+
+// acc += A-panel . B-panel^T over K (K % 64 == 0, K >= 128), prologue already issued.  On return every DMA of this tile has
+// landed and every wave has passed the last barrier: the K-tile buffers are free.
+// The first wait is `vmcnt(8)` whatever else the wave has in flight: it bounds the number of PENDING loads by 8, and loads
+// retire in order among themselves, so the four oldest prologue pieces have landed even with younger stores outstanding.
+#define G8_MSTAMP(i)                                                                    \
+    do {                                                                                \
+        if (st && threadIdx.x == 0) st[(i)] = __builtin_readcyclecounter();              \
+    } while (0)
+template <int SLACK>
+__device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char* smem, f32x16_t (&acc)[4][2], unsigned long long* st) {
+    G8_MSTAMP(8);
+    vm_wait<8 + SLACK>();    // A-first, B-first of K-tile 0 (this wave's pieces)
+    G8_MSTAMP(9);
     bar();                   // ... everybody's
     if (wr == 1) bar();      // waves 4-7 run one barrier behind waves 0-3 from here on
-
+    G8_MSTAMP(10);
     int cb = 0;
     int t = 0;
+    if (SLACK > 0 && nk >= 3) {     // the previous epilogue's stores drain under the first K-tile instead of in front of it
+        ktile<2, SLACK>(smem, c, cb, 0, acc);
+        cb ^= BUF_BYTES;
+        t = 1;
+    }
+    G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
         ktile<2>(smem, c, cb, t * KB, acc);
         cb ^= BUF_BYTES;
+        if (t == 1) G8_MSTAMP(12);
     }
+    G8_MSTAMP(13);
     ktile<1>(smem, c, cb, t * KB, acc);
     ktile<0>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
+    G8_MSTAMP(14);
     if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
+    G8_MSTAMP(15);
+}
+// `younger`: VMEM operations this wave has issued since the tile's prologue (only a LOWER bound matters: see vm_wait_tail)
+__device__ __forceinline__ void mainloop8p(const Ctx& c, int wr, int nk, int younger, char* smem, f32x16_t (&acc)[4][2],
+                                           unsigned long long* st) {
+    if (younger >= 32) mainloop8p_s<32>(c, wr, nk, smem, acc, st);
+    else if (younger >= 16) mainloop8p_s<16>(c, wr, nk, smem, acc, st);
+    else mainloop8p_s<0>(c, wr, nk, smem, acc, st);
 }
 
 // -----------------------------------------------------------------------------------------------------------------------
+// Persistent kernel: workgroup b walks the tiles b, b + gridDim.x, ... (gridDim.x = one workgroup per CU); the prologue DMA of
+// the next tile is issued BEFORE the epilogue of the finished one, so the first fill of the pipeline (7.4 k cycles when it
+// was exposed: profiles/r02_gemm8p_stamps.txt), the workgroup turnover and most of the store drain overlap the epilogue.
+//
 // Epilogue: wave-private.  acc[Mi][Ni][4 g + r] = C[m0 + wr*128 + Mi*32 + (lane & 31)][n0 + wc*64 + Ni*32 + 8 g + 4 (lane >> 5) + r].
-// Every 32 x 64 block goes through the wave's own LDS slice so that all global traffic (the stores, and the loads of the
-// activation-derivative operand) is 16-byte lanes along rows: full 128-byte lines per row per instruction.
+// Every 32-row block goes through the wave's own 4-KiB LDS slice ([32 rows][128 B], 16-byte slots XOR-swizzled with row & 7;
+// above the K-tile buffers) so that all global traffic (the stores, and the loads of the activation-derivative operand) is
+// 16-byte lanes along rows: full 128-byte lines per row per instruction.  128 B = 64 bf16 columns (one pass per block) or
+// 32 fp32 columns (two passes).
+//
+// tile_body's four panel pointers are `__restrict__` for the sake of hipcc's s_waitcnt insertion, not of the optimiser: inlining
+// a function with noalias arguments tags the LDS-DMA instructions (based on the panels) with alias scopes and every other LDS
+// access with "does not alias them".  Without the tags the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read that
+// follows an LDS-DMA -- a full drain of the DMA queue three times per K-tile.  (Nothing is written through the panels, so
+// overlapping A / B tiles behind different restrict pointers are fine.)  The hand-counted vmcnt waits + barriers order the
+// DMA data for the reads.
 // -----------------------------------------------------------------------------------------------------------------------
+constexpr int SLICE = 4096;
+constexpr int LDS_TOTAL = LDS_BYTES + 8 * SLICE;       // 160 KiB: the whole LDS of a CU
+
+#define G8_STAMPW(i, w)                                                                                  \
+    do {                                                                                                 \
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(w) * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+
+struct TileXY {
+    int wg, m0, n0;
+};
+
 template <typename TO, int ACT, bool CS>
-__global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tm = wg / p.tiles_n, tn = wg % p.tiles_n;
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    mainloop8p(reinterpret_cast<const bf16*>(p.A), reinterpret_cast<const bf16*>(p.B), p.M, p.N, p.K, p.lda, p.ldb, m0, n0, smem, acc);
-
+__device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk, const bf16* __restrict__ Acur, const bf16* __restrict__ Bcur,
+                                          const bf16* __restrict__ Anext, const bf16* __restrict__ Bnext, const TileXY cur, const TileXY nxt,
+                                          const bool first) {
     constexpr int ES = (int)sizeof(TO);
     constexpr int EPV = 16 / ES;                 // elements per 16-byte vector
-    constexpr int PITCH = 64 * ES + 16;          // LDS pitch of a staged 64-column row
-    constexpr int SLICE = 32 * PITCH;
-    constexpr int VPR = 64 * ES / 16;            // 16-byte vectors per row: 8 (bf16) / 16 (f32)
-    constexpr int NV = 32 * VPR / 64;            // vectors per lane per block: 4 / 8
-    static_assert(8 * SLICE <= LDS_BYTES, "wave slices do not fit");
-    const int lane = threadIdx.x & 63, r5 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PC = 128 / ES;                 // columns per pass: 64 (bf16) / 32 (f32)
+    constexpr int NPASS = 64 / PC;               // passes per 32-row block: 1 / 2
+    constexpr int NG = PC / 8;                   // 4-element accumulator groups of this lane per pass: 8 / 4
+    struct Vecs { u32x4_t q[4]; };
+    const int m0 = cur.m0, n0 = cur.n0;
+    G8_STAMPW(0, cur.wg);
+    f32x16_t acc[4][2];
+    {
+        int tid_m = threadIdx.x;
+        asm volatile("" : "+v"(tid_m));
+        Ctx c;
+        make_ctx(c, tid_m, Acur, Bcur, p.M - m0, p.N - n0, p.lda, p.ldb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        if (first) issue_prologue(c, smem);      // later tiles: issued by the previous tile's body, ahead of its epilogue
+        // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
+        constexpr int NST = 16 * (int)sizeof(TO) / 2;
+        const int younger = (first || (p.debug & 3) || (p.debug & 64)) ? 0 : (p.aux_out ? 2 * NST : NST);
+        mainloop8p(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
+    }
+    G8_STAMPW(1, cur.wg);
+    // ---- this tile's epilogue state.  Lane constants come from an OPAQUE copy of the thread id so that they are recomputed
+    // here (a dozen integer ops) instead of being kept alive -- i.e. spilled -- across the main loop.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane = tid_e & 63, r5 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    char* ws = smem + wave * SLICE;
+    char* ws = smem + LDS_BYTES + wave * SLICE;
     TO* C = reinterpret_cast<TO*>(p.C);
     TO* aux = reinterpret_cast<TO*>(p.aux_out);
     const TO* din = reinterpret_cast<const TO*>(p.dact_in);
-    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
     auto wfence = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // row-wise (coalesced) side of the slice: vector i of this lane = row (lane + 64 i) / VPR, 16-byte column (lane + 64 i) % VPR
-    auto rows_store = [&](TO* dst, int Mi) {
+    // row side of the slice: vector i of this lane = row (lane >> 3) + 8 i, 16-byte slot lane & 7
+    const int rs_row = lane >> 3, rs_slot = lane & 7;
+    const int rs_off = rs_row * 128 + ((rs_slot ^ (rs_row & 7)) << 4);    // + i * 1024 (row + 8 keeps row & 7)
+    // accumulator side: group q of a pass = columns 8 q + 4 h .. + 3 of the pass (bf16: 8 bytes, slot q; f32: 16 bytes, slot 2 q + h)
+    auto cell = [&](int q) {
+        const int slot = ES == 2 ? q : 2 * q + h;
+        return reinterpret_cast<TO*>(ws + r5 * 128 + ((slot ^ (r5 & 7)) << 4) + (ES == 2 ? 8 * h : 0));
+    };
+    const int cur_tm = m0 / TM;
+    const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    // Row side of the global traffic through buffer descriptors based at the tile's first row: ONE per-lane offset register
+    // for every access of the tile (+ a wave-uniform term), and the hardware range check drops rows >= M (the extent is
+    // the tile's valid rows); lanes whose 16-byte column lies past N carry an out-of-range offset instead of a branch.
+    const long tile_bytes = (long)min(256, p.M - m0) * p.ldc * ES;
+    const int ext = (int)min(tile_bytes, 0x7fffffffL);
+    const size_t tile_off = (size_t)m0 * p.ldc;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(C + tile_off), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(((ACT == 3 || ACT == 4) ? din : C) + tile_off), 0, ext, 0x00020000);
+    auto lane_off = [&](int ps) {    // byte offset of (row rs_row, this lane's column of pass ps) from (tile row 0, column 0)
+        const int n = nw + ps * PC + rs_slot * EPV;
+        return n < p.N ? (uint32_t)((rs_row * p.ldc + n) * ES) : 0x80000000u;
+    };
+    auto row_term = [&](int Mi, int i) { return (uint32_t)((wr * 128 + Mi * 32 + 8 * i) * p.ldc * ES); };   // wave-uniform
+    auto rows_store = [&](const __amdgpu_buffer_rsrc_t& rs, int Mi, uint32_t lo) {
+        u32x4_t q[4];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = lane + 64 * i, row = v / VPR, cv = v % VPR;
-            const int m = mw + Mi * 32 + row, n = nw + cv * EPV;
-            const uint4 q = *reinterpret_cast<const uint4*>(ws + row * PITCH + cv * 16);
-            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(dst + (size_t)m * p.ldc + n) = q;
+        for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const u32x4_t*>(ws + rs_off + i * 1024);
+        if (!(p.debug & 1)) {
+            const int cp = (p.debug >> 4) & 3;      // experiment: cache policy of the output stores
+            if (cp == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rs, lo + row_term(Mi, i), 0, 0);
+            } else if (cp == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rs, lo + row_term(Mi, i), 0, 2);
+            } else if (cp == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rs, lo + row_term(Mi, i), 0, 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rs, lo + row_term(Mi, i), 0, 18);
+            }
         }
     };
-    struct Vecs { uint4 q[NV]; };
-    auto rows_fetch = [&](const TO* src, int Mi) {     // clamped, unguarded: one memory round trip
+    auto rows_fetch = [&](const __amdgpu_buffer_rsrc_t& rs, int Mi, uint32_t lo) {     // rows >= M / columns >= N read as zero
         Vecs r;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = lane + 64 * i, row = v / VPR, cv = v % VPR;
-            const int m = min(mw + Mi * 32 + row, p.M - 1), n = min(nw + cv * EPV, p.N - EPV);
-            r.q[i] = *reinterpret_cast<const uint4*>(src + (size_t)m * p.ldc + n);
-        }
+        for (int i = 0; i < 4; ++i) r.q[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, lo + row_term(Mi, i), 0, 0);
         return r;
     };
     auto rows_put = [&](const Vecs r) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = lane + 64 * i, row = v / VPR, cv = v % VPR;
-            *reinterpret_cast<uint4*>(ws + row * PITCH + cv * 16) = r.q[i];
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(ws + rs_off + i * 1024) = r.q[i];
     };
-    // accumulator side of the slice: this lane's 4-element group (Ni, g)
-    auto cell = [&](int Ni, int g) { return reinterpret_cast<TO*>(ws + r5 * PITCH + (Ni * 32 + g * 8 + 4 * h) * ES); };
+    uint32_t lo[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) lo[ps] = lane_off(ps);
 
-    float csum = 0.f;
-    Vecs dq0, dq1, dq2, dq3;   // the activation-derivative operand of the four 32-row blocks (fetched one block ahead)
-    if constexpr (ACT == 3 || ACT == 4) dq0 = rows_fetch(din, 0);
-#pragma unroll
-    for (int Mi = 0; Mi < 4; ++Mi) {
-        const bool row_ok = (mw + Mi * 32 + r5) < p.M;
-        float u[2][4][4];
-        if constexpr (ACT == 3 || ACT == 4) {
-            rows_put(Mi == 0 ? dq0 : Mi == 1 ? dq1 : Mi == 2 ? dq2 : dq3);
-            if (Mi == 0) dq1 = rows_fetch(din, 1);
-            if (Mi == 1) dq2 = rows_fetch(din, 2);
-            if (Mi == 2) dq3 = rows_fetch(din, 3);
-            wfence();
-#pragma unroll
-            for (int Ni = 0; Ni < 2; ++Ni)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) io<TO>::load4(cell(Ni, g), u[Ni][g]);
-            wfence();
-        }
-        float vv[2][4][4];
+    // ---- loads the epilogue starts with go out AHEAD of the next tile's prologue: the counter a wave waits on retires in
+    // order, so a load issued behind the twelve LDS-DMA pieces could only be waited for together with them.
+    // Bias of this lane's 8 column groups: fetched once per tile, branch-free (a guarded load inside the block loop compiles
+    // to its own basic block ending in s_waitcnt vmcnt(0): a dependent memory round trip per group).
+    float4 bv[2][4];
+    {
+        const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.B);   // any valid address; discarded below
 #pragma unroll
         for (int Ni = 0; Ni < 2; ++Ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nw + Ni * 32 + g * 8 + 4 * h;
-                const bool ok = row_ok && n < p.N;
-                float v[4];
+            for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(bp + min(nw + Ni * 32 + g * 8 + 4 * h, p.N - 4));
+    }
+    Vecs dq = Vecs();   // the activation-derivative operand, fetched one pass ahead
+    if constexpr (ACT == 3 || ACT == 4) dq = rows_fetch(rD, 0, lo[0]);
+    pin();
+
+    // ---- next tile: its prologue flies under this tile's epilogue.  Issued UNCONDITIONALLY (after the last tile it re-reads that
+    // tile's panels into buffers nobody reads; the kernel drains it before exiting): behind a branch, hipcc's s_waitcnt for the
+    // bias loads above has to assume the path without the twelve younger DMA pieces and drains them too.
+    {
+        int tid_n = threadIdx.x;
+        asm volatile("" : "+v"(tid_n));
+        Ctx cn;
+        make_ctx(cn, tid_n, Anext, Bnext, p.M - nxt.m0, p.N - nxt.n0, p.lda, p.ldb);
+        issue_prologue(cn, smem);
+    }
+    if (p.debug & 2) {      // ablation: no epilogue (the store keeps the accumulators alive)
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][3] + acc[2][0][7] + acc[3][1][15] + bv[0][0].x;
+        return;
+    }
+    if (!p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[Mi][Ni][4 * g + r] * p.alpha;
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + min(n, p.N - 4));
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
-                if (aux) {      // pre-activation out first
+        for (int Ni = 0; Ni < 2; ++Ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[Ni][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.stamps) { asm volatile("" :: "v"(bv[0][0].x), "v"(bv[1][3].w)); G8_STAMPW(2, cur.wg); }
+    float csum = 0.f;
+#pragma unroll
+    for (int Mi = 0; Mi < 4; ++Mi) {
+        [[maybe_unused]] const bool row_ok = (mw + Mi * 32 + r5) < p.M;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            pin();      // nothing of this pass may be computed ahead of the previous one (128 fresh values on top of the accumulators)
+            if constexpr (ACT == 3 || ACT == 4) {
+                rows_put(dq);
+                constexpr int LAST = 4 * NPASS - 1;
+                const int nx = Mi * NPASS + ps + 1;
+                if (nx <= LAST) dq = rows_fetch(rD, nx / NPASS, lo[nx % NPASS]);
+                wfence();
+            }
+            if (aux) {      // pre-activation out first (wave-uniform branch around LDS traffic and stores only)
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    const int Ni = ES == 2 ? q / 4 : ps, g = ES == 2 ? q % 4 : q;
+                    const float4 b = bv[Ni][g];
                     float pre[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pre[r] = ok ? v[r] : 0.f;
-                    io<TO>::store4(cell(Ni, g), pre);
+                    pre[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
+                    pre[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
+                    pre[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
+                    pre[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
+                    io<TO>::store4(cell(q), pre);
+                    if (q & 1) pin();      // keeps the scheduler from computing every group ahead of the first store (VGPR pressure)
                 }
+                wfence();
+                rows_store(__builtin_amdgcn_make_buffer_rsrc((void*)(aux + tile_off), 0, ext, 0x00020000), Mi, lo[ps]);
+                wfence();
+            }
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {      // a lane's cells are its own: the derivative operand is read and replaced in place
+                const int Ni = ES == 2 ? q / 4 : ps, g = ES == 2 ? q % 4 : q;
+                const float4 b = bv[Ni][g];
+                float v[4];
+                v[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
+                v[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
+                v[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
+                v[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
                 if constexpr (ACT == 1) {
                     gelu4(v);
                 } else if constexpr (ACT == 2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if constexpr (ACT == 3) {
-                    dgelu4_mul(v, u[Ni][g]);
-                } else if constexpr (ACT == 4) {
+                } else if constexpr (ACT == 3 || ACT == 4) {
+                    float u[4];
+                    io<TO>::load4(cell(q), u);
+                    if constexpr (ACT == 3) {
+                        dgelu4_mul(v, u);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (u[Ni][g][r] > 0.f) ? v[r] : 0.f;
+                        for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
+                    }
                 }
+                if constexpr (CS) {     // rows past M hold copies of row M - 1 (clamped loads): keep them out of the column sums
 #pragma unroll
-                for (int r = 0; r < 4; ++r) vv[Ni][g][r] = ok ? v[r] : 0.f;
+                    for (int r = 0; r < 4; ++r) v[r] = row_ok ? v[r] : 0.f;
+                }
+                io<TO>::store4(cell(q), v);
+                if (q & 1) pin();
             }
-        if (aux) {
             wfence();
-            rows_store(aux, Mi);
+            if constexpr (CS) {     // column sums of the block as stored (rounded to TO)
+                static_assert(!CS || ES == 2, "fused column sums: bf16 output only");
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    csum += io<TO>::load1(reinterpret_cast<const TO*>(ws + r * 128 + (((lane >> 3) ^ (r & 7)) << 4)) + (lane & 7));
+            }
+            rows_store(rC, Mi, lo[ps]);
             wfence();
         }
-#pragma unroll
-        for (int Ni = 0; Ni < 2; ++Ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) io<TO>::store4(cell(Ni, g), vv[Ni][g]);
-        wfence();
-        if constexpr (CS) {     // column sums of the block as stored (rounded to TO); rows / columns past M / N hold zeros
-#pragma unroll
-            for (int r = 0; r < 32; ++r) csum += io<TO>::load1(reinterpret_cast<const TO*>(ws + r * PITCH) + lane);
-        }
-        rows_store(C, Mi);
-        wfence();
+        G8_STAMPW(3 + Mi, cur.wg);
     }
+    G8_STAMPW(7, cur.wg);
     if constexpr (CS) {         // one partial row per 128-row wave block; the launcher folds them
         const int n = nw + lane;
-        if (n < p.N) p.colsum[(size_t)(tm * 2 + wr) * p.N + n] = csum;
+        if (n < p.N) p.colsum[(size_t)(cur_tm * 2 + wr) * p.N + n] = csum;
     }
+}
+
+template <typename TO, int ACT, bool CS>
+__global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = p.tiles_m * p.tiles_n;
+    const bf16* A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* B = reinterpret_cast<const bf16*>(p.B);
+    const int nk = ((p.debug & 4) ? 128 : p.K) / KE;
+    auto tile_at = [&](int vb) {
+        TileXY t;
+        t.wg = xcd_remap(vb, nwg);
+        t.m0 = (t.wg / p.tiles_n) * TM;
+        t.n0 = (t.wg % p.tiles_n) * TN;
+        return t;
+    };
+    int vb = blockIdx.x;
+    TileXY cur = tile_at(vb);
+    if (p.debug >> 8) {     // experiment: de-synchronise the workgroups' store bursts with a staggered start (G groups over one tile time)
+        const int G = (p.debug >> 8) & 0xff;
+        const long long T = (long long)nk * 2300 + 9000;
+        const long long until = (long long)__builtin_readcyclecounter() + T * ((blockIdx.x >> 3) % G) / G;
+        while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
+    }
+    bool first = true;
+    while (true) {
+        vb += gridDim.x;
+        const bool more = vb < nwg;
+        const TileXY nxt = more ? tile_at(vb) : cur;
+        tile_body<TO, ACT, CS>(p, smem, nk, A + (size_t)cur.m0 * p.lda, B + (size_t)cur.n0 * p.ldb, A + (size_t)nxt.m0 * p.lda,
+                               B + (size_t)nxt.n0 * p.ldb, cur, nxt, first);
+        if (!more) break;
+        cur = nxt;
+        first = false;
+    }
+    vm_wait<0>();      // the trailing prologue must not land in LDS that already belongs to another workgroup
 }
 
 template <typename TO, int ACT, bool CS>
@@ -353,12 +529,19 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     a.tiles_m = (d->M + TM - 1) / TM;
     a.tiles_n = (d->N + TN - 1) / TN;
     static bool attr_set = false;
+    static int n_cu = 0;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TO, ACT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+                                  LDS_TOTAL);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        n_cu &= ~7;      // a multiple of the 8 XCDs: workgroup b and its later tiles b + k * grid stay on XCD b % 8
+        if (n_cu < 8) n_cu = 8;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm8p_kernel<TO, ACT, CS>), dim3(a.tiles_m * a.tiles_n), dim3(THREADS), LDS_BYTES, s, a);
+    const int nwg = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL((gemm8p_kernel<TO, ACT, CS>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     if constexpr (CS) return colsum_f32_launch(a.colsum, a.colsum_dst, a.tiles_m * 2, d->N, s);
     return MOREC_OK;
@@ -366,10 +549,15 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // 0: automatic (eligible large problems), 1: never, 2: every eligible problem regardless of size
-static int g_mode8p = -1;
+static int g_mode8p = -1, g_debug8p = 0;
+static unsigned long long g_stamps = 0;
 extern "C" int morec_tuning_set(const char* key, int value) {
     if (!key) return MOREC_E_ARG;
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
+    // device buffer (16 x 8 bytes per workgroup) that receives s_memtime stamps of wave 0: address in two halves
+    if (!strcmp(key, "gemm8p_stamps_lo")) { g_stamps = (g_stamps & 0xffffffff00000000ull) | (unsigned)value; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_stamps_hi")) { g_stamps = (g_stamps & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); return MOREC_OK; }
     return MOREC_E_UNSUPPORTED;
 }
 
@@ -384,6 +572,8 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 115L)) return G8_NOT_TAKEN;
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->act == MOREC_ACT_GELU ? 1
                      : d->act == MOREC_ACT_RELU ? 2 : 0;
+    a.debug = g_debug8p;
+    a.stamps = reinterpret_cast<unsigned long long*>(g_stamps);
     if (d->out_dtype == MOREC_F32) {
         if (mode != 0 || a.colsum) return G8_NOT_TAKEN;
         return launch8p<float, 0, false>(d, a, s);

@@ -18,6 +18,8 @@ struct GemmArgs {
     int vec_store;   // output rows are 16-byte addressable: stage the tile through LDS and store full lines
     int wave_epilogue;
     float* colsum_dst;   // host side only: fp32 [N] the partial rows are folded into after the launch
+    unsigned long long* stamps;   // gemm8p: per-workgroup s_memtime stamps (debug bit 8), else null
+    int debug;       // gemm8p ablation bits (tuning key "gemm8p_debug"; 0 in production)
     float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
 };
 
