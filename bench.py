@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only: every rank joins the process group, rank 0 prints the "
+                    "world size it observed as one JSON line and exits (no GPU work; used by the CPU test of the N > 1 launch path)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     return ap.parse_args()
@@ -87,16 +89,55 @@ def synth_batches(n, B, S, item_num, rng):
     return ids.astype(np.int64)
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` outside a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves, the way
+    the reference's launcher does (T/train_bert_base.py:40-50: ``torch.distributed.launch --nproc_per_node N run.py ...``), so
+    that an N-GPU request can never silently run on one GPU.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {a.gpus} without a launcher environment: starting {a.gpus} ranks ({' '.join(cmd[1:9])} ...)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline(a)))
         return
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:     # fail loudly: the line's n_gpus must be the number of ranks that actually ran
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if a.launch_check:
+        if world > 1:
+            dist.init_process_group(a.backend if a.backend != "nccl" or torch.cuda.is_available() else "gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            if seen != world:
+                raise SystemExit(f"bench.py: {seen} of {world} ranks joined")
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": seen, "backend": a.backend if world > 1 else None}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if a.share_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPU(s) "
+                         "(--share-device runs every rank on cuda:0 for a functional check)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -105,6 +146,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # 'nccl' is RCCL on ROCm
         else:
             dist.init_process_group(a.backend)
+        joined = torch.ones(1, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(joined)          # the first collective: every rank is really there (RCCL communicator built)
+        if int(joined.item()) != world:
+            raise SystemExit(f"bench.py: {int(joined.item())} of {world} ranks joined the {a.backend} group")
 
     from idvs.morec_amd import engine as _engine
     from idvs.morec_amd import ops
@@ -314,7 +359,7 @@ def main():
                        "note": "launch-latency class at this size (16 MB of algorithmic traffic per step on one GPU); grows with the pooled column count"}
 
     out = {"metric": "user-sequences/sec end-to-end train step, SASRec+BERT-base", "value": round(world * a.batch * a.steps / dt, 2),
-           "unit": "user-seq/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "unit": "user-seq/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1), "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": a.dtype, "data": "synthetic MIND-shaped (80k items, Zipf(1.0) popularity, 30-token titles, history 23), random-init weights",
            "config": {"workload": f"SASRec(2 blocks, 2 heads, D=512) + BERT-{a.bert} text encoder, in-batch debiased CE, "
