@@ -148,24 +148,26 @@ def g11(out):
     print("g12 keys", len(keys["state_dict"]))
 
 
-def g13(out):
+def g13(out, name="swin_tiny", fname="g13_swin_tiny_scalars.npz", tag="g13", B=2):
     """Full-size Swin-T (config from pretrained_models/swin_tiny) inside the reference vision ``Model``: scalars only (loss, probe
-    elements of the item vectors, gradient norms); weights come from ``det_param`` on both sides."""
+    elements of the item vectors, gradient norms); weights come from ``det_param`` on both sides.
+    ``name='swin_base'`` (g15): the same capture with pretrained_models/swin_base/config.json -- BASELINE.json configs[4]
+    (embed 128, depths 2/2/18/2, heads 4/8/16/32), launcher V/run.py:47-54."""
     res = {}
-    cfg_t = SwinConfig.from_pretrained("/root/reference/pretrained_models/swin_tiny").to_dict()
+    cfg_t = SwinConfig.from_pretrained(f"/root/reference/pretrained_models/{name}").to_dict()
     kw = {k: cfg_t[k] for k in ["image_size", "patch_size", "num_channels", "embed_dim", "depths", "num_heads", "window_size",
                                 "mlp_ratio", "drop_path_rate", "layer_norm_eps"]}
     kw.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    S, D, item_num, B = 3, 256, 12, 2
+    S, D, item_num = 3, 256, 12
     args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
-                                 CV_model_load="swin_tiny")
-    pop = np.abs(det_normal("pop.g13", (item_num + 1,), std=1.0)) + 0.05
+                                 CV_model_load=name)
+    pop = np.abs(det_normal(f"pop.{tag}", (item_num + 1,), std=1.0)) + 0.05
     pop = (pop / pop.sum()).astype(np.float32)
     m = RefModel(args, item_num, True, build_swin(kw, D), pop.tolist())
     load_det(m)
     m.eval()
-    ids, log_mask = synth_batch("g13", B, S, item_num)
-    images = det_normal("g13.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
+    ids, log_mask = synth_batch(tag, B, S, item_num)
+    images = det_normal(f"{tag}.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
     images[0] = 0.0
     px = torch.from_numpy(images[ids.reshape(-1)])
     m.zero_grad()
@@ -180,8 +182,8 @@ def g13(out):
     for k, p in m.named_parameters():
         if p.grad is not None:
             res[f"grad_norm.{k}"] = np.float64(p.grad.double().norm().item())
-    np.savez_compressed(os.path.join(out, "g13_swin_tiny_scalars.npz"), **res)
-    print("g13 swin-tiny loss", loss.item())
+    np.savez_compressed(os.path.join(out, fname), **res)
+    print(tag, name, "loss", loss.item())
 
 
 if __name__ == "__main__":
@@ -193,3 +195,5 @@ if __name__ == "__main__":
         g11(HERE)
     if a.only in ("", "g13"):
         g13(HERE)
+    if a.only in ("", "g15"):
+        g13(HERE, name="swin_base", fname="g15_swin_base_scalars.npz", tag="g15", B=2)

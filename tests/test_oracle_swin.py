@@ -96,18 +96,16 @@ def test_vision_model_loss_matches_reference():
         assert abs(float(p[n].grad.double().norm()) - ref) <= 5e-4 * ref + 1e-7, n
 
 
-def test_swin_tiny_full_size_scalars():
-    """Full Swin-T (depths 2/2/6/2, 224 x 224) inside the vision Model: oracle vs the reference's loss / probes / grad norms."""
-    G13 = np.load(os.path.join(GOLDEN_DIR, "g13_swin_tiny_scalars.npz"))
+def _full_size_scalars(fname, tag, cfg):
+    G13 = np.load(os.path.join(GOLDEN_DIR, fname))
     S, D, item_num, B = (int(v) for v in G13["cfg"])
-    cfg = SwinCfg()
     names = [k[len("grad_norm."):] for k in G13.files if k.startswith("grad_norm.")]
     shapes = swin_shapes(cfg, D)
     from idvs.morec_amd.model.spec import sasrec_param_shapes
     shapes.update(sasrec_param_shapes(S, D, 2))
     p = {n: torch.from_numpy(det_param(n, shapes[n])).requires_grad_(True) for n in names}
     ids, log_mask, pop = G13["ids"], G13["log_mask"], G13["pop"]
-    images = det_normal("g13.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
+    images = det_normal(f"{tag}.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
     images[0] = 0.0
     px = torch.from_numpy(images[ids.reshape(-1)])
     E = vit_encoder_forward(p, cfg, px)
@@ -119,3 +117,13 @@ def test_swin_tiny_full_size_scalars():
     for n in names:
         ref = float(G13[f"grad_norm.{n}"])
         assert abs(float(p[n].grad.double().norm()) - ref) <= 1e-3 * ref + 1e-7, n
+
+
+def test_swin_tiny_full_size_scalars():
+    """Full Swin-T (depths 2/2/6/2, 224 x 224) inside the vision Model: oracle vs the reference's loss / probes / grad norms."""
+    _full_size_scalars("g13_swin_tiny_scalars.npz", "g13", SwinCfg())
+
+
+def test_swin_base_full_size_scalars():
+    """BASELINE.json configs[4]: Swin-B (embed 128, depths 2/2/18/2, heads 4/8/16/32) -- oracle vs the reference's g15 scalars."""
+    _full_size_scalars("g15_swin_base_scalars.npz", "g15", SwinCfg(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)))

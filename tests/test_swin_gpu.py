@@ -255,34 +255,46 @@ def test_droppath_training_matches_oracle_with_exported_scales():
         assert froerr(t.grad.cpu().numpy(), ref.numpy()) < 1e-3 or float(ref.norm()) < 1e-7, n
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_g13_swin_tiny_full_size_golden(golden_dir, dt):
-    """Full-size Swin-T tower (real config, 224 x 224) in the vision Model against the reference's scalars."""
-    G13 = np.load(os.path.join(golden_dir, "g13_swin_tiny_scalars.npz"))
-    S, D, item_num, B = (int(v) for v in G13["cfg"])
+def _full_size_swin_golden(golden_dir, dt, name, fname, tag):
+    G = np.load(os.path.join(golden_dir, fname))
+    S, D, item_num, B = (int(v) for v in G["cfg"])
     args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
-                                 CV_model_load="swin_tiny", compute_dtype=dt)
-    m = Model(args, item_num, True, HipSwinForImageClassification(SwinShape.named("swin_tiny"), D), G13["pop"].tolist())
+                                 CV_model_load=name, compute_dtype=dt)
+    m = Model(args, item_num, True, HipSwinForImageClassification(SwinShape.named(name), D), G["pop"].tolist())
     load_det(m).to(DEV).eval()
-    ids, log_mask = G13["ids"], G13["log_mask"]
-    images = det_normal("g13.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
+    ids, log_mask = G["ids"], G["log_mask"]
+    images = det_normal(f"{tag}.images", (item_num + 1, 3, 224, 224), std=1.0).astype(np.float32)
     images[0] = 0.0
     px = torch.from_numpy(images[ids.reshape(-1)]).to(DEV)
     with torch.no_grad():
         vec = m.cv_encoder(px)
-    e_v = relerr(vec[:, :8].cpu().numpy(), G13["item_vec_probe"])
+    e_v = relerr(vec[:, :8].cpu().numpy(), G["item_vec_probe"])
     assert e_v < (2e-4 if dt == "fp32" else 6e-2), e_v
     loss = m(torch.from_numpy(ids).view(-1).to(DEV), px, torch.from_numpy(log_mask).to(DEV), DEV)
-    e_l = abs(float(loss.detach()) - float(G13["loss"]))
-    assert e_l < (1e-3 if dt == "fp32" else 5e-2), (float(loss.detach()), float(G13["loss"]))
+    e_l = abs(float(loss.detach()) - float(G["loss"]))
+    assert e_l < (1e-3 if dt == "fp32" else 5e-2), (float(loss.detach()), float(G["loss"]))   # north_star: loss within 1e-3 in fp32
     loss.backward()
     worst = 0.0
     for n, p in m.named_parameters():
-        ref = float(G13[f"grad_norm.{n}"])
+        ref = float(G[f"grad_norm.{n}"])
         got = float(p.grad.double().norm())
         worst = max(worst, abs(got - ref) / (ref + 1e-9)) if ref > 1e-6 else worst
         assert abs(got - ref) <= (5e-3 if dt == "fp32" else 1.5e-1) * ref + (1e-6 if dt == "fp32" else 1e-3), (n, got, ref)
-    print(f"g13 swin-tiny {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
+    print(f"{tag} {name} {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_g13_swin_tiny_full_size_golden(golden_dir, dt):
+    """Full-size Swin-T tower (real config, 224 x 224) in the vision Model against the reference's scalars."""
+    _full_size_swin_golden(golden_dir, dt, "swin_tiny", "g13_swin_tiny_scalars.npz", "g13")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_g15_swin_base_full_size_golden(golden_dir, dt):
+    """BASELINE.json configs[4]: full-size Swin-B tower (pretrained_models/swin_base/config.json: embed 128, depths 2/2/18/2,
+    heads 4/8/16/32; V/run.py:47-54) in the vision Model against scalars captured from the reference + installed HF Swin
+    (tests/golden/make_golden_vision.py --only g15)."""
+    _full_size_swin_golden(golden_dir, dt, "swin_base", "g15_swin_base_scalars.npz", "g15")
 
 
 def test_patchify_from_uint8_images_is_bit_exact():
