@@ -337,6 +337,47 @@ def main():
                       "distinct_item_fraction": round(uniq, 4),
                       "note": "opt-in (--dedup): each distinct item of the batch encoded once; exact with dropout off, shares dropout masks between duplicates otherwise"}
 
+    # secondary line (never `value`): the same step in the PARITY mode (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32 -- the mode the
+    # reference goldens pin at 1e-4 on the loss), so that the price of reference-level numerics is a measured number
+    fp32_info = None
+    main_gemm_log = list(gemm_log)
+    if not vision and not id_tower and a.dtype == "bf16" and not a.no_secondary and world == 1:
+        try:
+            args32 = types.SimpleNamespace(**dict(vars(args), compute_dtype="fp32"))
+            torch.manual_seed(12345)
+            model32 = Model(args32, a.item_num, True, HipBertModel(shape), pop).to(dev)
+            model32.train()
+            saved = (ts, )
+            ts32 = TrainStep(model32, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False)
+            ts = ts32                      # run_step closes over `ts`
+            n32 = max(2, min(4, a.steps))
+            run_step(0)
+            torch.cuda.synchronize()
+            del gemm_log[:]
+            timing_on["v"] = True
+            t1 = time.perf_counter()
+            for i in range(n32):
+                run_step(a.warmup + i % a.steps)
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t1
+            timing_on["v"] = False
+            fl32 = sum(f for f, _, _, _ in gemm_log)
+            ms32 = sum(e0.elapsed_time(e1) for _, e0, e1, _ in gemm_log)
+            tf32 = fl32 / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+            fp32_info = {"ms_per_step": round(dt32 / n32 * 1e3, 2), "user_seq_per_s": round(a.batch * n32 / dt32, 2), "steps": n32,
+                         "gemm_tflops": round(tf32, 1), "mfma_f32_peak": MFMA_PEAK_TFLOPS["f32"],
+                         "frac_of_f32_mfma_peak": round(tf32 / MFMA_PEAK_TFLOPS["f32"], 4),
+                         "note": "compute_dtype=fp32: every GEMM on exact-fp32 MFMA; the mode whose loss matches the reference goldens "
+                                 "to < 1e-4 (tests/test_model_gpu.py g6). tests/test_bench_mode_parity_gpu.py bounds the bf16 mode "
+                                 "against it at this configuration: step-0 loss 5e-3 (measured 1.3e-3), gradient norms 2.5e-2 (measured < 1e-2), 20-step loss curve 2 % (measured 0.9 %)"}
+            (ts, ) = saved
+            del ts32, model32
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
+            fp32_info = {"error": f"{type(e).__name__}: {e}"}
+            timing_on["v"] = False
+        gemm_log[:] = main_gemm_log
+
     # roofline of the dominant kernel: algorithmic FLOPs of every GEMM launch / its measured duration
     fl = sum(f for f, _, _, _ in gemm_log)
     ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in gemm_log)
@@ -377,6 +418,9 @@ def main():
         out["padded_token_layout"] = padded_info
     if dedup_info is not None:
         out["with_item_dedup"] = dedup_info
+    if fp32_info is not None:
+        out["fp32_parity_mode"] = fp32_info
+        out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 5e-3, gradient norms 2.5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 / < 1e-2 / 0.9 %)"
     if a.dedup:
         out["config"]["item_dedup"] = True
     if vision:

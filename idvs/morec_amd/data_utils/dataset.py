@@ -108,3 +108,15 @@ class SequentialDistributedSampler(torch.utils.data.sampler.Sampler):
 
     def __len__(self):
         return self.num_samples
+
+
+def epoch_batches(n_samples: int, batch_size: int, world: int, rank: int, epoch: int):
+    """The index batches one rank sees in one epoch under the reference's sampler + loader (``T/run.py:114,123-124,230``):
+    ``torch.utils.data.DistributedSampler`` itself (shuffle with seed 0 + epoch, PAD to a multiple of ``world`` by repeating the
+    head of the permutation, rank r takes every world-th index) cut into ``batch_size`` pieces by a ``DataLoader`` without
+    ``drop_last`` -- the LAST BATCH IS SHORT, so the batch size is not a constant of the step."""
+    from torch.utils.data.distributed import DistributedSampler
+    sampler = DistributedSampler(range(n_samples), num_replicas=world, rank=rank, shuffle=True, seed=0, drop_last=False)
+    sampler.set_epoch(epoch)
+    idx = list(iter(sampler))
+    return [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]

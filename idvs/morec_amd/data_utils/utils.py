@@ -17,7 +17,9 @@ def save_model(now_epoch, model, model_dir, optimizer, rng_state, cuda_rng_state
     os.makedirs(model_dir, exist_ok=True)
     ckpt_path = os.path.join(model_dir, f"epoch-{now_epoch}.pt")
     torch.save({"model_state_dict": _unwrap(model).state_dict(),
-                "optimizer": optimizer.state_dict() if optimizer is not None else None,
+                # torch.optim.AdamW or train_step.TrainStep (same state_dict form: TrainStep.optimizer_state_dict)
+                "optimizer": (optimizer.optimizer_state_dict() if hasattr(optimizer, "optimizer_state_dict") else optimizer.state_dict())
+                if optimizer is not None else None,
                 "rng_state": rng_state, "cuda_rng_state": cuda_rng_state,
                 "scaler_state": scaler.state_dict() if scaler is not None else {}}, ckpt_path)
     if Log_file is not None:

@@ -121,9 +121,10 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     return x2, saved
 
 
-def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
+def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict, need_dx: bool = True):
     """g: fp32 gradient buffers (accumulated into): qkv [3H,H], bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b
-    (bias entries may be None).  Returns (da, db) with dx0 = da + db."""
+    (bias entries may be None).  Returns (da, db) with dx0 = da + db; ``need_dx=False`` (nothing trainable below this
+    layer) skips the input-gradient GEMM and returns (None, None)."""
     desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2 = saved
     # dz* = gradient at the residual sum (also the residual branch's gradient); dzd* = after the sub-layer's dropout
     dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
@@ -140,6 +141,8 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict):
     if g.get("bqkv") is not None:
         ops.colsum_(dqkv, g["bqkv"])
     linear_wgrad_(dqkv, x0, g["qkv"])
+    if not need_dx:
+        return None, None
     dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=x0.shape[1])
     return dx0, dz1
 
@@ -186,7 +189,7 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     return x2, saved
 
 
-def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: dict):
+def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: dict, need_dx: bool = True):
     """Backward of ``layer_forward_cls``: dx2_c is the gradient at the [CLS] rows [n_seq, H].  Returns (da, db) over ALL
     tokens with dx0 = da + db (db carries the residual-branch gradient, non-zero on the [CLS] rows only)."""
     desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, gact, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq, cu = saved
@@ -207,6 +210,8 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     if g.get("bqkv") is not None:
         ops.colsum_(dqkv, g["bqkv"])
     linear_wgrad_(dqkv, x0, g["qkv"])
+    if not need_dx:
+        return None, None
     dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=H)
     dres = dctx.zero_()                      # reuse: residual-branch gradient, [CLS] rows only
     scatter_cls(dz1, dres, n_seq, T, cu)
@@ -324,8 +329,39 @@ def token_packing(mask: torch.Tensor):
     return cu, tok_idx
 
 
+def bert_grad_from(trainable_names, n_layers: int, prefix: str = TE) -> int:
+    """Lowest point of the text tower that has a trainable parameter (the reference freezes ``bert_model`` parameters by
+    index, ``T/run.py:73-75``; its default ``--freeze_paras_before 165`` = embeddings + layers 0-9, and autograd then never
+    walks below layer 10): -1 = the embeddings, k >= 0 = encoder layer k, ``n_layers`` = nothing inside ``bert_model``."""
+    bm = prefix + "bert_model."
+    lo = n_layers
+    for n in trainable_names:
+        if not n.startswith(bm) or ".pooler." in n:
+            continue
+        if n.startswith(bm + "embeddings."):
+            return -1
+        if n.startswith(bm + "encoder.layer."):
+            lo = min(lo, int(n[len(bm + "encoder.layer."):].split(".")[0]))
+    return lo
+
+
+def bert_needs_grad_buffer(name: str, grad_from: int, prefix: str = TE) -> bool:
+    """Does the backward pass (which stops at ``grad_from``, see ``bert_grad_from``) write a gradient for this parameter?"""
+    bm = prefix + "bert_model."
+    if not name.startswith(bm):
+        return True
+    if ".pooler." in name:
+        return False
+    if name.startswith(bm + "embeddings."):
+        return grad_from < 0
+    if name.startswith(bm + "encoder.layer."):
+        return int(name[len(bm + "encoder.layer."):].split(".")[0]) >= max(grad_from, 0)
+    return True
+
+
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
-                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None):
+                 mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None,
+                 grad_from: int = -1):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
 
     ``unpad``: run the encoder layers on the REAL tokens only (packed rows + ``cu_seqlens``) instead of all T positions of
@@ -359,17 +395,18 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
             keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
     saved_layers = []
     for l, w in enumerate(prep["layers"]):
+        ng = need_grad and l >= grad_from      # layers below the first trainable one keep nothing for a backward that never reaches them
         if l == n_layers - 1:     # only hidden[:, 0] is consumed (encoders.py:69): row-wise work on the [CLS] rows only
-            cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l, cu)
+            cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, ng, drop, 1 + 3 * l, cu)
         else:
-            x, sv = layer_forward(cfg, w, x, keep, Nc, need_grad, drop, 1 + 3 * l, cu)
+            x, sv = layer_forward(cfg, w, x, keep, Nc, ng, drop, 1 + 3 * l, cu)
         saved_layers.append(sv)
     if n_layers == 0:
         cls = ops.strided_rows_copy(x, torch.empty((Nc, H), device=x.device, dtype=dtype), Nc, H, T, 1)
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
-    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx) if need_grad else None
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from) if need_grad else None
     return item, saved
 
 
@@ -378,19 +415,23 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     ``bert_model`` is, ``("layer", l)`` after layer ``l`` -- so a data-parallel driver can start reducing them while the
     rest of the backward pass still runs."""
     bm = prefix + "bert_model."
-    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx = saved
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from = saved
+    n_layers = len(prep["layers"])
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
     linear_wgrad_(dv, cls, grads[prefix + "fc.weight"])
+    if grad_from >= n_layers and n_layers > 0:      # the whole of bert_model is frozen: the backward ends at the projection head
+        if on_ready is not None:
+            on_ready("head")
+        return
     dcls = ops.gemm_nt(dv, prep["fc"].wt, K=dv.shape[1], N=H)
     if on_ready is not None:
         on_ready("head")
-    n_layers = len(prep["layers"])
     da, db = None, None
     if n_layers == 0:
         da = torch.zeros((Nc * T, H), device=dcls.device, dtype=dcls.dtype)
         ops.strided_rows_copy(dcls, da, Nc, H, 1, T)
-    for l in reversed(range(n_layers)):
+    for l in reversed(range(max(grad_from, 0), n_layers)):
         L = bm + f"encoder.layer.{l}."
         dqkv, dbqkv = grads.get(L + "qkv_fused.weight"), grads.get(L + "qkv_fused.bias")
         fused = dqkv is not None
@@ -402,16 +443,19 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
                  f1=grads[L + "intermediate.dense.weight"], b1=grads[L + "intermediate.dense.bias"],
                  f2=grads[L + "output.dense.weight"], b2=grads[L + "output.dense.bias"],
                  ln2_g=grads[L + "output.LayerNorm.weight"], ln2_b=grads[L + "output.LayerNorm.bias"])
+        need_dx = not (grad_from >= 0 and l == grad_from)     # nothing trainable below layer grad_from (embeddings frozen too)
         if l == n_layers - 1:
-            da, db = layer_backward_cls(cfg, prep["layers"][l], saved_layers[l], dcls, g)
+            da, db = layer_backward_cls(cfg, prep["layers"][l], saved_layers[l], dcls, g, need_dx)
         else:
-            da, db = layer_backward(cfg, prep["layers"][l], saved_layers[l], da, db, g)
+            da, db = layer_backward(cfg, prep["layers"][l], saved_layers[l], da, db, g, need_dx)
         if not fused:
             for i, n in enumerate(("query", "key", "value")):
                 grads[L + f"attention.self.{n}.weight"] = dqkv[i * H:(i + 1) * H]
                 grads[L + f"attention.self.{n}.bias"] = dbqkv[i * H:(i + 1) * H]
         if on_ready is not None:
             on_ready(("layer", l))
+    if grad_from >= 0:        # frozen embeddings: no embedding-LayerNorm backward, no word / position / type scatter
+        return
     if tok_idx is not None:   # back to the padded layout the embedding stage (and its dropout stream) lives in: [PAD] rows get zero
         pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
         ops.indexed_rows_copy(da, pa, out_idx=tok_idx)

@@ -54,22 +54,25 @@ class BertEncoderFn(torch.autograd.Function):
         p = dict(zip(names, params))
         need = any(ctx.needs_input_grad)
         prep = engine.bert_prepare(p, n_layers, dtype, prefix)
-        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop)
-        ctx.stuff = (p, prep, saved, names, prefix)
+        # the backward stops at the lowest trainable point of the tower (T/run.py:73-75 freezes a prefix by parameter index)
+        grad_from = engine.bert_grad_from([n for n, nd in zip(names, ctx.needs_input_grad[2:]) if nd], n_layers, prefix)
+        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop, grad_from=grad_from)
+        ctx.stuff = (p, prep, saved, names, prefix, grad_from)
         ctx.needs = ctx.needs_input_grad
         return item
 
     @staticmethod
     def backward(ctx, d_item):
-        p, prep, saved, names, prefix = ctx.stuff
+        p, prep, saved, names, prefix, grad_from = ctx.stuff
         ctx.stuff = None
         bm = prefix + "bert_model."
-        qkv = {bm + f"encoder.layer.{l}.attention.self.{n}.{k}" for l in range(len(prep["layers"]))
-               for n in ("query", "key", "value") for k in ("weight", "bias")}
-        grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
+        skip = {bm + f"encoder.layer.{l}.attention.self.{n}.{k}" for l in range(len(prep["layers"]))
+                for n in ("query", "key", "value") for k in ("weight", "bias")}
+        skip |= {n for n in names if not engine.bert_needs_grad_buffer(n, grad_from, prefix)}    # never reached by the backward
+        grads = _zeros_like_params(names, [p[n] for n in names], skip=skip)
         engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
         needs = ctx.needs[2:]
-        return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
+        return (None, None) + tuple(grads.get(n) if nd else None for n, nd in zip(names, needs))
 
 
 class SwinEncoderFn(torch.autograd.Function):
@@ -127,6 +130,33 @@ def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
+def pool_exchange(E: torch.Tensor, ci, n_valid: torch.Tensor, world: int, rank: int):
+    """The forward exchange of the pooled-negative step in TWO collectives instead of five: one all-gather of
+    the encoded item vectors, one all-gather of a packed int32 record per rank -- slot ids | log-pop bits | validity | the
+    rank's valid-row count -- whose last word also replaces the scalar all-reduce (every rank sums the same ``world`` counts in
+    the same order: identical n_valid everywhere, deterministically).  Returns (E_pool, pooled CeInputs, n_valid_global)."""
+    Nc = ci.col_ids.shape[0]
+    blob = torch.cat((ci.col_ids.to(torch.int32), ci.col_logpop.to(torch.float32).view(torch.int32), ci.col_valid.to(torch.int32),
+                      n_valid.reshape(1).to(torch.float32).view(torch.int32))).view(1, -1)
+    g = _all_gather_cat(blob, world)                                   # [world, 3 Nc + 1]
+    Epool = _all_gather_cat(E, world)
+    pooled = engine.CeInputs(ci.row_ids, g[:, :Nc].reshape(-1).contiguous(),
+                             g[:, Nc:2 * Nc].reshape(-1).contiguous().view(torch.float32).to(ci.col_logpop.dtype),
+                             g[:, 2 * Nc:3 * Nc].reshape(-1).to(torch.uint8).contiguous(), ci.row_valid, ci.B, ci.S, rank * E.shape[0])
+    n_glob = g[:, 3 * Nc].contiguous().view(torch.float32).sum()
+    return Epool, pooled, n_glob
+
+
+def reduce_scatter_dE(dEpool: torch.Tensor, world: int, rank: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """The backward exchange: SUM of every rank's gradient w.r.t. the pooled item vectors, each rank keeping the rows it owns.
+    Always reduced in fp32 (an 8-way sum in bf16 would round seven times), then returned in the compute dtype."""
+    t = dEpool if dEpool.dtype == torch.float32 else (ops.cast(dEpool, torch.float32) if dEpool.is_cuda else dEpool.float())
+    d = _reduce_scatter_sum(t, world, rank)
+    if d.dtype == out_dtype:
+        return d
+    return ops.cast(d, out_dtype) if d.is_cuda else d.to(out_dtype)
+
+
 def _reduce_scatter_sum(t: torch.Tensor, world: int, rank: int) -> torch.Tensor:
     n = t.shape[0] // world
     if dist.get_backend() == "gloo":   # gloo has no reduce_scatter: all-reduce and keep our shard (smoke / CPU tests only)
@@ -155,10 +185,7 @@ class InBatchCEFn(torch.autograd.Function):
         n_valid = ci.row_valid.sum(dtype=torch.float32)
         if world > 1:
             rank = dist.get_rank()
-            Epool = _all_gather_cat(E, world)
-            ci = engine.CeInputs(ci.row_ids, _all_gather_cat(ci.col_ids, world), _all_gather_cat(ci.col_logpop, world),
-                                 _all_gather_cat(ci.col_valid, world), ci.row_valid, ci.B, ci.S, rank * E.shape[0])
-            dist.all_reduce(n_valid)
+            Epool, ci, n_valid = pool_exchange(E, ci, n_valid, world, rank)
         else:
             rank, Epool = 0, E
         loss_sum, saved = backend.ce_forward(ci, P, Epool)
@@ -171,5 +198,5 @@ class InBatchCEFn(torch.autograd.Function):
         ctx.stuff = None
         g = (dloss.to(torch.float32) * loss_mult / n_valid).reshape(1).contiguous()
         dP, dEpool = backend.ce_backward(ci, P, Epool, saved, g, 1.0)
-        dE = _reduce_scatter_sum(dEpool, world, rank) if world > 1 else dEpool
+        dE = reduce_scatter_dE(dEpool, world, rank, dEpool.dtype) if world > 1 else dEpool
         return dP, dE, None, None, None, None

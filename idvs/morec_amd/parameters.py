@@ -61,6 +61,9 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="N > 0: train on N synthetic MIND-shaped users (no data files)")
     p.add_argument("--synthetic_items", type=int, default=20000)
     p.add_argument("--max_steps", type=int, default=0)
+    p.add_argument("--checkpoint_root", type=str, default="./checkpoint", help="parent of checkpoint_<tower>.../cpt_<label>/ (T/run.py:326-331)")
+    p.add_argument("--pretrained_dir", type=str, default="../pretrained_models",
+                   help="directory holding <bert_model_load>/pytorch_model.bin (T/run.py:29-53 reads ../../pretrained_models/)")
     return p
 
 

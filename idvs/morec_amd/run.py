@@ -5,7 +5,11 @@
         --bert_model_load bert_base_uncased --synthetic 60000 --batch_size 128 --embedding_dim 512 --fused_step --pool_negatives
 
 Two optimisation paths: the reference's (DDP + torch.optim.AdamW on the drop-in ``Model``; ``T/run.py:148-162,241-247``
-without the fp16 GradScaler, which bf16 does not need) and ``--fused_step`` (``train_step.TrainStep``)."""
+without the fp16 GradScaler, which bf16 does not need) and ``--fused_step`` (``train_step.TrainStep``).
+Checkpoints: reference format (``epoch-N.pt``), saved by rank 0 when the validation Hit@10 improves (modal runs only, as
+``T/run.py:265-267``), resumed with ``--load_ckpt_name epoch-N.pt`` (``T/run.py:130-139,193-195``; early stopping is switched off
+on a resumed run, like there); ``--mode test`` evaluates a checkpoint on the test split (``T/run_test.py:115-128``).  Both
+optimisation paths read and write the SAME optimizer state (``TrainStep.optimizer_state_dict``)."""
 from __future__ import annotations
 
 import logging
@@ -19,7 +23,8 @@ import torch.distributed as dist
 import torch.optim as optim
 from torch.nn.parallel import DistributedDataParallel as DDP
 
-from .data_utils import collate_bce_batch, collate_train_batch, eval_model, get_item_embeddings, read_behaviors, read_news
+from .data_utils import (collate_bce_batch, collate_train_batch, epoch_batches, eval_model, get_checkpoint, get_item_embeddings,
+                         load_model, read_behaviors, read_news, save_model)
 from .model import BceModel, BertShape, HipBertModel, Model
 from .model.swin import HipSwinForImageClassification
 from .swin_engine import SwinShape
@@ -72,6 +77,35 @@ def run_eval(model, item_content, user_history, users_eval, batch_size, item_num
     return hit10
 
 
+def model_dir_of(args):
+    """``T/run.py:326-331``: ./checkpoint/checkpoint_<item_tower>_<encoder>_freeze_<n>/cpt_<hyper-parameters>."""
+    enc = args.CV_model_load if getattr(args, "CV_model_load", "None") != "None" else args.bert_model_load
+    dir_label = f"{args.item_tower}_{enc}_freeze_{args.freeze_paras_before}"
+    label = f"bs_{args.batch_size}_ed_{args.embedding_dim}_lr_{args.lr}_Flr_{args.fine_tune_lr}_dp_{args.drop_rate}_L2_{args.l2_weight}"
+    return os.path.join(args.checkpoint_root, "checkpoint_" + dir_label, "cpt_" + label)
+
+
+def _load_pretrained_text_tower(bert, args):
+    """``BertModel.from_pretrained(bert_model_load)`` (``T/run.py:51-53``): weights from ``<pretrained_dir>/<bert_model_load>/
+    pytorch_model.bin`` (or ``model.safetensors``) when that directory exists; otherwise the tower keeps its random
+    initialisation and says so -- there are no checkpoints in this image (``pretrained_models/`` ships configs only)."""
+    d = os.path.join(args.pretrained_dir, args.bert_model_load)
+    for fn in ("pytorch_model.bin", "model.safetensors"):
+        path = os.path.join(d, fn)
+        if os.path.exists(path):
+            if fn.endswith(".bin"):
+                sd = torch.load(path, map_location="cpu", weights_only=True)
+            else:
+                from safetensors.torch import load_file
+                sd = load_file(path)
+            sd = {k[len("bert."):] if k.startswith("bert.") else k: v for k, v in sd.items()}
+            missing, unexpected = bert.load_state_dict(sd, strict=False)
+            Log.info("text tower: %s loaded (%d missing, %d unexpected keys)" % (path, len(missing), len(unexpected)))
+            return True
+    Log.warning("text tower: no pretrained weights under %s -- RANDOM initialisation" % d)
+    return False
+
+
 def train(args, use_modal, local_rank):
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -88,13 +122,24 @@ def train(args, use_modal, local_rank):
             item_content = (np.load(args.images_npy, mmap_mode="r") if args.images_npy != "None" else
                             np.random.default_rng(4321).integers(0, 256, (item_num + 1, R, R, 3), dtype=np.uint8))
             assert item_content.shape == (item_num + 1, R, R, 3) and item_content.dtype == np.uint8
+    elif use_modal and not vision:                                       # T/run.py:28-98: tokenizer -> fixed-length id / mask tables
+        from transformers import BertTokenizer
+        from .data_utils import get_doc_input_bert, read_news_bert
+        tok_dir = os.path.join(args.pretrained_dir, args.bert_model_load)
+        if not os.path.exists(os.path.join(tok_dir, "vocab.txt")):
+            raise SystemExit(f"modal run on real data: no tokenizer vocabulary under {tok_dir} (--pretrained_dir / --bert_model_load)")
+        tokenizer = BertTokenizer.from_pretrained(tok_dir)
+        a, b, c = read_news_bert(os.path.join(args.root_data_dir, args.dataset, args.news), args, tokenizer)
+        item_num, item_id_to_dic, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(
+            os.path.join(args.root_data_dir, args.dataset, args.behaviors), a, b, c, S, args.min_seq_len, Log)
+        tables = get_doc_input_bert(item_id_to_dic, args)
+        item_content = np.concatenate([x for x in tables if x is not None], axis=1)
+    elif vision:
+        raise SystemExit("vision runs on real data read the item images through --images_npy or --image_lmdb (data_utils.images)")
     else:
         a, b, c = read_news(os.path.join(args.root_data_dir, args.dataset, args.news))
         item_num, _, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(
             os.path.join(args.root_data_dir, args.dataset, args.behaviors), a, b, c, S, args.min_seq_len, Log)
-        if use_modal:
-            raise SystemExit("modal runs on real data need the tokenizer files of the reference's pretrained_models/ "
-                             "(read_news_bert + get_doc_input_bert are provided in data_utils.preprocess)")
         item_content = np.arange(item_num + 1)
     bert = None
     if vision:
@@ -110,16 +155,38 @@ def train(args, use_modal, local_rank):
         for index, (name, param) in enumerate(bert.named_parameters()):   # T/run.py:73-75
             if index < args.freeze_paras_before or name in pooler:
                 param.requires_grad = False
+    if use_modal and not vision:
+        _load_pretrained_text_tower(bert, args)
     bce = args.loss == "bce"
     if bce and (args.fused_step or vision):
         raise SystemExit("--loss bce runs on the drop-in autograd path with the text / ID towers (bce_text/main-end2end)")
     model = (BceModel(args, item_num, use_modal, bert) if bce else Model(args, item_num, use_modal, bert, pop)).to(local_rank)
     neg_rng = np.random.default_rng(777 + rank)
     users = list(users_train.keys())
-    steps_per_epoch = len(users) // (args.batch_size * world)
+    model_dir = model_dir_of(args)
+    ckpt, start_epoch, is_early_stop = None, 0, True
+    if "None" not in args.load_ckpt_name:                               # T/run.py:130-139: BEFORE the arenas / DDP are built
+        ckpt_path = get_checkpoint(model_dir, args.load_ckpt_name)
+        if ckpt_path is None:
+            raise SystemExit(f"--load_ckpt_name {args.load_ckpt_name}: not found under {model_dir}")
+        start_epoch = load_model(model, ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        if ckpt.get("rng_state") is not None:
+            torch.set_rng_state(ckpt["rng_state"])
+        if ckpt.get("cuda_rng_state") is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(ckpt["cuda_rng_state"])
+        is_early_stop = False
+        Log.info("model loaded from %s (epoch %d)" % (ckpt_path, start_epoch))
+    if args.mode == "test":                                             # T/run_test.py:115-128
+        if ckpt is None:
+            raise SystemExit("--mode test needs --load_ckpt_name epoch-N.pt")
+        return run_eval(model, item_content, hist_test, users_test, 512, item_num, use_modal, args, "test", local_rank)
+    stepper, optimizer = None, None
     if args.fused_step:
         stepper = TrainStep(model, lr=args.lr, fine_tune_lr=args.fine_tune_lr, l2_weight=args.l2_weight,
                             fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives)
+        if ckpt is not None and ckpt.get("optimizer") is not None:     # T/run.py:193-195
+            stepper.load_optimizer_state_dict(ckpt["optimizer"])
         wrapped = model
     else:
         wrapped = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True) if world > 1 else model
@@ -131,14 +198,20 @@ def train(args, use_modal, local_rank):
         groups = [{"params": [p for n, p in named if tower(n)], "lr": args.fine_tune_lr, "weight_decay": args.fine_tune_l2_weight},
                   {"params": [p for n, p in named if not tower(n)], "lr": args.lr, "weight_decay": args.l2_weight}]
         optimizer = optim.AdamW([g for g in groups if g["params"]])   # T/run.py:159-162
+        if ckpt is not None and ckpt.get("optimizer") is not None:
+            optimizer.load_state_dict(ckpt["optimizer"])
     best, step = 0.0, 0
+    max_epoch, early_stop_epoch, early_stop_count = 0, args.epoch, 0
+    early_stop_gap = 6 if vision else 10                               # T/run.py:221 / V/run.py:185
     for ep in range(1, args.epoch + 1):
+        now_epoch = start_epoch + ep
         model.train()
-        order = np.random.default_rng(ep).permutation(len(users))      # DistributedSampler.set_epoch analogue
-        order = order[rank::world]
+        # T/run.py:114,123-124,230: DistributedSampler(seed 0 + epoch, padded to a multiple of the world size) + a loader
+        # without drop_last -- the last batch of an epoch is short
+        batches = epoch_batches(len(users), args.batch_size, world, rank, now_epoch)
         t0, loss_acc = time.time(), None
-        for b in range(steps_per_epoch):
-            batch_users = [users[i] for i in order[b * args.batch_size:(b + 1) * args.batch_size]]
+        for b, batch_idx in enumerate(batches):
+            batch_users = [users[i] for i in batch_idx]
             if bce:      # bce_text/main-end2end/run.py:224-237
                 items, log_mask = collate_bce_batch(users_train, batch_users, item_content, S, item_num, use_modal, neg_rng)
                 items, log_mask = items.to(local_rank), log_mask.to(local_rank)
@@ -175,11 +248,23 @@ def train(args, use_modal, local_rank):
         if torch.isnan(torch.tensor(mean_loss)):                        # T/run.py:249-251
             Log.info("NaN loss, stopping")
             break
-        Log.info("epoch %d: %d steps, mean loss %.5f, %.1f user-seq/s" % (ep, b + 1, mean_loss, (b + 1) * args.batch_size * world / dt))
+        n_seq = sum(len(x) for x in batches[:b + 1]) * world
+        Log.info("epoch %d: %d steps, mean loss %.5f, %.1f user-seq/s" % (now_epoch, b + 1, mean_loss, n_seq / dt))
         hit10 = run_eval(wrapped, item_content, hist_valid, users_valid, 512, item_num, use_modal, args, "valid", local_rank)
-        best = max(best, hit10)
-        if args.max_steps and step >= args.max_steps:
+        need_break = False
+        if hit10 > best:                                                # T/run.py:291-304
+            best, max_epoch, early_stop_count = hit10, now_epoch, 0
+            if use_modal and rank == 0:                                 # T/run.py:265-267: modal runs only, rank 0 only
+                save_model(now_epoch, model, model_dir, stepper if stepper is not None else optimizer, torch.get_rng_state(),
+                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None, None, Log)
+        else:
+            early_stop_count += 1
+            if early_stop_count > early_stop_gap:
+                need_break = is_early_stop
+                early_stop_epoch = now_epoch
+        if need_break or (args.max_steps and step >= args.max_steps):
             break
+    Log.info("max eval Hit10 %.5f in epoch %d; early stop in epoch %d" % (best * 100, max_epoch, early_stop_epoch))
     return best
 
 

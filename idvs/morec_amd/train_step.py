@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import engine, ops, swin_engine
-from .functional import _all_gather_cat, _reduce_scatter_sum
+from .functional import pool_exchange, reduce_scatter_dE
 
 
 def _round8(n: int) -> int:
@@ -68,6 +68,23 @@ class ParamArena:
             assert o == end and n % 8 == 0, "parameters are not adjacent in the arena"
             end = o + n
         return buf[o0:end].view(shape)
+
+
+def _check_qkv_groups(train_names, all_names, pattern, members):
+    """The fused [3H, H] projection needs a layer's q / k / v parameters to be trainable TOGETHER.  A freeze boundary that
+    falls inside the group (``--freeze_paras_before`` not at a layer boundary: the reference trains the unfrozen rest of the
+    group, ``T/run.py:73-75``) cannot be represented by the flat arenas -- refuse it instead of silently not training them."""
+    train = set(train_names)
+    for n in all_names:
+        mt = re.search(pattern, n)
+        if not mt:
+            continue
+        base = n[: mt.start(1)]
+        grp = [base + mbr for mbr in members]
+        hit = [g_ in train for g_ in grp if g_ in all_names]
+        if any(hit) and not all(hit):
+            raise ValueError(f"freeze boundary inside the q/k/v group of {base!r}: freeze whole layers (parameter index at a layer "
+                             "boundary, e.g. 5 + 16 k for BERT) or use the autograd path (DDP + torch.optim.AdamW) for this setting")
 
 
 def _order_bert(names):
@@ -126,6 +143,17 @@ class TrainStep:
         named = OrderedDict((n, p) for n, p in model.named_parameters())
         train = [n for n, p in named.items() if p.requires_grad and ".pooler." not in n]
         self.vision = bool(getattr(model, "vision", False) and model.use_modal)
+        _check_qkv_groups(train, list(named), r"\.attention\.self\.((?:query|key|value)\.(?:weight|bias))$",
+                          [f"{x}.{k}" for x in ("query", "key", "value") for k in ("weight", "bias")])
+        _check_qkv_groups(train, list(named), r"\.attention\.((?:q|k|v)_proj\.(?:weight|bias))$",
+                          [f"{x}_proj.{k}" for x in ("q", "k", "v") for k in ("weight", "bias")])
+        if model.use_modal and not self.vision:
+            # the fused path encodes ONE attribute (what every reference launcher builds, T/model/encoders.py:95-103); with
+            # title,abstract[,body] the token row is [ids | mask | ids | mask ...] and must be narrowed per attribute and averaged
+            # (encoders.py:107-116) -- the drop-in Model does that, TrainStep does not
+            attrs = list(getattr(model.args, "news_attributes", ["title"]))
+            if attrs != ["title"]:
+                raise ValueError(f"TrainStep supports news_attributes == ['title'] (got {attrs}); use the autograd path for several attributes")
         if self.vision:
             # V/run.py:121-130, applied literally to the installed-HF names: 'image_net' parameters whose name contains
             # 'fc' or 'classifier' (the replaced head -- and, with transformers >= 5 naming, mlp.fc1 / mlp.fc2) train
@@ -216,6 +244,8 @@ class TrainStep:
             self.bert_heads = bert.config.num_attention_heads
             self.bert_layers, self.bert_eps = L, bert.config.layer_norm_eps
             self.bert_mask_value = m.bert_encoder.text_encoders["title"].mask_value
+            # lowest trainable point of the tower: the backward (and what the forward keeps for it) stops there
+            self.bert_grad_from = engine.bert_grad_from(list(a0.offsets) if len(self.groups) > 1 else [], L)
             for l in range(L):
                 Lp = engine.TE + f"bert_model.encoder.layer.{l}."
                 wn = [Lp + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
@@ -241,8 +271,8 @@ class TrainStep:
         self._pending, self._reduced = [], []
         # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
         grads = dict(g)
-        for n, t in self.frozen.items():
-            if ".pooler." not in n:
+        for n, t in self.frozen.items():      # frozen tensors the backward still passes through get scratch buffers
+            if ".pooler." not in n and (self.vision or not m.use_modal or engine.bert_needs_grad_buffer(n, self.bert_grad_from)):
                 grads[n] = torch.zeros_like(t)
         ids = sample_items_id.view(-1)
         d_item, d_user = m.dropout_cfgs()
@@ -258,9 +288,12 @@ class TrainStep:
             E, saved_b = swin_engine.swin_forward(p, prep_b, self.swin_shape, sample_items, self.dtype, True, swin_engine.IN,
                                                   d_item, m.training)
         elif m.use_modal:
+            if sample_items.shape[1] != 2 * m.args.num_words_title:
+                raise ValueError(f"token rows of width {sample_items.shape[1]}: expected [input_ids | attention_mask] of the title, "
+                                 f"2 x {m.args.num_words_title}")
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
             E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
-                                             self.bert_mask_value, engine.TE, d_item)
+                                             self.bert_mask_value, engine.TE, d_item, grad_from=self.bert_grad_from)
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
             E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
@@ -274,15 +307,12 @@ class TrainStep:
         ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
         n_valid = ci.row_valid.sum(dtype=torch.float32)
         Epool = E
-        if self.world > 1 and self.pool:
-            Epool = _all_gather_cat(E, self.world)
-            ci = engine.CeInputs(ci.row_ids, _all_gather_cat(ci.col_ids, self.world), _all_gather_cat(ci.col_logpop, self.world),
-                                 _all_gather_cat(ci.col_valid, self.world), ci.row_valid, ci.B, ci.S, self.rank * E.shape[0])
-            self._all_reduce(n_valid)
+        if self.world > 1 and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
+            Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool)
         gscale = (1.0 / n_valid).reshape(1)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
-        dE = _reduce_scatter_sum(dEpool, self.world, self.rank) if (self.world > 1 and self.pool) else dEpool
+        dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype) if (self.world > 1 and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
         dE.view(B, S + 1, D)[:, :-1, :].add_(dx.view(B, S, D))      # the two sources of dE (T/model/model.py:39-41,49)
         if dedup:   # slot gradients -> distinct-item gradients (fp32 accumulation), back to the compute dtype for the encoder
@@ -343,6 +373,87 @@ class TrainStep:
                 for grp in self.groups:
                     grp["arena"].grad.mul_(1.0 / self.world)
 
+    # -----------------------------------------------------------------------------------------------
+    def sync_shadow(self):
+        """Re-derive the bf16 shadow of every arena from its fp32 master.  The shadow is otherwise written only at
+        construction and by the AdamW kernel, and the Linear weights of the next forward / backward are read from it: call
+        this after ANY in-place write to the parameters that did not go through ``optimizer_step`` -- ``load_state_dict``
+        (checkpoint resume), manual re-initialisation, a rank-0 broadcast."""
+        for grp in self.groups:
+            a = grp["arena"]
+            if a.shadow is not None:
+                ops.cast(a.data, torch.bfloat16, out=a.shadow)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """``model.load_state_dict`` + ``sync_shadow`` (the parameters are views of the arenas, so the copy lands there)."""
+        out = self.model.load_state_dict(state_dict, strict=strict)
+        self.sync_shadow()
+        return out
+
+    def _reference_param_order(self):
+        """Trainable parameters in the order of the reference's two AdamW groups (``T/run.py:150-162``: names containing
+        ``bert_model`` first, the rest second, each in ``named_parameters()`` order; V/run.py:121-135 for the vision tower)."""
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad and ".pooler." not in n]
+        if self.vision:
+            tower = lambda n: "image_net" in n and not ("fc" in n or "classifier" in n)   # noqa: E731
+        else:
+            tower = lambda n: "bert_model" in n                                            # noqa: E731
+        g0 = [n for n, _ in named if tower(n)]
+        g1 = [n for n, _ in named if not tower(n)]
+        return [g for g in (g0, g1) if g]
+
+    def _arena_of(self, name):
+        for grp in self.groups:
+            if name in grp["arena"].offsets:
+                return grp
+        raise KeyError(name)
+
+    def optimizer_state_dict(self):
+        """The fused optimizer's state in the form of ``torch.optim.AdamW.state_dict()`` for the reference's parameter
+        groups, so that ``save_model`` / ``load_model`` (``T/data_utils/utils.py:107-114``, ``T/run.py:193-195``) and a plain
+        ``optim.AdamW`` can exchange checkpoints with a ``--fused_step`` run."""
+        state, groups, idx = {}, [], 0
+        for names in self._reference_param_order():
+            grp = self._arena_of(names[0])
+            ids = []
+            for n in names:
+                a = self._arena_of(n)["arena"]
+                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": a.view(a.exp_avg, n).detach().clone(),
+                              "exp_avg_sq": a.view(a.exp_avg_sq, n).detach().clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({"lr": grp["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": grp["wd"], "amsgrad": False,
+                           "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                           "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd):
+        order = [n for names in self._reference_param_order() for n in names]
+        ids = [i for g_ in sd["param_groups"] for i in g_["params"]]
+        if len(ids) != len(order):
+            raise ValueError(f"optimizer state holds {len(ids)} parameters, this model trains {len(order)}")
+        steps = set()
+        for i, n in zip(ids, order):
+            st = sd["state"].get(i)
+            if st is None:          # parameter never stepped
+                continue
+            a = self._arena_of(n)["arena"]
+            a.view(a.exp_avg, n).copy_(st["exp_avg"].to(a.exp_avg.device))
+            a.view(a.exp_avg_sq, n).copy_(st["exp_avg_sq"].to(a.exp_avg.device))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one step count")
+        self.step_count = steps.pop() if steps else 0
+
+    def global_loss(self, loss):
+        """With pooled negatives ``step`` returns THIS rank's share ``loss_sum_local / n_valid_global`` (the shares add up to
+        the loss of the single-process step at batch N*B); this is the SUM over ranks, for logging."""
+        if self.world > 1 and self.pool:
+            t = loss.detach().clone().reshape(1)
+            self._all_reduce(t)
+            return t[0]
+        return loss
+
     def optimizer_step(self):
         self.step_count += 1
         for grp in self.groups:
@@ -351,7 +462,8 @@ class TrainStep:
                        self.eps, grp["wd"], self.step_count)
 
     def step(self, sample_items_id, sample_items, log_mask):
-        """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling)."""
+        """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling).  Returns the loss
+        of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``."""
         loss = self.forward_backward(sample_items_id, sample_items, log_mask)
         self.reduce_gradients()
         self.optimizer_step()

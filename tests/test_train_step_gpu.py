@@ -136,3 +136,138 @@ def test_item_dedup_is_exact_without_dropout(dtype):
         den = float(a.norm()) + 1e-12
         # key-bias gradients are mathematically zero (softmax shift invariance): rounding noise only
         assert float((a - b).norm()) / den < (2e-4 if dtype == "fp32" else 6e-2) or den < (1e-6 if dtype == "fp32" else 1e-3), (n, float((a - b).norm()) / den)
+
+
+def _freeze_prefix(model, n_before):
+    """T/run.py:73-75: bert_model parameters with index < n_before (and the pooler) do not train."""
+    bert = model.bert_encoder.text_encoders["title"].bert_model
+    for index, (name, param) in enumerate(bert.named_parameters()):
+        if index < n_before or "pooler" in name:
+            param.requires_grad = False
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_frozen_prefix_stops_the_backward_and_matches_the_full_one(dtype):
+    """``--freeze_paras_before 5 + 16`` (embeddings + layer 0 of the 2-layer micro BERT frozen, the shape of the reference's default
+    165 on BERT-base): the backward stops at layer 1 -- and every trainable parameter still receives exactly the gradient the full
+    backward gives it; frozen ones are untouched by the step."""
+    from idvs.morec_amd.train_step import TrainStep
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    model_f, ids, items, lm, pop, _ = _setup(dtype)
+    model_a, *_ = _setup(dtype)
+    _freeze_prefix(model_f, 5 + 16)
+    kw = dict(lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.02)
+    ts_f, ts_a = TrainStep(model_f, **kw), TrainStep(model_a, **kw)
+    assert ts_f.bert_grad_from == 1 and ts_a.bert_grad_from == -1
+    before = {k: v.detach().clone() for k, v in model_f.state_dict().items()}
+    lf = ts_f.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
+    la = ts_a.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
+    assert abs(float(lf) - float(la)) < 1e-6
+    for n in ts_f.g:
+        if n.endswith("qkv_fused") or ".qkv_fused." in n:
+            continue
+        gf, ga = ts_f.g[n].float(), ts_a.g[n].float()
+        assert torch.equal(gf, ga), n                       # same kernels on the same inputs: bit-identical
+    ts_f.reduce_gradients(); ts_f.optimizer_step()
+    after = model_f.state_dict()
+    for n, p in model_f.named_parameters():
+        if not p.requires_grad:
+            assert torch.equal(after[n], before[n]), n
+    changed = [n for n, p in model_f.named_parameters() if p.requires_grad and not torch.equal(after[n], before[n])]
+    assert any("encoder.layer.1." in n for n in changed) and not any("encoder.layer.0." in n for n in changed)
+
+
+def test_freeze_boundary_inside_qkv_group_is_refused():
+    from idvs.morec_amd.train_step import TrainStep
+    model, *_ = _setup("fp32")
+    _freeze_prefix(model, 5 + 2)       # query.weight / query.bias frozen, key / value trainable
+    with pytest.raises(ValueError, match="q/k/v group"):
+        TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+
+
+def test_several_news_attributes_are_refused_by_the_fused_step():
+    from idvs.morec_amd.train_step import TrainStep
+    model, *_ = _setup("fp32")
+    model.args.news_attributes = ["title", "abstract"]
+    with pytest.raises(ValueError, match="news_attributes"):
+        TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+
+
+def test_sync_shadow_after_in_place_parameter_writes():
+    """bf16 mode reads the Linear weights from the arena's bf16 shadow (written by AdamW): ``load_state_dict`` / ``sync_shadow``
+    make an in-place parameter write visible to the next step; without it the step runs on the stale shadow."""
+    from idvs.morec_amd.train_step import TrainStep
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    model, ids, items, lm, pop, _ = _setup("bf16")
+    kw = dict(lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+    ts = TrainStep(model, **kw)
+    l0 = float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
+    new = {k: (v * 1.5 if ("dense.weight" in k or "w_1.weight" in k) else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(new)                       # in place, bypassing the optimizer
+    l_stale = float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
+    ts.sync_shadow()
+    l_sync = float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
+    model2, *_ = _setup("bf16")
+    model2.load_state_dict({k: v.cpu() for k, v in new.items()})
+    l_fresh = float(TrainStep(model2, **kw).forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
+    assert abs(l_sync - l_fresh) < 1e-6 and abs(l_stale - l_fresh) > 1e-4, (l0, l_stale, l_sync, l_fresh)
+    ts.load_state_dict({k: v for k, v in model2.state_dict().items()})      # the one-call form
+    assert abs(float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))) - l_fresh) < 1e-6
+
+
+def test_optimizer_state_round_trip_and_exchange_with_torch_adamw():
+    """``TrainStep.optimizer_state_dict`` has the form of ``torch.optim.AdamW.state_dict()`` over the reference's two parameter
+    groups (T/run.py:150-162): a resumed fused run continues bit-for-bit, and ``optim.AdamW`` accepts the same dict."""
+    from idvs.morec_amd.train_step import TrainStep
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    model, ids, items, lm, pop, _ = _setup("fp32")
+    kw = dict(lr=1e-3, fine_tune_lr=5e-4, l2_weight=0.01, fine_tune_l2_weight=0.02)
+    ts = TrainStep(model, **kw)
+    for _ in range(2):
+        ts.step(tdev(ids).view(-1), tdev(items), tdev(lm))
+    osd = ts.optimizer_state_dict()
+    msd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ts.step(tdev(ids).view(-1), tdev(items), tdev(lm))
+    want = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # resume in a fresh process-alike: new model + TrainStep, weights and optimizer state loaded
+    model2, *_ = _setup("fp32")
+    ts2 = TrainStep(model2, **kw)
+    ts2.load_state_dict(msd)
+    ts2.load_optimizer_state_dict(osd)
+    assert ts2.step_count == 2
+    ts2.step(tdev(ids).view(-1), tdev(items), tdev(lm))
+    for k, v in model2.state_dict().items():
+        # not bit-equal everywhere: a few gradients (token-type / position embedding rows) are summed with fp32 atomics
+        assert torch.allclose(v.cpu(), want[k], rtol=0, atol=2e-6), (k, float((v.cpu() - want[k]).abs().max()))
+    # the same dict in torch's optimizer, parameter groups as the reference builds them
+    named = [(n, p) for n, p in model2.named_parameters() if p.requires_grad and ".pooler." not in n]
+    groups = [{"params": [p for n, p in named if "bert_model" in n], "lr": 5e-4, "weight_decay": 0.02},
+              {"params": [p for n, p in named if "bert_model" not in n], "lr": 1e-3, "weight_decay": 0.01}]
+    opt = torch.optim.AdamW(groups)
+    opt.load_state_dict(osd)
+    n0 = [n for n, _ in named if "bert_model" in n][3]
+    a = ts._arena_of(n0)["arena"]
+    st = opt.state[dict(named)[n0]]
+    assert float(st["step"]) == 2.0
+    # osd was exported after step 2; ts has since taken step 3, so compare with the exported tensors themselves
+    idx = [n for n, _ in named if "bert_model" in n].index(n0)
+    assert torch.equal(st["exp_avg"].cpu(), osd["state"][idx]["exp_avg"].cpu())
+
+
+def test_short_last_batch_runs_through_the_same_step():
+    """DistributedSampler + DataLoader without drop_last (T/run.py:114,123-124): the last batch of an epoch is short -- the batch
+    size is not a constant of TrainStep."""
+    from idvs.morec_amd.train_step import TrainStep
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    model, ids, items, lm, pop, (S, D, shape) = _setup("fp32")
+    model_b, *_ = _setup("fp32")
+    kw = dict(lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+    ts, ts_b = TrainStep(model, **kw), TrainStep(model_b, **kw)
+    B = ids.shape[0]
+    T2 = items.shape[1]
+    it3 = items.reshape(B, S + 1, T2)
+    ts.step(tdev(ids).view(-1), tdev(items), tdev(lm))                                    # full batch first ...
+    l_short = float(ts.forward_backward(tdev(ids[:4]).view(-1), tdev(it3[:4].reshape(-1, T2)), tdev(lm[:4])))   # ... then 4 of 9
+    ts_b.step(tdev(ids).view(-1), tdev(items), tdev(lm))
+    l_ref = float(ts_b.forward_backward(tdev(ids[:4].copy()).view(-1), tdev(it3[:4].reshape(-1, T2).copy()), tdev(lm[:4].copy())))
+    assert np.isfinite(l_short) and abs(l_short - l_ref) < 1e-6
