@@ -96,6 +96,7 @@ _SIGS = {
     "morec_swin_pool_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_bias_residual": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_droppath_scale": (C.c_int, [_P, C.c_int, C.c_float, C.c_uint64, _P]),
+    "morec_image_resize_u8": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -39,6 +39,8 @@ def collate_train_batch(u2seq, users, item_content, max_seq_len, use_modal):
         seq = u2seq[u]
         ids[r, L - len(seq):] = seq
         log_mask[r, L - len(seq):] = 1.0
+    if use_modal and hasattr(item_content, "device_batch"):      # vision catalogue in the reference's LMDB (data_utils/images.py)
+        return torch.from_numpy(ids), item_content.device_batch(ids, "cuda"), torch.from_numpy(log_mask)
     items = np.asarray(item_content)[ids] if use_modal else ids
     items = torch.from_numpy(np.ascontiguousarray(items))
     if items.dtype != torch.uint8:          # uint8 = decoded images of the vision variant (normalised on the device)

@@ -1,0 +1,176 @@
+"""Host half of the vision input pipeline: the reference's on-disk image format and the tables the device-side
+resize needs.
+
+* ``LmdbImageStore`` reads what ``dataset/HM/build_lmdb_hm.py:13-66`` writes: an LMDB whose values are pickled ``LMDB_Image``
+  objects (``channels``, ``size`` = (H, W), ``image`` = raw RGB bytes, ``id``) keyed by the ascii item id, plus ``__keys__`` /
+  ``__len__``; ``V/data_utils/dataset.py:61-66,91-97`` opens it read-only and unpickles one record per sequence slot.
+  The ``lmdb`` module is optional (it is not part of this image): any object with ``get(key) -> bytes`` can stand in.
+* ``resize_table`` / ``pack_images``: what ``ops.image_resize_u8`` (``morec_image_resize_u8``) consumes -- the reference resizes
+  each image on the host with ``tv.transforms.Resize((R, R))`` (Pillow BILINEAR), here the DECODED uint8 images cross PCIe at
+  their native size and are resampled on the GPU with the same fixed-point taps."""
+from __future__ import annotations
+
+import io
+import math
+import os
+import pickle
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2          # Pillow Resample.c: 8-bit images
+
+
+class LMDB_Image:
+    """Field-for-field the record class of ``dataset/HM/build_lmdb_hm.py:13-22`` / ``V/data_utils/dataset.py:16-25``."""
+
+    def __init__(self, image, id):
+        self.channels = image.shape[2]
+        self.size = image.shape[:2]
+        self.image = image.tobytes()
+        self.id = id
+
+    def get_image(self):
+        image = np.frombuffer(self.image, dtype=np.uint8)
+        return image.reshape(*self.size, self.channels)
+
+
+class _RecordUnpickler(pickle.Unpickler):
+    """The builder pickles ``__main__.LMDB_Image`` (it runs as a script) and the reference unpickles with that name imported into
+    ITS ``__main__``; here any ``LMDB_Image`` resolves to the class above, wherever it was defined."""
+
+    def find_class(self, module, name):
+        if name == "LMDB_Image":
+            return LMDB_Image
+        return super().find_class(module, name)
+
+
+def decode_record(blob: bytes) -> np.ndarray:
+    """One LMDB value -> uint8 [H, W, 3] (``IMAGE.get_image()``; the reference then does ``.convert('RGB')`` on an RGB array)."""
+    rec = _RecordUnpickler(io.BytesIO(blob)).load()
+    img = rec.get_image()
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise ValueError(f"record {getattr(rec, 'id', '?')}: expected RGB, got shape {img.shape}")
+    return img
+
+
+class LmdbImageStore:
+    """``V/data_utils/dataset.py:61-66``: ``lmdb.open(db_path, subdir=isdir, readonly=True, lock=False, readahead=False,
+    meminit=False)``; ``__len__`` / ``__keys__`` read once."""
+
+    def __init__(self, db_path=None, backend=None):
+        if backend is None:
+            try:
+                import lmdb
+            except ImportError as e:            # noqa: F841
+                raise ImportError("the `lmdb` module is needed to open an image database (pip package `lmdb`); it is not part of this "
+                                  "image -- pass backend=<object with get(key) -> bytes> or use --images_npy") from None
+            self._env = lmdb.open(db_path, subdir=os.path.isdir(db_path), readonly=True, lock=False, readahead=False, meminit=False)
+            self._txn = self._env.begin()
+            backend = self._txn
+        self._kv = backend
+        self.length = pickle.loads(self._kv.get(b"__len__"))
+        self.keys = pickle.loads(self._kv.get(b"__keys__"))
+
+    def __len__(self):
+        return self.length
+
+    def image(self, key: bytes) -> np.ndarray:
+        blob = self._kv.get(key)
+        if blob is None:
+            raise KeyError(key)
+        return decode_record(blob)
+
+    def batch(self, keys) -> list:
+        """Decoded images of one training batch; ``None`` key (padding slot: the reference leaves an all-zero tensor there,
+        ``V/data_utils/dataset.py:88``) -> a 1 x 1 mid-grey image (the slot reaches nothing in the loss)."""
+        pad = np.full((1, 1, 3), 128, dtype=np.uint8)
+        return [pad if k is None else self.image(k) for k in keys]
+
+
+def _bilinear(x: float) -> float:
+    x = -x if x < 0.0 else x
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+_TABLES = {}
+
+
+def resize_table(in_size: int, out_size: int) -> np.ndarray:
+    """Pillow ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (BILINEAR, full box) as one int32 array: ``[ksize]`` followed by
+    ``out_size`` rows ``(first input index, tap count, taps[ksize])``.  Python floats are IEEE doubles, the arithmetic is written
+    in Pillow's order; cached per (in_size, out_size)."""
+    key = (int(in_size), int(out_size))
+    t = _TABLES.get(key)
+    if t is not None:
+        return t
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    tab = np.zeros(1 + out_size * (2 + ksize), dtype=np.int32)
+    tab[0] = ksize
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bilinear((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        row = 1 + xx * (2 + ksize)
+        tab[row], tab[row + 1] = xmin, xmax
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            tab[row + 2 + x] = int(-0.5 + v * (1 << PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PRECISION_BITS))
+    _TABLES[key] = tab
+    return tab
+
+
+def pack_images(images, R: int):
+    """list of uint8 [H, W, 3] arrays -> (flat uint8 bytes, int64 meta [n, 5], int32 tables) for ``morec_image_resize_u8``."""
+    tabs, tab_off, off = [], {}, 0
+
+    def table(size):
+        nonlocal off
+        if size not in tab_off:
+            t = resize_table(size, R)
+            tab_off[size] = off
+            tabs.append(t)
+            off += t.size
+        return tab_off[size]
+
+    meta = np.zeros((len(images), 5), dtype=np.int64)
+    pos = 0
+    for i, im in enumerate(images):
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError(f"image {i}: expected uint8 [H, W, 3], got {im.dtype} {im.shape}")
+        H, W = im.shape[:2]
+        meta[i] = (pos, H, W, table(W), table(H))
+        pos += H * W * 3
+    flat = np.empty(pos, dtype=np.uint8)
+    for i, im in enumerate(images):
+        flat[meta[i, 0]:meta[i, 0] + im.size] = im.reshape(-1)
+    return flat, meta, np.concatenate(tabs)
+
+
+class LmdbItemImages:
+    """The item catalogue of a vision run read straight from the reference's LMDB: indexable by item id like the ``item_content``
+    arrays of the other towers, but an access decodes the records and resamples them ON THE DEVICE (``ops.image_resize_u8``).
+    ``item_id_to_keys``: ``read_images`` / ``read_behaviors`` output (id 0 = padding item, no key)."""
+
+    def __init__(self, store: LmdbImageStore, item_id_to_keys: dict, R: int):
+        self.store, self.keys, self.R = store, item_id_to_keys, R
+        self.n = max(item_id_to_keys) + 1 if item_id_to_keys else 1
+
+    def __len__(self):
+        return self.n
+
+    def device_batch(self, ids, device):
+        """item ids (any shape, numpy) -> uint8 [*ids.shape, R, R, 3] on ``device``."""
+        from .. import ops
+        flat = np.asarray(ids).reshape(-1)
+        imgs = self.store.batch([self.keys.get(int(i)) if int(i) != 0 else None for i in flat])
+        out = ops.image_resize_u8(imgs, self.R, device)
+        return out.view(*np.asarray(ids).shape, self.R, self.R, 3)

@@ -28,6 +28,13 @@ def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, l
     vision = bool(use_modal and getattr(m, "vision", False))
     # vision (``get_itemLMDB_embeddings``, V/data_utils/metrics.py:63-76): ``item_content`` is the decoded image tensor
     # f32[item_num+1, 3, R, R] (the LMDB / PIL decode of V/data_utils/dataset.py is host-side I/O outside this library)
+    if hasattr(item_content, "device_batch"):       # LmdbItemImages: records decoded per chunk, resized on the device
+        outs = []
+        with torch.no_grad():
+            for s in range(0, len(item_content), test_batch_size):
+                ids = np.arange(s, min(len(item_content), s + test_batch_size))
+                outs.append(m.cv_encoder(item_content.device_batch(ids, local_rank).contiguous()))
+        return torch.cat(outs, 0).float().detach()
     content = torch.as_tensor(np.asarray(item_content))
     if not vision:
         content = content.long()

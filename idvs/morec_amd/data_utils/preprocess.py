@@ -103,3 +103,18 @@ def get_doc_input_bert(item_id_to_content, args):
             mask[item_id] = enc["attention_mask"]
         out += [ids, mask]
     return tuple(out)
+
+
+def read_images(images_path):
+    """``V/data_utils/preprocess.py:88-101``: one item name per line (``v<int>``) -> ids 1.. in file order and the LMDB key of each
+    (the ascii decimal of the name's integer, as ``dataset/HM/build_lmdb_hm.py:44-50`` wrote it)."""
+    item_id_to_keys, item_name_to_id, item_id_to_name = {}, {}, {}
+    index = 1
+    with open(images_path, "r") as f:
+        for line in f:
+            image_name = line.strip("\n").split("\t")[0]
+            item_name_to_id[image_name] = index
+            item_id_to_name[index] = image_name
+            item_id_to_keys[index] = u"{}".format(int(image_name.replace("v", ""))).encode("ascii")
+            index += 1
+    return item_id_to_keys, item_name_to_id, item_id_to_name

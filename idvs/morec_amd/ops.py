@@ -399,3 +399,20 @@ def probe(device="cuda"):
     out = torch.zeros(4096, device=device, dtype=torch.int32)
     check(_lib.lib().morec_probe(_p(out), _stream()), "morec_probe")
     return out
+
+
+def image_resize_u8(images, R: int, device=None):
+    """Decoded uint8 [H, W, 3] images of arbitrary sizes (numpy arrays) -> uint8 [n, R, R, 3] on the device: one pinned H2D
+    copy of the packed bytes + ``morec_image_resize_u8`` (Pillow's BILINEAR resampler, bit for bit -- what the reference's
+    dataloader workers do per image with ``tv.transforms.Resize``, ``V/data_utils/dataset.py:68-73``)."""
+    from .data_utils.images import pack_images
+    device = torch.device("cuda") if device is None else torch.device(device)
+    if device.type != "cuda":
+        raise _lib.MorecError("libmorec_hip needs device tensors (no CPU fallback)")
+    flat, meta, tabs = pack_images(images, R)
+    src = torch.from_numpy(flat).pin_memory().to(device, non_blocking=True)
+    meta_d = torch.from_numpy(meta).to(device, non_blocking=True)
+    tabs_d = torch.from_numpy(tabs).to(device, non_blocking=True)
+    out = torch.empty((len(images), R, R, 3), device=device, dtype=torch.uint8)
+    check(_lib.lib().morec_image_resize_u8(_p(src), _p(meta_d), _p(tabs_d), _p(out), len(images), R, _stream()), "morec_image_resize_u8")
+    return out

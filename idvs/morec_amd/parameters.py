@@ -46,6 +46,8 @@ def build_parser():
     # ============== vision variant (V/parameters.py:34-39) ==============
     p.add_argument("--CV_model_load", type=str, default="None", help="swin_tiny | swin_small | swin_base (vision item tower)")
     p.add_argument("--CV_resize", type=int, default=224)
+    p.add_argument("--image_lmdb", type=str, default="None", help="LMDB of pickled LMDB_Image records (dataset/HM/build_lmdb_hm.py; "
+                   "V/parameters.py --lmdb_data): decoded per batch, resized on the GPU; needs the optional `lmdb` module")
     p.add_argument("--images_npy", type=str, default="None",
                    help="uint8 array [item_num + 1, R, R, 3] of decoded, resized item images (row 0 = padding item); stands in for the "
                         "LMDB reader of V/data_utils/dataset.py, whose lmdb / torchvision dependencies are not part of this package")

@@ -134,8 +134,14 @@ def train(args, use_modal, local_rank):
             os.path.join(args.root_data_dir, args.dataset, args.behaviors), a, b, c, S, args.min_seq_len, Log)
         tables = get_doc_input_bert(item_id_to_dic, args)
         item_content = np.concatenate([x for x in tables if x is not None], axis=1)
-    elif vision:
-        raise SystemExit("vision runs on real data read the item images through --images_npy or --image_lmdb (data_utils.images)")
+    elif vision:                                                         # V/run.py:62-80: item list -> LMDB keys, images from the LMDB
+        from .data_utils import LmdbImageStore, LmdbItemImages, read_images
+        if args.image_lmdb == "None":
+            raise SystemExit("vision run on real data: --image_lmdb <the LMDB of dataset/HM/build_lmdb_hm.py> (or --synthetic N --images_npy ...)")
+        a, b, c = read_images(os.path.join(args.root_data_dir, args.dataset, args.news))
+        item_num, id2key, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(
+            os.path.join(args.root_data_dir, args.dataset, args.behaviors), a, b, c, S, args.min_seq_len, Log)
+        item_content = LmdbItemImages(LmdbImageStore(os.path.join(args.root_data_dir, args.dataset, args.image_lmdb)), id2key, args.CV_resize)
     else:
         a, b, c = read_news(os.path.join(args.root_data_dir, args.dataset, args.news))
         item_num, _, users_train, users_valid, users_test, hist_valid, hist_test, _, pop = read_behaviors(

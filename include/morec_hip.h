@@ -287,6 +287,16 @@ int morec_dropout_keep_mask(uint8_t* out, size_t n, float p, uint64_t seed, void
 /* diagnostics: dumps MFMA fragment layouts and ds_read_b64_tr_b16 semantics into out (int32[4096]) */
 int morec_probe(int32_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Vision input pipeline, device half: n decoded uint8 HWC images of arbitrary sizes, packed back to back
+ * in `src`, -> uint8 [n, R, R, 3], bit for bit the reference's host-side tv.transforms.Resize((R, R)) on the PIL image
+ * (V/data_utils/dataset.py:68-73,91-98 = Pillow's two-pass BILINEAR resampler).  meta: int64 [n][5] = byte offset in src, H, W,
+ * offset (in int32 words) of the horizontal and of the vertical tap table in `tables`; a table = ksize, then R rows of
+ * (first input index, tap count, taps[ksize]) in Pillow's 2^22 fixed point (host: data_utils/images.py::resize_table).
+ * ToTensor + Normalize(0.5, 0.5) are fused into morec_swin_patchify_u8.
+ * ------------------------------------------------------------------------------------------ */
+int morec_image_resize_u8(const uint8_t* src, const int64_t* meta, const int32_t* tables, uint8_t* out, int n, int R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
