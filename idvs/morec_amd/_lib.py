@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmorec_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+DACT_MUL = 3      # morec_gemm_desc.dact: multiply by dact_in (which holds act'(pre): aux_deriv outputs)
 
 
 class MorecError(RuntimeError):
@@ -27,7 +28,7 @@ class MorecError(RuntimeError):
 class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
                 ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int), ("dact", C.c_int),
-                ("accumulate", C.c_int), ("split_k", C.c_int), ("alpha", C.c_float)]
+                ("accumulate", C.c_int), ("split_k", C.c_int), ("alpha", C.c_float), ("aux_deriv", C.c_int)]
 
 
 class AttnDesc(C.Structure):

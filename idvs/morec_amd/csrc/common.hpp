@@ -176,6 +176,30 @@ __device__ __forceinline__ void gelu4(float (&v)[4]) {
         v[2 * q] = r[0]; v[2 * q + 1] = r[1];
     }
 }
+// v[k] = gelu'(v[k])
+__device__ __forceinline__ void dgelu4(float (&v)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2_t x = {v[2 * q], v[2 * q + 1]};
+        f32x2_t cdf, e;
+        gelu_parts2(x, cdf, e);
+        const f32x2_t d = (x * 0.39894228040143267794f) * e + cdf;
+        v[2 * q] = d[0]; v[2 * q + 1] = d[1];
+    }
+}
+// v[k] = gelu(v[k]), d[k] = gelu'(v[k]): one evaluation of the shared erf / exp for both
+__device__ __forceinline__ void gelu4_with_deriv(float (&v)[4], float (&d)[4]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2_t x = {v[2 * q], v[2 * q + 1]};
+        f32x2_t cdf, e;
+        gelu_parts2(x, cdf, e);
+        const f32x2_t g = x * cdf;
+        const f32x2_t dd = (x * 0.39894228040143267794f) * e + cdf;
+        v[2 * q] = g[0]; v[2 * q + 1] = g[1];
+        d[2 * q] = dd[0]; d[2 * q + 1] = dd[1];
+    }
+}
 // v[k] *= gelu'(u[k])
 __device__ __forceinline__ void dgelu4_mul(float (&v)[4], const float (&u)[4]) {
 #pragma unroll

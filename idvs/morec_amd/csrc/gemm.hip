@@ -52,14 +52,27 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
         } else if constexpr (ACT == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        } else if constexpr (ACT == 3 || ACT == 4) {
+        } else if constexpr (ACT == 3 || ACT == 4 || ACT == 5) {
             float u[4];
             io<TO>::load4(din + (size_t)m * p.ldc + n, u);
             if constexpr (ACT == 3) {
                 dgelu4_mul(v, u);
-            } else {
+            } else if constexpr (ACT == 4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= u[r];
+            }
+        }
+        if constexpr (ACT == 1 || ACT == 2) {       // aux_out = act'(pre) instead of pre (morec_gemm_desc.aux_deriv)
+            if (p.aux_deriv) {
+                if constexpr (ACT == 1) {
+                    dgelu4(pre);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[r] = pre[r] > 0.f ? 1.f : 0.f;
+                }
             }
         }
     };
@@ -180,6 +193,16 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
                                 pre[0] += b.x; pre[1] += b.y; pre[2] += b.z; pre[3] += b.w;
                             }
                         }
+                        if constexpr (ACT == 1 || ACT == 2) {
+                            if (p.aux_deriv) {
+                                if constexpr (ACT == 1) {
+                                    dgelu4(pre);
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) pre[r] = pre[r] > 0.f ? 1.f : 0.f;
+                                }
+                            }
+                        }
                         char* l = smem + (wm * MIP * 16 + ml * 16 + c16) * ROWB + (wn * G::NI * 16 + ni * 16 + g4 * 4) * (int)sizeof(TO);
                         io<TO>::store4(reinterpret_cast<TO*>(l), pre);
                     }
@@ -276,8 +299,8 @@ static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
 
 template <typename G, typename TI, typename TO>
 static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
-    const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->act == MOREC_ACT_GELU ? 1
-                     : d->act == MOREC_ACT_RELU ? 2 : 0;
+    const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
+                     : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;
     if constexpr (sizeof(TI) != sizeof(TO)) {     // bf16 operands -> fp32 output: only the linear epilogue is used
         if (mode != 0 || a.colsum) return MOREC_E_UNSUPPORTED;
         return launch_gemm_act<G, TI, TO, 0>(d, a, s);
@@ -285,6 +308,7 @@ static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
         if (a.colsum) {     // fused bias gradient: only behind the activation-derivative epilogues
             if (mode == 3) return launch_gemm_act<G, TI, TO, 3, true>(d, a, s);
             if (mode == 4) return launch_gemm_act<G, TI, TO, 4, true>(d, a, s);
+            if (mode == 5) return launch_gemm_act<G, TI, TO, 5, true>(d, a, s);
             return MOREC_E_UNSUPPORTED;
         }
         switch (mode) {
@@ -292,6 +316,7 @@ static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
             case 2: return launch_gemm_act<G, TI, TO, 2>(d, a, s);
             case 3: return launch_gemm_act<G, TI, TO, 3>(d, a, s);
             case 4: return launch_gemm_act<G, TI, TO, 4>(d, a, s);
+            case 5: return launch_gemm_act<G, TI, TO, 5>(d, a, s);
             default: return launch_gemm_act<G, TI, TO, 0>(d, a, s);
         }
     }
@@ -349,6 +374,8 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux_out = aux_out; a.dact_in = dact_in;
     a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.act = d->act; a.dact = d->dact; a.accumulate = d->accumulate; a.alpha = d->alpha;
+    a.aux_deriv = d->aux_deriv;
+    if (d->aux_deriv && (d->act == MOREC_ACT_NONE || !aux_out)) return MOREC_E_ARG;
     a.colsum = colsum_out ? workspace : nullptr;
     a.colsum_dst = colsum_out;
     {   // epilogue form: per-wave LDS slices without workgroup barriers pay off where the epilogue is heavy (GELU + the second

@@ -329,7 +329,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
     const int ext = (int)min(tile_bytes, 0x7fffffffL);
     const size_t tile_off = (size_t)m0 * p.ldc;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(C + tile_off), 0, ext, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(((ACT == 3 || ACT == 4) ? din : C) + tile_off), 0, ext, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(((ACT >= 3) ? din : C) + tile_off), 0, ext, 0x00020000);
     auto lane_off = [&](int ps) {    // byte offset of (row rs_row, this lane's column of pass ps) from (tile row 0, column 0)
         const int n = nw + ps * PC + rs_slot * EPV;
         return n < p.N ? (uint32_t)((rs_row * p.ldc + n) * ES) : 0x80000000u;
@@ -383,7 +383,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
             for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(bp + min(nw + Ni * 32 + g * 8 + 4 * h, p.N - 4));
     }
     Vecs dq = Vecs();   // the activation-derivative operand, fetched one pass ahead
-    if constexpr (ACT == 3 || ACT == 4) dq = rows_fetch(rD, 0, lo[0]);
+    if constexpr (ACT >= 3) dq = rows_fetch(rD, 0, lo[0]);
     pin();
 
     // ---- next tile: its prologue flies under this tile's epilogue.  Issued UNCONDITIONALLY (after the last tile it re-reads that
@@ -414,29 +414,75 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             pin();      // nothing of this pass may be computed ahead of the previous one (128 fresh values on top of the accumulators)
-            if constexpr (ACT == 3 || ACT == 4) {
+            if constexpr (ACT >= 3) {
                 rows_put(dq);
                 constexpr int LAST = 4 * NPASS - 1;
                 const int nx = Mi * NPASS + ps + 1;
                 if (nx <= LAST) dq = rows_fetch(rD, nx / NPASS, lo[nx % NPASS]);
                 wfence();
             }
-            if (aux) {      // pre-activation out first (wave-uniform branch around LDS traffic and stores only)
+            if (aux) {      // second output first (wave-uniform branch): the pre-activation, or act'(pre) with aux_deriv
+                if constexpr (ACT == 1 || ACT == 2) {
+                    // one evaluation of the activation serves both outputs: the results are parked as packed bf16 (16 registers)
+                    // while the slice carries the second output to its rows
+                    static_assert(ES == 2, "activation epilogues are instantiated for bf16 outputs");
+                    uint2 park[NG];
 #pragma unroll
-                for (int q = 0; q < NG; ++q) {
-                    const int Ni = ES == 2 ? q / 4 : ps, g = ES == 2 ? q % 4 : q;
-                    const float4 b = bv[Ni][g];
-                    float pre[4];
-                    pre[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
-                    pre[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
-                    pre[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
-                    pre[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
-                    io<TO>::store4(cell(q), pre);
-                    if (q & 1) pin();      // keeps the scheduler from computing every group ahead of the first store (VGPR pressure)
+                    for (int q = 0; q < NG; ++q) {
+                        const int Ni = q / 4, g = q % 4;
+                        const float4 b = bv[Ni][g];
+                        float v[4], d[4];
+                        v[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
+                        v[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
+                        v[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
+                        v[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = v[r];
+                        if (p.aux_deriv) {
+                            if constexpr (ACT == 1) {
+                                gelu4_with_deriv(v, d);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { d[r] = v[r] > 0.f ? 1.f : 0.f; v[r] = fmaxf(v[r], 0.f); }
+                            }
+                        } else {
+                            if constexpr (ACT == 1) {
+                                gelu4(v);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            }
+                        }
+                        io<TO>::store4(cell(q), d);
+                        park[q] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        if (q & 1) pin();      // keeps the scheduler from computing every group ahead of the first store (VGPR pressure)
+                    }
+                    wfence();
+                    rows_store(__builtin_amdgcn_make_buffer_rsrc((void*)(aux + tile_off), 0, ext, 0x00020000), Mi, lo[ps]);
+                    wfence();
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) *reinterpret_cast<uint2*>(cell(q)) = park[q];
+                    wfence();
+                    rows_store(rC, Mi, lo[ps]);
+                    wfence();
+                    continue;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) {
+                        const int Ni = ES == 2 ? q / 4 : ps, g = ES == 2 ? q % 4 : q;
+                        const float4 b = bv[Ni][g];
+                        float pre[4];
+                        pre[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
+                        pre[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
+                        pre[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
+                        pre[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
+                        io<TO>::store4(cell(q), pre);
+                        if (q & 1) pin();
+                    }
+                    wfence();
+                    rows_store(__builtin_amdgcn_make_buffer_rsrc((void*)(aux + tile_off), 0, ext, 0x00020000), Mi, lo[ps]);
+                    wfence();
                 }
-                wfence();
-                rows_store(__builtin_amdgcn_make_buffer_rsrc((void*)(aux + tile_off), 0, ext, 0x00020000), Mi, lo[ps]);
-                wfence();
             }
 #pragma unroll
             for (int q = 0; q < NG; ++q) {      // a lane's cells are its own: the derivative operand is read and replaced in place
@@ -452,14 +498,17 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
                 } else if constexpr (ACT == 2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                } else if constexpr (ACT == 3 || ACT == 4) {
+                } else if constexpr (ACT >= 3) {
                     float u[4];
                     io<TO>::load4(cell(q), u);
                     if constexpr (ACT == 3) {
                         dgelu4_mul(v, u);
-                    } else {
+                    } else if constexpr (ACT == 4) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (u[r] > 0.f) ? v[r] : 0.f;
+                    } else {        // MOREC_DACT_MUL: the operand already holds act'(pre)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= u[r];
                     }
                 }
                 if constexpr (CS) {     // rows past M hold copies of row M - 1 (clamped loads): keep them out of the column sums
@@ -570,8 +619,8 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (a.colsum && d->M < 128) return G8_NOT_TAKEN;      // partial-row workspace is sized per 64 rows
     // automatic: enough tiles to fill the 256 CUs, and at most 15 % of the tile columns past N
     if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 115L)) return G8_NOT_TAKEN;
-    const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->act == MOREC_ACT_GELU ? 1
-                     : d->act == MOREC_ACT_RELU ? 2 : 0;
+    const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
+                     : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;
     a.debug = g_debug8p;
     a.stamps = reinterpret_cast<unsigned long long*>(g_stamps);
     if (d->out_dtype == MOREC_F32) {
@@ -582,6 +631,7 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (a.colsum) {
         if (mode == 3) return launch8p<bf16, 3, true>(d, a, s);
         if (mode == 4) return launch8p<bf16, 4, true>(d, a, s);
+        if (mode == 5) return launch8p<bf16, 5, true>(d, a, s);
         return G8_NOT_TAKEN;
     }
     switch (mode) {
@@ -589,6 +639,7 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
         case 2: return launch8p<bf16, 2, false>(d, a, s);
         case 3: return launch8p<bf16, 3, false>(d, a, s);
         case 4: return launch8p<bf16, 4, false>(d, a, s);
+        case 5: return launch8p<bf16, 5, false>(d, a, s);
         default: return launch8p<bf16, 0, false>(d, a, s);
     }
 }

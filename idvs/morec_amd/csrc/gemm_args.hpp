@@ -12,6 +12,7 @@ struct GemmArgs {
     const void* dact_in;
     int M, N, K, lda, ldb, ldc;
     int act, dact, accumulate;
+    int aux_deriv;   // aux_out receives act'(pre) instead of pre
     int kchunk;
     int tiles_m, tiles_n;
     float alpha;

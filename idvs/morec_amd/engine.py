@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
-from ._lib import ACT_GELU, ACT_RELU
+from ._lib import ACT_GELU, ACT_RELU, DACT_MUL
 
 
 @dataclass
@@ -102,7 +102,9 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
 def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
                   drop: DropCfg = NO_DROP, site0: int = 0, cu=None):
     """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b.
-    Dropout sites of a layer: site0 = attention probabilities, site0+1 = attention sub-layer output, site0+2 = FFN output."""
+    Dropout sites of a layer: site0 = attention probabilities, site0+1 = attention sub-layer output, site0+2 = FFN output.
+    The FFN's first GEMM leaves the activation's DERIVATIVE act'(x1 W1^T + b1) beside its output (one erf / exp evaluation serves
+    both), so the backward's dU = (dZ W2) * act' is a plain multiply in that GEMM's epilogue."""
     dh = cfg.H // cfg.heads
     desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
                          drop.p_attn, drop.site(site0), cu)
@@ -113,7 +115,7 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True,
                                              p_in=ph, seed_in=s1)
     u = torch.empty((x0.shape[0], w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
-    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u)
+    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
     x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
                                              p_in=ph, seed_in=s2)
@@ -130,7 +132,7 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict, need_dx
     dz2, dzd2 = ops.layernorm_bwd(dx2_a, dx2_b, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
                                   dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
-    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # + d(b1)
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=DACT_MUL, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # x act', + d(b1)
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=x1.shape[1])
     dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,
@@ -181,7 +183,7 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
                                              p_in=ph, seed_in=s1)
     u = torch.empty((n_seq, w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
-    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u)
+    g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
     x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
                                              p_in=ph, seed_in=s2)
@@ -197,7 +199,7 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     dz2, dzd2 = ops.layernorm_bwd(dx2_c, None, z2, mean2, rstd2, w["ln2_g"], g["ln2_g"], g["ln2_b"], p_in=ph, seed_in=s2,
                                   dbias=g.get("b2"))
     linear_wgrad_(dzd2, gact, g["f2"])
-    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=cfg.act, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # + d(b1)
+    du = ops.gemm_nt(dzd2, w["f2"].wt, dact=DACT_MUL, dact_in=u, K=dzd2.shape[1], N=u.shape[1], colsum_out=g.get("b1"))   # x act', + d(b1)
     linear_wgrad_(du, x1, g["f1"])
     dx1 = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=H)
     dz1, dzd1 = ops.layernorm_bwd(dx1, dz2, z1, mean1, rstd1, w["ln1_g"], g["ln1_g"], g["ln1_b"], p_in=ph, seed_in=s1,

@@ -47,7 +47,8 @@ _CS_WS = {}      # per-device fp32 scratch of the fused column sums (stream-orde
 
 
 def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=None, dact=ACT_NONE, dact_in=None,
-            accumulate=0, split_k=1, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, colsum_out=None):
+            accumulate=0, split_k=1, alpha=1.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None, colsum_out=None,
+            aux_deriv=False):
     """out[M,N] (+)= alpha * a[M,K] @ b[N,K]^T with the fused epilogues of ``morec_gemm_nt``; ``colsum_out`` (fp32 [N],
     ``dact`` epilogues only) additionally receives ``+= out.sum(0)``: the bias gradient of the layer below."""
     _dev(a), _dev(b)
@@ -59,7 +60,7 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     ldc = out.stride(0) if ldc is None else ldc
-    d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha)
+    d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
     if colsum_out is not None:
         need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4
         ws = _CS_WS.get(a.device)

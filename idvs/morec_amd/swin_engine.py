@@ -16,7 +16,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
-from ._lib import ACT_GELU
+from ._lib import ACT_GELU, DACT_MUL
 from .engine import NO_DROP, DropCfg, linear_wgrad_, prepare_linear
 
 IN = "cv_encoder.image_net."
@@ -175,7 +175,7 @@ def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, n
                                                     bias=p[L + "attention.o_proj.bias"], res=x, z_inplace=True,
                                                     rowscale=scale, rows_per_scale=tokens)
             pre = torch.empty((x.shape[0], w["f1"].w.shape[0]), device=x.device, dtype=dtype) if need_grad else None
-            g = ops.gemm_nt(hn, w["f1"].w, bias=p[L + "mlp.fc1.bias"], act=ACT_GELU, aux_out=pre)
+            g = ops.gemm_nt(hn, w["f1"].w, bias=p[L + "mlp.fc1.bias"], act=ACT_GELU, aux_out=pre, aux_deriv=need_grad)   # pre = GELU'(fc1)
             f = ops.gemm_nt(g, w["f2"].w)
             pending = (f, p[L + "mlp.fc2.bias"], h)
             saved_blocks.append((desc, bias_t, x, xn, mean1, rstd1, qkv, ctx, h, hn, mean2, rstd2, pre, g, scale, tokens))
@@ -239,7 +239,7 @@ def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             desc, bias_t, x, xn, mean1, rstd1, qkv, ctx, h, hn, mean2, rstd2, pre, g, scale, tokens = saved_stages[s][b]
             # MLP branch: out = h + fc2(gelu(fc1(LN2(h)))) + b2
             linear_wgrad_(dout, g, grads[L + "mlp.fc2.weight"])
-            du = ops.gemm_nt(dout, w["f2"].wt, dact=ACT_GELU, dact_in=pre, K=dout.shape[1], N=pre.shape[1],
+            du = ops.gemm_nt(dout, w["f2"].wt, dact=DACT_MUL, dact_in=pre, K=dout.shape[1], N=pre.shape[1],
                              colsum_out=grads[L + "mlp.fc1.bias"])
             linear_wgrad_(du, hn, grads[L + "mlp.fc1.weight"])
             dhn = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=C)

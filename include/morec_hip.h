@@ -40,6 +40,7 @@ extern "C" {
 #define MOREC_ACT_NONE 0
 #define MOREC_ACT_GELU 1 /* exact erf GELU (HF BertIntermediate; T/model/encoders.py:59 nn.GELU) */
 #define MOREC_ACT_RELU 2 /* T/model/modules.py:12 */
+#define MOREC_DACT_MUL 3 /* morec_gemm_desc.dact only: C = acc * dact_in[m,n] (dact_in already holds act'(pre), see aux_deriv) */
 
 const char* morec_strerror(int code);
 int morec_version(void);
@@ -65,6 +66,8 @@ typedef struct {
     int accumulate;    /* 0: C = v   1: C += v (non-atomic)   2: atomicAdd (fp32 C only; used with split_k) */
     int split_k;       /* >= 1: K is cut into split_k chunks over blockIdx.z (requires accumulate == 2 when > 1) */
     float alpha;
+    int aux_deriv;     /* 1: aux_out receives act'(acc + bias) instead of acc + bias -- the backward GEMM then runs with
+                        * dact = MOREC_DACT_MUL (one multiply per element instead of re-evaluating erf / exp for GELU') */
 } morec_gemm_desc;
 
 int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,

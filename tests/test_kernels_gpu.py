@@ -82,6 +82,41 @@ def test_gemm_epilogues(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("shape", [(260, 384, 256), (5000, 3072, 768)])
+@pytest.mark.parametrize("act", [ACT_GELU, ACT_RELU])
+def test_gemm_activation_derivative_pair(dt, shape, act):
+    """``aux_deriv`` forward + ``MOREC_DACT_MUL`` backward (how the FFN of every encoder layer runs: T/model/modules.py:14-17, HF
+    BertIntermediate): the forward GEMM leaves act'(pre) as its second output, the backward GEMM multiplies by it -- together the
+    autograd backward of ``act(x W^T + b)``.  Small shape -> the two-buffer kernel, large -> the eight-phase kernel (bf16)."""
+    from idvs.morec_amd._lib import DACT_MUL
+    M, N, K = shape
+    a, b = rnd(M, K, dt=dt, scale=0.2), rnd(N, K, dt=dt, scale=0.2, seed=1)
+    bias = rnd(N, seed=2)
+    dprime = torch.empty(M, N, device=DEV, dtype=dt)
+    c = ops.gemm_nt(a, b, bias=bias, act=act, aux_out=dprime, aux_deriv=True)
+    pre = (a.double() @ b.double().t() + bias.double()).requires_grad_(True)
+    y = torch.nn.functional.gelu(pre) if act == ACT_GELU else torch.relu(pre)
+    y.sum().backward()
+    assert rel(c, y.detach()) < tol(dt)
+    if act == ACT_GELU:
+        assert float((dprime.double() - pre.grad).abs().max()) < (1e-5 if dt == torch.float32 else 1e-2)
+    else:     # 0 / 1 except where the pre-activation rounds across zero
+        assert float(((dprime.double() - pre.grad).abs() > 0).double().mean()) < (1e-6 if dt == torch.float32 else 5e-3)
+    # backward GEMM of the pair: dU = (dZ . W2) * act'  with the column sums (d b1) fused
+    dz, w2 = rnd(M, 64, dt=dt, scale=0.2, seed=7), rnd(N, 64, dt=dt, scale=0.2, seed=8)
+    cs = torch.zeros(N, device=DEV)
+    du = ops.gemm_nt(dz, w2, dact=DACT_MUL, dact_in=dprime, colsum_out=cs)
+    ref = (dz.double() @ w2.double().t()) * dprime.double()
+    assert rel(du, ref) < tol(dt)
+    assert float((cs.double() - du.double().sum(0)).abs().max()) < 1e-5 * float(du.double().sum(0).abs().max()) + 1e-6 * M ** 0.5
+    # and the same product through the explicit-derivative epilogue (dact = act, operand = pre-activation) agrees
+    pre_t = torch.empty(M, N, device=DEV, dtype=dt)
+    ops.gemm_nt(a, b, bias=bias, act=act, aux_out=pre_t)
+    du2 = ops.gemm_nt(dz, w2, dact=act, dact_in=pre_t)
+    assert rel(du, du2.double()) < (1e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("shape", [(260, 384, 256), (77, 96, 64), (3000, 3072, 768), (5000, 136, 96), (2100, 1536, 384)])
 def test_gemm_dact_fused_colsum(dt, shape):
     """``morec_gemm_nt_colsum``: same C as the plain call (bit for bit), and colsum_out += C.sum(0) -- the bias gradient that

@@ -210,9 +210,9 @@ def test_sync_shadow_after_in_place_parameter_writes():
     model2, *_ = _setup("bf16")
     model2.load_state_dict({k: v.cpu() for k, v in new.items()})
     l_fresh = float(TrainStep(model2, **kw).forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
-    assert abs(l_sync - l_fresh) < 1e-6 and abs(l_stale - l_fresh) > 1e-4, (l0, l_stale, l_sync, l_fresh)
+    assert abs(l_sync - l_fresh) < 1e-5 and abs(l_stale - l_fresh) > 1e-4, (l0, l_stale, l_sync, l_fresh)
     ts.load_state_dict({k: v for k, v in model2.state_dict().items()})      # the one-call form
-    assert abs(float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))) - l_fresh) < 1e-6
+    assert abs(float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))) - l_fresh) < 1e-5      # the loss sum is accumulated with fp32 atomics
 
 
 def test_optimizer_state_round_trip_and_exchange_with_torch_adamw():
