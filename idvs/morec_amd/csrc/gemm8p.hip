@@ -610,8 +610,13 @@ extern "C" int morec_tuning_set(const char* key, int value) {
     return MOREC_E_UNSUPPORTED;
 }
 
-int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+int gemm8p_mode() {
     if (g_mode8p < 0) { const char* e = getenv("MOREC_GEMM8P"); g_mode8p = e ? atoi(e) : 0; }
+    return g_mode8p;
+}
+
+int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
+    (void)gemm8p_mode();
     if (g_mode8p == 1) return G8_NOT_TAKEN;
     if (d->in_dtype != MOREC_BF16 || a.accumulate != 0 || !a.vec_store || d->split_k > 1) return G8_NOT_TAKEN;
     if (d->K % KE || d->K < 2 * KE || d->N < 64 || d->M < 1) return G8_NOT_TAKEN;

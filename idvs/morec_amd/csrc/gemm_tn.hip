@@ -10,6 +10,10 @@
 // Bank conflicts: the 8 rows a 32-lane half touches would share banks at a 512-byte pitch; the 32-byte column
 // block index is XOR-ed with (token & 7) on the DMA source side and on the read side (destination stays linear).
 #include "gemm_core.hpp"
+#include "gemm_args.hpp"
+
+int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_stride, int M, int N, int K, int ldy, int ldx, int ldo,
+                         int mchunk, int zs, hipStream_t s);
 
 namespace {
 constexpr int TT = 64;                 // tokens per stage
@@ -193,14 +197,22 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     a.tiles_n = (N + TC - 1) / TC; a.tiles_k = (K + TC - 1) / TC;
     a.slabs = (zs > 1 && workspace) ? workspace : nullptr;
     if (a.slabs && (K % 4 || !aligned16(workspace))) return MOREC_E_ALIGN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
-        attr_set = true;
+    int r8 = G8_NOT_TAKEN;
+    if (a.slabs)                    // split-m partials -> slabs: the eight-phase kernel (gemm_tn8p.hip) when the launch is large enough
+        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.slabs, (size_t)N * K, M, N, K, ldy, ldx, K, mchunk, zs, reinterpret_cast<hipStream_t>(stream));
+    else if (zs == 1 && !accumulate)
+        r8 = gemm_tn8p_try_launch(a.DY, a.X, C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, reinterpret_cast<hipStream_t>(stream));
+    if (r8 != G8_NOT_TAKEN && r8 != MOREC_OK) return r8;
+    if (r8 == G8_NOT_TAKEN) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
+                           reinterpret_cast<hipStream_t>(stream), a);
+        MOREC_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
-                       reinterpret_cast<hipStream_t>(stream), a);
-    MOREC_CHECK_LAUNCH();
     if (a.slabs) {
         const size_t total4 = (size_t)N * K / 4;
         const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
