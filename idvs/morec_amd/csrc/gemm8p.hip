@@ -484,8 +484,23 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
                     wfence();
                 }
             }
+            // a lane's cells are its own: the derivative operand is read (all groups first: one LDS round trip, not eight dependent
+            // ones) and replaced in place
+            [[maybe_unused]] uint32_t uraw[NG][ES == 2 ? 2 : 4];
+            if constexpr (ACT >= 3) {
 #pragma unroll
-            for (int q = 0; q < NG; ++q) {      // a lane's cells are its own: the derivative operand is read and replaced in place
+                for (int q = 0; q < NG; ++q) {
+                    if constexpr (ES == 2) {
+                        const uint2 t = *reinterpret_cast<const uint2*>(cell(q));
+                        uraw[q][0] = t.x; uraw[q][1] = t.y;
+                    } else {
+                        const uint4 t = *reinterpret_cast<const uint4*>(cell(q));
+                        uraw[q][0] = t.x; uraw[q][1] = t.y; uraw[q][2] = t.z; uraw[q][3] = t.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
                 const int Ni = ES == 2 ? q / 4 : ps, g = ES == 2 ? q % 4 : q;
                 const float4 b = bv[Ni][g];
                 float v[4];
@@ -500,7 +515,13 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 } else if constexpr (ACT >= 3) {
                     float u[4];
-                    io<TO>::load4(cell(q), u);
+                    if constexpr (ES == 2) {
+                        u[0] = bfbits2f(uraw[q][0] & 0xffffu); u[1] = bfbits2f(uraw[q][0] >> 16);
+                        u[2] = bfbits2f(uraw[q][1] & 0xffffu); u[3] = bfbits2f(uraw[q][1] >> 16);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) u[r] = __uint_as_float(uraw[q][r]);
+                    }
                     if constexpr (ACT == 3) {
                         dgelu4_mul(v, u);
                     } else if constexpr (ACT == 4) {
@@ -516,7 +537,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
                     for (int r = 0; r < 4; ++r) v[r] = row_ok ? v[r] : 0.f;
                 }
                 io<TO>::store4(cell(q), v);
-                if (q & 1) pin();
+                if (ACT != 5 && (q & 1)) pin();
             }
             wfence();
             if constexpr (CS) {     // column sums of the block as stored (rounded to TO)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): kernel trace + PMC passes of the bench command and of four GEMM shapes; everything lands in
+# gpurun_out/ (copy what is to be judged into profiles/).   bash scripts/capture_profiles.sh <tag>
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+BENCH="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary"
+rm -rf /tmp/prof; mkdir -p /tmp/prof
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o kt -- $BENCH > $O/${TAG}_prof_bench_line.json 2> /dev/null
+python $R/scripts/prof_summary.py /tmp/prof/kt_results.db 6 "$TAG: rocprofv3 --kernel-trace --stats -- bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary (6 steps traced)" > $O/${TAG}_bench_kernel_stats.csv
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o pf -- $BENCH > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof -o pw -- $BENCH > /dev/null 2>&1
+python $R/scripts/pmc_traffic.py /tmp/prof/pf_results.db /tmp/prof/pw_results.db $O/${TAG}_prof_bench_line.json $O/${TAG}_gemm_pmc.json
+{
+for spec in "51200 2304 768 bias" "51200 3072 768 gelu" "51200 3072 768 dmul" "51200 768 3072 nt" "51200 2304 768 tn" "51200 768 3072 tn"; do
+  echo "# rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT -- python scripts/gemm_one.py $spec   (per-dispatch sums over the chip, 3 dispatches averaged)"
+  rm -f /tmp/prof/sq_results.db
+  timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT -d /tmp/prof -o sq -- python $R/scripts/gemm_one.py $spec > /dev/null 2>&1
+  python $R/scripts/pmc_summary.py /tmp/prof/sq_results.db "%gemm%8p%"
+done
+} > $O/${TAG}_gemm_pmc_sq.txt 2>&1

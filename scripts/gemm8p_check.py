@@ -109,8 +109,8 @@ def main():
         print("ALL OK" if ok else "SOME FAILED", flush=True)
     for M in ([int(args_[0])] if args_ else [51200, 80640]):
         print(f"--- timing, M = {M} (us, TF/s); old = two-buffer kernel, new = eight-phase")
-        for name, N, K, kind in [("qkv", 2304, 768, "bias"), ("o", 768, 768, "plain"), ("fc1+gelu", 3072, 768, "gelu"), ("fc2", 768, 3072, "plain"),
-                                 ("d_fc2(dact+cs)", 3072, 768, "dact"), ("d_fc1", 768, 3072, "plain"), ("d_qkv", 768, 2304, "plain")]:
+        for name, N, K, kind in [("qkv", 2304, 768, "bias"), ("o", 768, 768, "plain"), ("fc1+gelu", 3072, 768, "gelu"), ("fc1+gelu+d", 3072, 768, "gelu_d"), ("fc2", 768, 3072, "plain"),
+                                 ("d_fc2(dact+cs)", 3072, 768, "dact"), ("d_fc2(dmul+cs)", 3072, 768, "dmul"), ("d_fc1", 768, 3072, "plain"), ("d_qkv", 768, 2304, "plain")]:
             a = torch.randn(M, K, device=dev).to(dt); b = torch.randn(N, K, device=dev).to(dt)
             out = torch.empty(M, N, device=dev, dtype=dt)
             kw = {}
@@ -118,8 +118,12 @@ def main():
                 kw = dict(bias=torch.zeros(N, device=dev))
             if kind == "gelu":
                 kw = dict(bias=torch.zeros(N, device=dev), act=ACT_GELU, aux_out=torch.empty(M, N, device=dev, dtype=dt))
+            if kind == "gelu_d":
+                kw = dict(bias=torch.zeros(N, device=dev), act=ACT_GELU, aux_out=torch.empty(M, N, device=dev, dtype=dt), aux_deriv=True)
             if kind == "dact":
                 kw = dict(dact=ACT_GELU, dact_in=torch.randn(M, N, device=dev).to(dt), colsum_out=torch.zeros(N, device=dev))
+            if kind == "dmul":
+                kw = dict(dact=_lib.DACT_MUL, dact_in=torch.randn(M, N, device=dev).to(dt), colsum_out=torch.zeros(N, device=dev))
             t = {1: [], 2: []}
             for rnd in range(3):
                 for m in (1, 2):
