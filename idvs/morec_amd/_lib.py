@@ -39,7 +39,7 @@ class AttnDesc(C.Structure):
 
 class CeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("D", C.c_int), ("Nc", C.c_int), ("col_offset", C.c_int),
-                ("dtype", C.c_int)]
+                ("dtype", C.c_int), ("dE_fp32", C.c_int)]
 
 
 class SwinAttnDesc(C.Structure):

@@ -228,9 +228,17 @@ __global__ __launch_bounds__(256) void ce_bwd_dl_kernel(CeArgs p) {
 inline int pad8(int x) { return (x + 7) & ~7; }
 }  // namespace
 
-// workspace layout (floats unless noted):
-//   fwd:  pmax [Nr*K2] | psum [Nr*K2] | pos [Nr]
-//   bwd:  dl T[Nr*ldc] | dlt T[Nc*ldr] | Pt T[D*ldr] | Et T[D*ldc]     (ldc = pad8(Nc), ldr = pad8(Nr))
+// workspace layout:
+//   fwd:  pmax f32[Nr*K2] | psum f32[Nr*K2] | pos f32[Nr]
+//   bwd (fp32 mode):  dl T[Nr*ldc] | dlt T[Nc*ldr] | Pt T[D*ldr] | Et T[D*ldc]          (ldc = pad8(Nc), ldr = pad8(Nr))
+//   bwd (bf16 mode):  dl T[Nr*ldc] | Et T[D*ldc] | dE32 f32[Nc*D] (unless the caller takes dE in fp32) | slabs f32[split*Nc*D]
+static int ce_tn_split(int Nr, int Nc, int D) {     // token (row) split of dE = dl^T P so that the launch has ~256 workgroups
+    const int tiles = ((Nc + 255) / 256) * ((D + 255) / 256);
+    int s = (256 + tiles - 1) / tiles;
+    const int max_s = Nr / 256 > 0 ? Nr / 256 : 1;   // at least 4 stages of 64 rows per chunk
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
 extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
     if (!d) return 0;
     const size_t Nr = (size_t)d->B * d->S, Nc = d->Nc, D = d->D;
@@ -238,7 +246,11 @@ extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
     const size_t fwd = (2 * Nr * K2 + Nr) * sizeof(float);
     const size_t es = elt_size(d->dtype);
     const size_t ldc = pad8((int)Nc), ldr = pad8((int)Nr);
-    const size_t bwd = (Nr * ldc + Nc * ldr + D * ldr + D * ldc) * es + 256;
+    size_t bwd = (Nr * ldc + Nc * ldr + D * ldr + D * ldc) * es + 256;
+    if (d->dtype == MOREC_BF16 && Nc % 8 == 0 && D % 8 == 0) {
+        const size_t tn = (Nr * ldc + D * ldc) * es + Nc * D * sizeof(float) + (size_t)ce_tn_split((int)Nr, (int)Nc, (int)D) * Nc * D * sizeof(float) + 1024;
+        bwd = tn > bwd ? tn : bwd;
+    }
     return (fwd > bwd ? fwd : bwd) + 256;
 }
 
@@ -311,11 +323,6 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
     char* Et = Pt + (((size_t)a.D * ldr * es + 15) & ~(size_t)15);
     a.dl = dl; a.ld_dl = ldc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (ldr != a.Nr) {  // zero the pad columns the transposes do not touch
-        (void)hipMemsetAsync(dlt, 0, (size_t)a.Nc * ldr * es, s);
-        (void)hipMemsetAsync(Pt, 0, (size_t)a.D * ldr * es, s);
-    }
-    if (ldc != a.Nc) (void)hipMemsetAsync(Et, 0, (size_t)a.D * ldc * es, s);
     dim3 grid(a.tiles_m * a.tiles_n);
     if (d->dtype == MOREC_F32) {
         using G = GemmTile<float, 2>;
@@ -329,14 +336,42 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
         hipLaunchKernelGGL((ce_bwd_dl_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
     }
     MOREC_CHECK_LAUNCH();
+    morec_gemm_desc g{};
+    g.in_dtype = d->dtype; g.out_dtype = d->dtype; g.alpha = 1.0f; g.split_k = 1;
+    if (d->dtype == MOREC_BF16 && a.Nc % 8 == 0 && a.D % 8 == 0) {
+        // dE[Nc, D] = dl^T . P straight from the row-major dl and P (transposing LDS reads, morec_gemm_tn): no transposed copies of the
+        // Nr x Nc matrix, fp32 result -- handed out as it is when the caller reduces it over ranks (dE_fp32), else cast
+        char* Et2 = dl + (((size_t)a.Nr * ldc * es + 15) & ~(size_t)15);
+        float* dE32 = reinterpret_cast<float*>(Et2 + (((size_t)a.D * ldc * es + 15) & ~(size_t)15));
+        float* slabs = dE32 + (((size_t)a.Nc * a.D + 3) & ~(size_t)3);
+        float* dEo = d->dE_fp32 ? reinterpret_cast<float*>(dE) : dE32;
+        const int split = ce_tn_split(a.Nr, a.Nc, a.D);
+        if (split > 1) (void)hipMemsetAsync(dEo, 0, (size_t)a.Nc * a.D * sizeof(float), s);
+        rc = morec_gemm_tn(dl, P, dEo, a.Nr, a.Nc, a.D, ldc, a.D, a.D, MOREC_BF16, split, split > 1 ? 1 : 0, split > 1 ? slabs : nullptr, stream);
+        if (rc) return rc;
+        if (!d->dE_fp32) {
+            rc = morec_cast(dE32, dE, (size_t)a.Nc * a.D, MOREC_F32, MOREC_BF16, stream);
+            if (rc) return rc;
+        }
+        // dP[Nr, D] = dl[Nr, Nc] . Et[D, Nc]^T
+        if (ldc != a.Nc) (void)hipMemsetAsync(Et2, 0, (size_t)a.D * ldc * es, s);
+        rc = morec_transpose(E, Et2, a.Nc, a.D, a.D, ldc, d->dtype, d->dtype, stream);
+        if (rc) return rc;
+        g.M = a.Nr; g.N = a.D; g.K = ldc; g.lda = ldc; g.ldb = ldc; g.ldc = a.D;
+        return morec_gemm_nt(&g, dl, Et2, dP, nullptr, nullptr, nullptr, stream);
+    }
+    if (d->dE_fp32) return MOREC_E_UNSUPPORTED;
+    if (ldr != a.Nr) {  // zero the pad columns the transposes do not touch
+        (void)hipMemsetAsync(dlt, 0, (size_t)a.Nc * ldr * es, s);
+        (void)hipMemsetAsync(Pt, 0, (size_t)a.D * ldr * es, s);
+    }
+    if (ldc != a.Nc) (void)hipMemsetAsync(Et, 0, (size_t)a.D * ldc * es, s);
     rc = morec_transpose(dl, dlt, a.Nr, a.Nc, ldc, ldr, d->dtype, d->dtype, stream);
     if (rc) return rc;
     rc = morec_transpose(P, Pt, a.Nr, a.D, a.D, ldr, d->dtype, d->dtype, stream);
     if (rc) return rc;
     rc = morec_transpose(E, Et, a.Nc, a.D, a.D, ldc, d->dtype, d->dtype, stream);
     if (rc) return rc;
-    morec_gemm_desc g{};
-    g.in_dtype = d->dtype; g.out_dtype = d->dtype; g.alpha = 1.0f; g.split_k = 1;
     // dP[Nr, D] = dl[Nr, Nc] . Et[D, Nc]^T
     g.M = a.Nr; g.N = a.D; g.K = ldc; g.lda = ldc; g.ldb = ldc; g.ldc = a.D;
     rc = morec_gemm_nt(&g, dl, Et, dP, nullptr, nullptr, nullptr, stream);

@@ -503,9 +503,11 @@ def ce_inputs_local(sample_items_id: torch.Tensor, log_mask: torch.Tensor, log_p
     return CeInputs(ids32, ids32, logpop, col_valid, row_valid, B, S, 0)
 
 
-def ce_forward(ci: CeInputs, P: torch.Tensor, E: torch.Tensor):
-    """P [B*S, D], E [Nc, D] (compute dtype).  Returns (loss_sum fp32[1] on device, saved)."""
-    desc = ops.ce_desc(ci.B, ci.S, P.shape[1], E.shape[0], ci.col_offset, P.dtype)
+def ce_forward(ci: CeInputs, P: torch.Tensor, E: torch.Tensor, dE_fp32: bool = False):
+    """P [B*S, D], E [Nc, D] (compute dtype).  Returns (loss_sum fp32[1] on device, saved).  ``dE_fp32``: the backward hands dE out
+    in fp32 (pooled negatives: it is reduce-scattered over ranks before it is rounded to the compute dtype)."""
+    dE_fp32 = bool(dE_fp32) and P.dtype == torch.bfloat16 and E.shape[0] % 8 == 0 and P.shape[1] % 8 == 0
+    desc = ops.ce_desc(ci.B, ci.S, P.shape[1], E.shape[0], ci.col_offset, P.dtype, dE_fp32)
     ws = ops.ce_workspace(desc, P.device)
     loss_sum, lse, _ = ops.inbatch_ce_fwd(desc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, ws)
     return loss_sum, (desc, ws, lse)

@@ -188,7 +188,7 @@ class InBatchCEFn(torch.autograd.Function):
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, world, rank)
         else:
             rank, Epool = 0, E
-        loss_sum, saved = backend.ce_forward(ci, P, Epool)
+        loss_sum, saved = backend.ce_forward(ci, P, Epool, world > 1) if backend is engine else backend.ce_forward(ci, P, Epool)
         ctx.stuff = (ci, P, Epool, saved, world, rank, n_valid, loss_mult, backend)
         return (loss_sum[0] * loss_mult / n_valid).to(torch.float32)
 

@@ -237,8 +237,8 @@ def strided_rows_copy(src, out, R, D, in_stride, out_stride):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def ce_desc(B, S, D, Nc, col_offset, dtype):
-    return CeDesc(B, S, D, Nc, col_offset, code(dtype))
+def ce_desc(B, S, D, Nc, col_offset, dtype, dE_fp32=False):
+    return CeDesc(B, S, D, Nc, col_offset, code(dtype), int(bool(dE_fp32)))
 
 
 def ce_workspace(desc, device):
@@ -258,8 +258,9 @@ def inbatch_ce_fwd(desc, P, E, row_ids, col_ids, col_logpop, col_valid, row_vali
 
 
 def inbatch_ce_bwd(desc, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, lse, gscale_dev, gscale, ws):
+    """Returns (dP, dE); dE is fp32 when the descriptor asks for it (``dE_fp32``: the pooled step reduces it over ranks in fp32)."""
     dP = torch.empty_like(P)
-    dE = torch.empty_like(E)
+    dE = torch.empty_like(E, dtype=torch.float32) if desc.dE_fp32 else torch.empty_like(E)
     check(_lib.lib().morec_inbatch_ce_bwd(C.byref(desc), _p(P), _p(E), _p(row_ids), _p(col_ids), _p(col_logpop),
                                           _p(col_valid), _p(row_valid), _p(lse), _p(gscale_dev), gscale, _p(dP), _p(dE),
                                           _p(ws), _stream()), "morec_inbatch_ce_bwd")

@@ -309,7 +309,7 @@ class TrainStep:
         Epool = E
         if self.world > 1 and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank)
-        loss_sum, saved_c = engine.ce_forward(ci, P, Epool)
+        loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.world > 1 and self.pool))
         gscale = (1.0 / n_valid).reshape(1)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
         dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype) if (self.world > 1 and self.pool) else dEpool

@@ -252,6 +252,8 @@ typedef struct {
     int Nc;
     int col_offset;
     int dtype;
+    int dE_fp32;   /* backward only: dE is written as fp32 [Nc, D] whatever the compute dtype (the pooled-negative step reduce-scatters it
+                    * over ranks in fp32); bf16 compute with Nc % 8 == 0 only, MOREC_E_UNSUPPORTED otherwise */
 } morec_ce_desc;
 
 size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d);

@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     d = _lib.GemmDesc(0, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, 1, 1.0)
     assert h.morec_gemm_nt(C.byref(d), None, None, None, None, None, None, None) == -1
     assert h.morec_transpose(None, None, 4, 4, 4, 4, 0, 0, None) == -1
-    assert h.morec_inbatch_ce_workspace_bytes(C.byref(_lib.CeDesc(128, 20, 512, 2688, 0, 1))) > 0
+    assert h.morec_inbatch_ce_workspace_bytes(C.byref(_lib.CeDesc(128, 20, 512, 2688, 0, 1, 0))) > 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -373,6 +373,13 @@ def test_inbatch_ce(dt, cfg):
     dP, dE = ops.inbatch_ce_bwd(desc, P, E, row_ids, col_ids, logpop, col_valid, row_valid, lse, None, 1.0 / n_valid, ws)
     assert rel(dP.cpu(), Pc.grad) < (1e-4 if dt == torch.float32 else 3e-2)
     assert rel(dE.cpu(), Ec.grad) < (1e-4 if dt == torch.float32 else 3e-2)
+    if dt == torch.bfloat16 and Nc % 8 == 0:
+        # pooled-negative form: dE handed out in fp32 (it is reduce-scattered over ranks before any rounding)
+        desc32 = ops.ce_desc(B, S, D, Nc, off, dt, dE_fp32=True)
+        dP2, dE32 = ops.inbatch_ce_bwd(desc32, P, E, row_ids, col_ids, logpop, col_valid, row_valid, lse, None, 1.0 / n_valid, ws)
+        assert dE32.dtype == torch.float32 and torch.equal(dP2, dP)
+        assert rel(dE32.cpu(), Ec.grad) < 3e-2
+        assert float((dE32.to(dt).float() - dE.float()).abs().max()) <= 1e-2 * float(dE.float().abs().max()) + 1e-9
 
 
 def test_inbatch_ce_golden(golden_dir):
