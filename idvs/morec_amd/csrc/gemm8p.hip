@@ -70,15 +70,25 @@ struct Ctx {
 
 __device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int M0, int NQ>
+// ZERO: the first K-tile of an output tile starts its accumulators from the MFMA's inline-constant 0 operand instead of 128
+// v_mov per lane ahead of the loop.
+template <int M0, int NQ, bool ZERO>
 __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4 (&fa)[2][4], const uint4 (&fb)[4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)   // operand-swapped: the lane ends up owning ONE m and runs of 4 consecutive n
+        for (int mi = 0; mi < 2; ++mi) {  // operand-swapped: the lane ends up owning ONE m and runs of 4 consecutive n
+            f32x16_t cin = acc[M0 + mi][NQ];
+            if constexpr (ZERO) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) cin[v] = 0.f;
+                }
+            }
             acc[M0 + mi][NQ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[mi][ks]), acc[M0 + mi][NQ], 0, 0, 0);
+                                                                       __builtin_bit_cast(bf16x8_t, fa[mi][ks]), cin, 0, 0, 0);
+        }
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -93,7 +103,7 @@ __device__ __forceinline__ void vm_wait_tail() {
 }
 
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
-template <int REM, int SLACK = 0>
+template <int REM, int SLACK = 0, bool ZERO = false>
 __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2]) {
     static_assert(SLACK == 0 || REM == 2, "slack only on a steady K-tile");
     char* cur = smem + cb;
@@ -116,7 +126,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
-    mfma_quadrant<0, 0>(acc, fa, fb0);
+    mfma_quadrant<0, 0, ZERO>(acc, fa, fb0);
     bar();
     // ---- phase 1: B-second fragments; refill A-second of t+1
 #pragma unroll
@@ -125,7 +135,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
-    mfma_quadrant<0, 1>(acc, fa, fb1);
+    mfma_quadrant<0, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 2: A-second fragments; refill A-first of t+2 (this buffer)
 #pragma unroll
@@ -136,14 +146,14 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
-    mfma_quadrant<2, 1>(acc, fa, fb1);
+    mfma_quadrant<2, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2(c.rb, c.b1[0], c.b1[1], kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
-    mfma_quadrant<2, 0>(acc, fa, fb0);
+    mfma_quadrant<2, 0, ZERO>(acc, fa, fb0);
     bar();
 }
 
@@ -209,10 +219,17 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     G8_MSTAMP(10);
     int cb = 0;
     int t = 0;
-    if (SLACK > 0 && nk >= 3) {     // the previous epilogue's stores drain under the first K-tile instead of in front of it
-        ktile<2, SLACK>(smem, c, cb, 0, acc);
+    if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
+        ktile<2, SLACK, true>(smem, c, cb, 0, acc);
         cb ^= BUF_BYTES;
         t = 1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
@@ -278,17 +295,16 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
     const int m0 = cur.m0, n0 = cur.n0;
     G8_STAMPW(0, cur.wg);
     f32x16_t acc[4][2];
+    float bias_l;
     {
         int tid_m = threadIdx.x;
         asm volatile("" : "+v"(tid_m));
+        {   // any valid address when there is no bias (discarded in the epilogue): no branch around a load
+            const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.B);
+            bias_l = bp[min(n0 + ((tid_m >> 6) & 3) * 64 + (tid_m & 63), p.N - 1)];
+        }
         Ctx c;
         make_ctx(c, tid_m, Acur, Bcur, p.M - m0, p.N - n0, p.lda, p.ldb);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
         if (first) issue_prologue(c, smem);      // later tiles: issued by the previous tile's body, ahead of its epilogue
         // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
         constexpr int NST = 16 * (int)sizeof(TO) / 2;
@@ -370,17 +386,18 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) lo[ps] = lane_off(ps);
 
-    // ---- loads the epilogue starts with go out AHEAD of the next tile's prologue: the counter a wave waits on retires in
-    // order, so a load issued behind the twelve LDS-DMA pieces could only be waited for together with them.
-    // Bias of this lane's 8 column groups: fetched once per tile, branch-free (a guarded load inside the block loop compiles
-    // to its own basic block ending in s_waitcnt vmcnt(0): a dependent memory round trip per group).
+    // ---- bias: one float per lane (column nw + lane), loaded AHEAD of the main loop (bias_l, above: its round trip hides under
+    // the K-tiles and costs one register there), spread to the lanes' 8 column groups through the wave's slice.  (A load issued
+    // here instead would be waited for in front of the first pass: 1.4 k cycles per tile, profiles/r02_gemm8p_stamps.txt.)
     float4 bv[2][4];
     {
-        const float* bp = p.bias ? p.bias : reinterpret_cast<const float*>(p.B);   // any valid address; discarded below
+        reinterpret_cast<float*>(ws)[lane] = p.bias ? bias_l : 0.f;
+        wfence();
 #pragma unroll
         for (int Ni = 0; Ni < 2; ++Ni)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(bp + min(nw + Ni * 32 + g * 8 + 4 * h, p.N - 4));
+            for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(ws + (Ni * 32 + g * 8 + 4 * h) * 4);
+        wfence();
     }
     Vecs dq = Vecs();   // the activation-derivative operand, fetched one pass ahead
     if constexpr (ACT >= 3) dq = rows_fetch(rD, 0, lo[0]);
@@ -399,12 +416,6 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
     if (p.debug & 2) {      // ablation: no epilogue (the store keeps the accumulators alive)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][3] + acc[2][0][7] + acc[3][1][15] + bv[0][0].x;
         return;
-    }
-    if (!p.bias) {
-#pragma unroll
-        for (int Ni = 0; Ni < 2; ++Ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv[Ni][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (p.stamps) { asm volatile("" :: "v"(bv[0][0].x), "v"(bv[1][3].w)); G8_STAMPW(2, cur.wg); }
     float csum = 0.f;

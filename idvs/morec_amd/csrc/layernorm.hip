@@ -151,39 +151,51 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
     constexpr int EV = vio<T>::EV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int GRP = 64 / LPR, NP = 4 * GRP;     // row groups per wave, column-partial sets per block
-    float* sg = reinterpret_cast<float*>(smem_raw);  // [NP][N] dgamma partials
+    float* sgm = reinterpret_cast<float*>(smem_raw); // [N] gamma (re-read per row: 24 registers cheaper than holding it)
+    float* sg = sgm + N;                             // [NP][N] dgamma partials
     float* sb = sg + NP * (size_t)N;                // [NP][N] dbeta partials
     float* sd = sb + NP * (size_t)N;                // [NP][N] dbias partials (only when dbias)
     const int lane = threadIdx.x & (LPR - 1), wave = (threadIdx.x >> 6) * GRP + ((threadIdx.x & 63) / LPR);
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    float ag[VPL][EV], ab[VPL][EV], ad[VPL][EV], gm[VPL][EV];
+    float ag[VPL][EV], ab[VPL][EV], ad[VPL][EV];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-        const int c = (i * LPR + lane) * EV;
 #pragma unroll
-        for (int k = 0; k < EV; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; gm[i][k] = 0.f; }
-        if (FULL || c < N) load_f32v<EV>(gamma + c, gm[i]);
+        for (int k = 0; k < EV; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; ad[i][k] = 0.f; }
     }
-    for (int row = r0 + wave; row < r1; row += NP) {
-        const size_t base = (size_t)row * N;
-        // Every load of the row is issued before the first one is consumed, from unguarded (clamped) addresses: a load inside
-        // `if (c < N)` / `if (dy_b)` next to its use is its own basic block ending in s_waitcnt vmcnt(0), and the row then
-        // costs one memory round trip per vector per operand instead of one in total.
-        uint4 ra[VPL], rz[VPL], rb[VPL];
+    for (int c = threadIdx.x; c < N; c += 256) sgm[c] = gamma[c];
+    __syncthreads();
+    // Row loads go through buffer descriptors based at the block's first row: every load of a row is issued back to back
+    // and unguarded (a load inside `if (c < N)` / `if (dy_b)` next to its use is its own basic block ending in
+    // s_waitcnt vmcnt(0): one memory round trip per vector per operand instead of one per row); a row past the block's
+    // last one, or an absent dy_b (zero-extent descriptor), is an out-of-range offset: zeros, no memory traffic.
+    // The NEXT row's loads are issued as soon as this row's raw vectors are unpacked -- into the same registers, ahead of the
+    // two row reductions, the output arithmetic and the stores -- so the HBM round trip overlaps them.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const int blk_bytes = (r1 - r0) * N * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(dy_a + (size_t)r0 * N), 0, blk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)(z + (size_t)r0 * N), 0, blk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)((dy_b ? dy_b : dy_a) + (size_t)r0 * N), 0, dy_b ? blk_bytes : 0, 0x00020000);
+    uint4 ra[VPL], rz[VPL], rb[VPL];
+    auto as_uint4 = [](u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); };
+    auto fetch_row = [&](int row) {
+        const uint32_t ro = row < r1 ? (uint32_t)((row - r0) * N) * (uint32_t)sizeof(T) : 0x80000000u;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
-            ra[i] = vio<T>::load_raw(dy_a + base + cl);
-            rz[i] = vio<T>::load_raw(z + base + cl);
+            ra[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rA, ro + cl * (int)sizeof(T), 0, 0));
+            rz[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rZ, ro + cl * (int)sizeof(T), 0, 0));
         }
-        if (dy_b) {
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) {
-                const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
-                rb[i] = vio<T>::load_raw(dy_b + base + cl);
-            }
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * LPR + lane) * EV, cl = FULL ? c : min(c, N - EV);
+            rb[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rB, ro + cl * (int)sizeof(T), 0, 0));
         }
+    };
+    fetch_row(r0 + wave);
+    for (int row = r0 + wave; row < r1; row += NP) {
+        const size_t base = (size_t)row * N;
         const float mu = mean[row], rs = rstd[row];
         const float rsc = (dzd && rowscale) ? rowscale[row / rps] : 1.0f;
         float g[VPL][EV], xh[VPL][EV];
@@ -194,9 +206,9 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
             if (FULL || c < N) {
                 float d[EV], zz[EV];
                 vio<T>::unpack(ra[i], d);
-                if (dy_b) {
+                {
                     float e[EV];
-                    vio<T>::unpack(rb[i], e);
+                    vio<T>::unpack(rb[i], e);      // zeros without dy_b
 #pragma unroll
                     for (int k = 0; k < EV; ++k) d[k] += e[k];
                 }
@@ -209,12 +221,14 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
                     for (int k = 0; k < EV; ++k) d[k] = kp[k] ? d[k] : 0.f;
                 }
                 vio<T>::unpack(rz[i], zz);
+                float gmv[EV];
+                load_f32v<EV>(sgm + c, gmv);
 #pragma unroll
                 for (int k = 0; k < EV; ++k) {
                     xh[i][k] = (zz[k] - mu) * rs;
                     ag[i][k] += d[k] * xh[i][k];
                     ab[i][k] += d[k];
-                    g[i][k] = d[k] * gm[i][k];
+                    g[i][k] = d[k] * gmv[k];
                     s1 += g[i][k];
                     s2 += g[i][k] * xh[i][k];
                 }
@@ -222,7 +236,11 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
 #pragma unroll
                 for (int k = 0; k < EV; ++k) { g[i][k] = 0.f; xh[i][k] = 0.f; }
             }
+            // one vector at a time: without the `c < N` blocks the whole row is one basic block and the scheduler interleaves every
+            // vector's arithmetic (dropout masks included) -- 38 spilled registers at VPL 3
+            if (FULL) __builtin_amdgcn_sched_barrier(0);
         }
+        fetch_row(row + NP);
         uint4 rd[VPL];
         if (dres) {      // pre-LN blocks only; requested together, in flight during the two row reductions
 #pragma unroll
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
                     for (int k = 0; k < EV; ++k) ad[i][k] += io<T>::round(o[k]);   // what colsum over the stored tensor would see
                 }
             }
+            if (FULL) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (dgamma || dbias) {
@@ -350,11 +369,20 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
     // rows per block: enough blocks to fill the chip, few enough that the per-block column flush (N atomics x 3) stays small
-    const int rpb = std::max(64, (((M + 4095) / 4096) + 15) & ~15);
+    // rows per block: ONE round of blocks at two per CU (LDS and registers allow two), never fewer than 64 rows so that the
+    // per-block column flush (3 N atomics) stays small.  (64-row blocks at M = 51200: 800 blocks = 1.56 rounds, 12 % slower.)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, n_cu = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        slots = 2 * n_cu;
+    }
+    const int rpb = std::max(64, (((M + slots - 1) / slots) + 7) & ~7);
     dim3 grid((M + rpb - 1) / rpb), block(256);
 #define LN_BWD_L(V, L)                                                                                          \
     do {                                                                                                        \
-        const size_t lds = (dgamma || dbias) ? (size_t)12 * (64 / L) * N * sizeof(float) : 0;                   \
+        const size_t lds = ((dgamma || dbias) ? (size_t)12 * (64 / L) * N : 0) * sizeof(float) + N * sizeof(float); \
         if (lds > 48 * 1024)                                                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V, L>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
@@ -366,7 +394,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
     if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16);
     else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32);
     else if (N == 96 * vio<T>::EV) {
-        const size_t lds = (dgamma || dbias) ? (size_t)12 * 2 * N * sizeof(float) : 0;
+        const size_t lds = ((dgamma || dbias) ? (size_t)12 * 2 * N : 0) * sizeof(float) + N * sizeof(float);
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, 3, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 32, true>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b, (const T*)z, mean, rstd, gamma,
