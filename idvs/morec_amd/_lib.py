@@ -68,6 +68,7 @@ _SIGS = {
     "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P]),
     "morec_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, _P]),
+    "morec_attn_bwd_dbias": (C.c_int, [C.POINTER(AttnDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "morec_bert_embed_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_float, C.c_uint64, _P]),
     "morec_bert_embed_bwd": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

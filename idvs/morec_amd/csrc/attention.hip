@@ -310,7 +310,8 @@ int check_desc(const morec_attn_desc* d) {
 
 // bf16 fast path on the matrix cores (attention_mfma.hip); MOREC_E_UNSUPPORTED = shape outside it
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
-                           void* dqkv, bool backward, hipStream_t s);
+                           void* dqkv, bool backward, hipStream_t s, float* csum = nullptr);
+int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
 
 extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx,
                               void* stream) {
@@ -352,4 +353,25 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
+}
+
+// morec_attn_bwd + the bias gradient of the fused q|k|v projection: dbias[3 H] += column sums of the dqkv rows as stored.
+// On the MFMA path every (sequence, head) wavefront leaves its own column sums in ws ([n_seq][3 H] fp32) and one small kernel
+// folds them -- instead of a second pass over the [rows x 3 H] tensor (54 us of a 115 us attention backward at 51200 rows,
+// profiles/r02b_bench_kernel_stats.csv).  Other shapes / dtypes: the plain backward followed by morec_colsum.
+extern "C" int morec_attn_bwd_dbias(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx,
+                                    void* dqkv, int rows, float* dbias, float* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!qkv || !key_keep || !dctx || !dqkv || !dbias || rows <= 0) return MOREC_E_ARG;
+    const int H3 = 3 * d->n_heads * d->dh;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ws && ws_bytes >= (size_t)d->n_seq * H3 * sizeof(float)) {
+        rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s, ws);
+        if (rc == MOREC_OK) return colsum_f32_launch(ws, dbias, d->n_seq, H3, s);
+        if (rc != MOREC_E_UNSUPPORTED) return rc;
+    }
+    rc = morec_attn_bwd(d, qkv, key_keep, dctx, dqkv, stream);
+    if (rc) return rc;
+    return morec_colsum(dqkv, dbias, rows, H3, H3, d->dtype, stream);
 }

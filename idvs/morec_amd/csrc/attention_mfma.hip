@@ -28,6 +28,7 @@ struct AttnMArgs {
     const float* key_keep;
     bf16* ctx;          // fwd: output; bwd: dctx input
     bf16* dqkv;
+    float* csum;        // bwd, optional: [n_seq][3 H] fp32 column sums of this sequence's dqkv rows (as stored), folded by the caller
     int n_seq, T, n_heads, dh, causal;
     float scale, mask_value;
     DropRng drop;
@@ -222,13 +223,25 @@ __device__ __forceinline__ void fwd_pv(const AttnMArgs& a, const char* sV, const
     }
 }
 
+// sum over the 16 lanes of a DPP row (every lane ends up with the total): quad butterflies, then the two mirrors
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+
 // dQ = dS K, dK = dS^T Q, dV = P_d^T dO for one head-width chunk of 16 NB columns (same d-contiguous output layout)
 template <int NB>
 __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ, const char* sK, const char* sO,
                                              const bf16x8_t (&dsf)[2], const bf16x8_t (&dsT)[2], const bf16x8_t (&pT)[2],
-                                             size_t row0, int pitch, int H, int col0) {
+                                             size_t row0, int pitch, int H, int col0, int seq) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t cq[NB], ck[NB], cv[NB];
+#pragma unroll
+    for (int db = 0; db < NB; ++db) { cq[db] = zero; ck[db] = zero; cv[db] = zero; }
     bf16x8_t kt[NB], qt[NB], ot[NB];
 #pragma unroll
     for (int db = 0; db < NB; ++db) {
@@ -253,6 +266,35 @@ __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ,
             store_row_d<NB>(a.dqkv, row0 + r, pitch, dcol, dq);
             store_row_d<NB>(a.dqkv, row0 + r, pitch, H + dcol, dk);
             store_row_d<NB>(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
+            if (a.csum) {
+#pragma unroll
+                for (int db = 0; db < NB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cq[db][e] += bf2f(f2bf(dq[db][e]));
+                        ck[db][e] += bf2f(f2bf(dk[db][e]));
+                        cv[db][e] += bf2f(f2bf(dv[db][e]));
+                    }
+            }
+        }
+    }
+    if (a.csum) {   // bias gradient of the fused projection: this (sequence, head)'s column sums, rows = the 16 lanes of a DPP row
+#pragma unroll
+        for (int db = 0; db < NB; ++db)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cq[db][e] = row16_sum(cq[db][e]);
+                ck[db][e] = row16_sum(ck[db][e]);
+                cv[db][e] = row16_sum(cv[db][e]);
+            }
+        if (c == 0) {
+            float* w = a.csum + (size_t)seq * 3 * H + col0 + 4 * NB * g;
+#pragma unroll
+            for (int db = 0; db < NB; ++db) {
+                *reinterpret_cast<float4*>(w + 4 * db) = make_float4(cq[db][0], cq[db][1], cq[db][2], cq[db][3]);
+                *reinterpret_cast<float4*>(w + H + 4 * db) = make_float4(ck[db][0], ck[db][1], ck[db][2], ck[db][3]);
+                *reinterpret_cast<float4*>(w + 2 * H + 4 * db) = make_float4(cv[db][0], cv[db][1], cv[db][2], cv[db][3]);
+            }
         }
     }
 }
@@ -343,7 +385,11 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
     const int H = a.n_heads * a.dh, pitch = 3 * H;
     const size_t row0 = a.cu ? (size_t)a.cu[seq] : (size_t)seq * a.T;
     if (a.cu) a.T = a.cu[seq + 1] - a.cu[seq];   // unpadded layout: this sequence's own length
-    if (a.T <= 0) return;                         // nothing to read or write (and the clamped loads need a valid last row)
+    if (a.T <= 0) {                               // nothing to read or write (and the clamped loads need a valid last row)
+        if (a.csum)
+            for (int j = lane; j < 3 * a.dh; j += 64) a.csum[(size_t)seq * 3 * H + (j / a.dh) * H + head * a.dh + j % a.dh] = 0.f;
+        return;
+    }
     const bf16* dctx = a.ctx;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t s[2][2] = {{zero, zero}, {zero, zero}}, dp[2][2] = {{zero, zero}, {zero, zero}};
@@ -448,8 +494,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
             stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
             __syncthreads();
         }
-        if (nc == 64) bwd_products<4>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0);
-        else bwd_products<2>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0);
+        if (nc == 64) bwd_products<4>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
+        else bwd_products<2>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
     }
 }
 
@@ -457,10 +503,10 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
 
 // returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
-                           void* dqkv, bool backward, hipStream_t s) {
+                           void* dqkv, bool backward, hipStream_t s, float* csum) {
     if (d->dtype != MOREC_BF16 || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
     AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
-                reinterpret_cast<bf16*>(dqkv), d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
+                reinterpret_cast<bf16*>(dqkv), csum, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
                 make_drop(d->p_drop, d->seed), d->cu_seqlens};
     dim3 grid(d->n_seq * d->n_heads), block(64);
     if (backward)

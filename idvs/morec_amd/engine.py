@@ -139,9 +139,7 @@ def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict, need_dx
                                   dbias=g.get("bo"))
     linear_wgrad_(dzd1, ctx, g["o"])
     dctx = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=ctx.shape[1])
-    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
-    if g.get("bqkv") is not None:
-        ops.colsum_(dqkv, g["bqkv"])
+    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx, dbias=g.get("bqkv"))
     linear_wgrad_(dqkv, x0, g["qkv"])
     if not need_dx:
         return None, None
@@ -208,9 +206,7 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     dctx_c = ops.gemm_nt(dzd1, w["o"].wt, K=dzd1.shape[1], N=H)
     dctx = torch.zeros((x0.shape[0], H), device=dctx_c.device, dtype=dctx_c.dtype)
     scatter_cls(dctx_c, dctx, n_seq, T, cu)
-    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx)
-    if g.get("bqkv") is not None:
-        ops.colsum_(dqkv, g["bqkv"])
+    dqkv = ops.attn_bwd(desc, qkv, key_keep, dctx, dbias=g.get("bqkv"))
     linear_wgrad_(dqkv, x0, g["qkv"])
     if not need_dx:
         return None, None

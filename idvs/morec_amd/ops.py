@@ -181,10 +181,16 @@ def attn_fwd(desc, qkv, key_keep):
     return ctx
 
 
-def attn_bwd(desc, qkv, key_keep, dctx):
+def attn_bwd(desc, qkv, key_keep, dctx, dbias=None):
+    """``dbias``: fp32 [3 H] gradient buffer of the fused q|k|v bias, accumulated into (column sums of dqkv)."""
     _dev(dctx)
     dqkv = torch.empty_like(qkv)
-    check(_lib.lib().morec_attn_bwd(C.byref(desc), _p(qkv), _p(key_keep), _p(dctx), _p(dqkv), _stream()), "morec_attn_bwd")
+    if dbias is None:
+        check(_lib.lib().morec_attn_bwd(C.byref(desc), _p(qkv), _p(key_keep), _p(dctx), _p(dqkv), _stream()), "morec_attn_bwd")
+    else:
+        ws = torch.empty((desc.n_seq, qkv.shape[1]), device=qkv.device, dtype=torch.float32)
+        check(_lib.lib().morec_attn_bwd_dbias(C.byref(desc), _p(qkv), _p(key_keep), _p(dctx), _p(dqkv), qkv.shape[0], _p(dbias),
+                                              _p(ws), ws.numel() * 4, _stream()), "morec_attn_bwd_dbias")
     return dqkv
 
 

@@ -266,6 +266,12 @@ def test_attention(dt, cfg):
     (ref * dctx.double()).sum().backward()
     dqkv = ops.attn_bwd(desc, qkv, keep, dctx)
     assert rel(dqkv, qd.grad) < (1e-4 if dt == torch.float32 else 3e-2)
+    # same backward with the fused q|k|v bias gradient: dqkv bit-identical, dbias += column sums of dqkv as stored
+    dbias = torch.full((3 * H,), 0.25, device=DEV)
+    dqkv2 = ops.attn_bwd(desc, qkv, keep, dctx, dbias=dbias)
+    assert torch.equal(dqkv2, dqkv)
+    want = 0.25 + dqkv.double().sum(0)
+    assert (dbias.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("dt", DT)
