@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmorec_hip.so")
+# MOREC_HIP_LIB: another build of the same ABI (A/B timing of kernel variants inside one GPU call)
+LIB_PATH = os.environ.get("MOREC_HIP_LIB") or os.path.join(_HERE, "libmorec_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

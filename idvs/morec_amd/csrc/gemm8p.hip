@@ -278,12 +278,15 @@ constexpr int LDS_TOTAL = LDS_BYTES + 8 * SLICE;       // 160 KiB: the whole LDS
         if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(w) * 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 
+// One unit of a workgroup's work list: an output tile over K-tiles [k0, k0 + nkt).  tail >= 0: one HALF (chunk 0 / 1) of the
+// K range of tail tile number `tail` (see gemm8p_kernel); the two halves meet through p.tail_ws / p.tail_cnt.
 struct TileXY {
     int wg, m0, n0;
+    int k0, nkt, tail, chunk;
 };
 
 template <typename TO, int ACT, bool CS>
-__device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk, const bf16* __restrict__ Acur, const bf16* __restrict__ Bcur,
+__device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const bf16* __restrict__ Acur, const bf16* __restrict__ Bcur,
                                           const bf16* __restrict__ Anext, const bf16* __restrict__ Bnext, const TileXY cur, const TileXY nxt,
                                           const bool first) {
     constexpr int ES = (int)sizeof(TO);
@@ -309,9 +312,63 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, int nk,
         // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
         constexpr int NST = 16 * (int)sizeof(TO) / 2;
         const int younger = (first || (p.debug & 3) || (p.debug & 64)) ? 0 : (p.aux_out ? 2 * NST : NST);
-        mainloop8p(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
+        mainloop8p(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), cur.nkt, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
     }
     G8_STAMPW(1, cur.wg);
+    if (cur.tail >= 0) {
+        // ---- tail split: this workgroup holds the sums over PART of K.  chunk 1 (the producer: the shorter K range, so that it
+        // is normally done first) parks its accumulators in p.tail_ws -- lane-linear, 32 x [512 lanes x 16 B]: every store / load
+        // instruction moves one contiguous 8 KiB -- and raises the tile's flag; chunk 0 (the consumer) waits for the flag, adds
+        // the parked half to its registers and runs the epilogue.  The exchange uses agent-scope (sc1) stores and loads, which
+        // go through to the memory side of the per-XCD L2s: "store complete" (vmcnt 0) is "visible to the other XCDs".  (A release
+        // fence instead -- __threadfence: buffer_wbl2 -- writes back EVERY dirty line of the XCD's L2, i.e. the output tiles of
+        // the rounds before: 60 us per launch.)  The consumer only ever waits for a workgroup of its own grid; sum order is fixed
+        // (consumer + producer), so results are bit-identical from run to run.
+        int tid_t = threadIdx.x;
+        asm volatile("" : "+v"(tid_t));
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tail_ws + (size_t)cur.tail * (TM * TN)), 0, TM * TN * 4, 0x00020000);
+        const bool producer = cur.chunk == 1;
+        if (producer) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        u32x4_t v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * g + e]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rw, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
+                    }
+            vm_wait<0>();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (producer) {
+                __hip_atomic_store(p.tail_cnt + cur.tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_load(p.tail_cnt + cur.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(p.tail_cnt + cur.tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+            }
+        }
+        __syncthreads();
+        if (producer) return;      // (one exit behind the common barriers: an exit inside the store branch made hipcc spill 130 registers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // 8 x 16 B per lane in flight per round trip (16 would spill the accumulators)
+            u32x4_t v[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[j][g] = __builtin_amdgcn_raw_buffer_load_b128(rw, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] += __uint_as_float(v[j][g][e]);
+            pin();
+        }
+    }
     // ---- this tile's epilogue state.  Lane constants come from an OPAQUE copy of the thread id so that they are recomputed
     // here (a dozen integer ops) instead of being kept alive -- i.e. spilled -- across the main loop.
     int tid_e = threadIdx.x;
@@ -576,33 +633,67 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
     const int nk = ((p.debug & 4) ? 128 : p.K) / KE;
-    auto tile_at = [&](int vb) {
+    // Work list of workgroup b (G = gridDim.x): F = nwg / G full rounds of tiles b, b + G, ...; then the R = nwg % G tail tiles.
+    // When at most half of the workgroups would have a tail tile (2 R <= G) and K is long (>= 24 K-tiles: below that the exchange
+    // costs what the split saves), every tail tile is cut in two K ranges taken by workgroups r and r + R: the last, partly
+    // filled round costs ~0.56 of a tile time + the exchange instead of a whole one (600 tiles on 256 CUs: 2.6 instead of 3).
+    const int G = gridDim.x, F = nwg / G, R = nwg - F * G;
+    const bool split = p.tail_ws != nullptr && F >= 1 && R >= 1 && 2 * R <= G && nk >= 24;
+    const int nk0 = (nk + p.tail_bias) / 2;   // the consumer's share: a little more than half (the producer's exchange hides behind it); flat optimum 2..6
+    const int n_units = F + ((int)blockIdx.x < (split ? 2 * R : R) ? 1 : 0);
+    auto unit_at = [&](int i) {
         TileXY t;
+        int vb = (int)blockIdx.x + i * G;
+        t.k0 = 0; t.nkt = nk; t.tail = -1; t.chunk = 0;
+        if (i >= F && split) {
+            t.chunk = (int)blockIdx.x >= R ? 1 : 0;
+            t.tail = (int)blockIdx.x - t.chunk * R;
+            vb = F * G + t.tail;
+            t.k0 = t.chunk ? nk0 : 0;
+            t.nkt = t.chunk ? nk - nk0 : nk0;
+        }
         t.wg = xcd_remap(vb, nwg);
         t.m0 = (t.wg / p.tiles_n) * TM;
         t.n0 = (t.wg % p.tiles_n) * TN;
         return t;
     };
-    int vb = blockIdx.x;
-    TileXY cur = tile_at(vb);
+    TileXY cur = unit_at(0);
     if (p.debug >> 8) {     // experiment: de-synchronise the workgroups' store bursts with a staggered start (G groups over one tile time)
-        const int G = (p.debug >> 8) & 0xff;
+        const int GS = (p.debug >> 8) & 0xff;
         const long long T = (long long)nk * 2300 + 9000;
-        const long long until = (long long)__builtin_readcyclecounter() + T * ((blockIdx.x >> 3) % G) / G;
+        const long long until = (long long)__builtin_readcyclecounter() + T * ((blockIdx.x >> 3) % GS) / GS;
         while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
     }
-    bool first = true;
-    while (true) {
-        vb += gridDim.x;
-        const bool more = vb < nwg;
-        const TileXY nxt = more ? tile_at(vb) : cur;
-        tile_body<TO, ACT, CS>(p, smem, nk, A + (size_t)cur.m0 * p.lda, B + (size_t)cur.n0 * p.ldb, A + (size_t)nxt.m0 * p.lda,
-                               B + (size_t)nxt.n0 * p.ldb, cur, nxt, first);
-        if (!more) break;
+    for (int i = 0; i < n_units; ++i) {
+        const bool more = i + 1 < n_units;
+        const TileXY nxt = more ? unit_at(i + 1) : cur;
+        tile_body<TO, ACT, CS>(p, smem, A + (size_t)cur.m0 * p.lda + cur.k0 * KE, B + (size_t)cur.n0 * p.ldb + cur.k0 * KE,
+                               A + (size_t)nxt.m0 * p.lda + nxt.k0 * KE, B + (size_t)nxt.n0 * p.ldb + nxt.k0 * KE, cur, nxt, i == 0);
         cur = nxt;
-        first = false;
     }
     vm_wait<0>();      // the trailing prologue must not land in LDS that already belongs to another workgroup
+}
+
+// Tail-split scratch: per stream (launches on one stream are ordered, so they can share it; two streams must not), sized for the
+// largest split (n_cu / 2 tail tiles x 256 KiB = 32 MiB at 256 CUs) + the arrival counters, allocated on first use
+// and kept.  More than 8 streams: the ninth runs without the split.
+static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
+    struct Slot { hipStream_t s; float* ws; int* cnt; int dev; };
+    static Slot slots[8];
+    static int n_slots = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < n_slots; ++i)
+        if (slots[i].s == s && slots[i].dev == dev) { a.tail_ws = slots[i].ws; a.tail_cnt = slots[i].cnt; return; }
+    if (n_slots == 8) return;
+    const size_t ws_bytes = (size_t)(n_cu / 2) * TM * TN * sizeof(float), cnt_bytes = (size_t)n_cu * sizeof(int);
+    char* base = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), ws_bytes + cnt_bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMemset(base + ws_bytes, 0, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return; }
+    slots[n_slots] = Slot{s, reinterpret_cast<float*>(base), reinterpret_cast<int*>(base + ws_bytes), dev};
+    a.tail_ws = slots[n_slots].ws;
+    a.tail_cnt = slots[n_slots].cnt;
+    ++n_slots;
 }
 
 template <typename TO, int ACT, bool CS>
@@ -622,6 +713,9 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int nwg = a.tiles_m * a.tiles_n;
+    a.tail_ws = nullptr;
+    a.tail_cnt = nullptr;
+    if (nwg > n_cu && nwg % n_cu && 2 * (nwg % n_cu) <= n_cu && d->K >= 24 * KE && !(a.debug & 128)) tail_workspace(s, n_cu, a);
     hipLaunchKernelGGL((gemm8p_kernel<TO, ACT, CS>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     if constexpr (CS) return colsum_f32_launch(a.colsum, a.colsum_dst, a.tiles_m * 2, d->N, s);
@@ -630,12 +724,13 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // 0: automatic (eligible large problems), 1: never, 2: every eligible problem regardless of size
-static int g_mode8p = -1, g_debug8p = 0;
+static int g_mode8p = -1, g_debug8p = 0, g_tail_bias = 4;
 static unsigned long long g_stamps = 0;
 extern "C" int morec_tuning_set(const char* key, int value) {
     if (!key) return MOREC_E_ARG;
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_tail_bias")) { g_tail_bias = value < 0 ? 0 : value > 16 ? 16 : value; return MOREC_OK; }
     // device buffer (16 x 8 bytes per workgroup) that receives s_memtime stamps of wave 0: address in two halves
     if (!strcmp(key, "gemm8p_stamps_lo")) { g_stamps = (g_stamps & 0xffffffff00000000ull) | (unsigned)value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_stamps_hi")) { g_stamps = (g_stamps & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); return MOREC_OK; }
@@ -654,11 +749,13 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (d->K % KE || d->K < 2 * KE || d->N < 64 || d->M < 1) return G8_NOT_TAKEN;
     const long tiles = (long)((d->M + TM - 1) / TM) * ((d->N + TN - 1) / TN);
     if (a.colsum && d->M < 128) return G8_NOT_TAKEN;      // partial-row workspace is sized per 64 rows
-    // automatic: enough tiles to fill the 256 CUs, and at most 15 % of the tile columns past N
-    if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 115L)) return G8_NOT_TAKEN;
+    // automatic: enough tiles to fill the 256 CUs, and at most a quarter of the tile columns past N (N = 192, 384, 576 of the Swin
+    // stages: faster here than in the two-buffer kernel; N = 96 is not -- profiles/r02_swin_gemm_shapes_modes.txt)
+    if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 134L)) return G8_NOT_TAKEN;
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
                      : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;
     a.debug = g_debug8p;
+    a.tail_bias = g_tail_bias;
     a.stamps = reinterpret_cast<unsigned long long*>(g_stamps);
     if (d->out_dtype == MOREC_F32) {
         if (mode != 0 || a.colsum) return G8_NOT_TAKEN;

@@ -280,8 +280,9 @@ int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_
     if (zs == 1 && M < 2 * TT) return G8_NOT_TAKEN;
     const int tiles_n = (N + 255) / 256, tiles_k = (K + 255) / 256;
     if (mode != 2) {
-        // automatic: tiles mostly full (at most 15 % of the tile area outside the matrix) and enough work per workgroup
-        if ((long)tiles_n * 256 * tiles_k * 256 * 100 > (long)N * K * 115) return G8_NOT_TAKEN;
+        // automatic: enough work per workgroup.  (No tile-fill rule: on every Swin-T / BERT weight-gradient shape measured --
+        // down to 96 x 96 outputs, 86 % of the tile outside the matrix -- this kernel is at least as fast as the two-buffer one,
+        // which is HBM-bound there as well: profiles/r02_swin_gemm_shapes_modes.txt.)
         if (mchunk < 8 * TT) return G8_NOT_TAKEN;
     }
     if ((long)M * ldy * 2 >= 0x7fffffffL || (long)M * ldx * 2 >= 0x7fffffffL) return G8_NOT_TAKEN;   // 32-bit stage offsets

@@ -39,6 +39,7 @@ struct SwinMArgs {
     int n_img, H, W, shift, heads;
     float scale;
     int n_win_total, wpw;  // windows per wavefront
+    int gx;                // window groups (4 wavefronts x wpw windows each)
 };
 
 __device__ __forceinline__ f32x4_t mfma(const uint4& a_rows, const uint4& b_rows, f32x4_t acc) {
@@ -85,6 +86,20 @@ __device__ __forceinline__ MaskBits make_mask_bits(int shift) {
             if (j < NT && jx >= WS - shift) m.bj |= 1u << (4 * t + r);
         }
     }
+    return m;
+}
+
+// Workgroup -> (head, window group).  A head's q / k / v / ctx slices are 64 bytes of a token row -- half a 128-byte line -- so the
+// heads of one window group must run on the SAME XCD (one L2) at about the same time, or every line is fetched from / merged
+// in HBM once per head.  Workgroups are dealt to the 8 XCDs round-robin: ids congruent mod 8 share an XCD, and within one
+// XCD consecutive ids walk the heads of one window group before moving to the next group.
+struct WgMap { int head, bx; };
+__device__ __forceinline__ WgMap wg_map(const SwinMArgs& a) {
+    const int lin = blockIdx.x, xcd = lin & 7, t = lin >> 3;
+    WgMap m;
+    m.head = t % a.heads;
+    m.bx = (t / a.heads) * 8 + xcd;
+    if (m.bx >= a.gx) m.bx = -1;
     return m;
 }
 
@@ -190,7 +205,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     __shared__ __attribute__((aligned(16))) char sVall[4 * TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g4 = lane >> 4;
-    const int head = blockIdx.y, C = a.heads * DH, pitch = 3 * C;
+    const WgMap wm = wg_map(a);
+    if (wm.bx < 0) return;
+    const int head = wm.head, C = a.heads * DH, pitch = 3 * C;
     char* sV = sVall + wave * TILE;
     // bias registers in the accumulator layout; padded keys carry -inf (their probabilities become exactly 0)
     float bias[4][4][4];
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
                 bias[tj][ti][r] = (j >= NT) ? -INFINITY : (i < NT ? a.bias_t[((size_t)head * NT + j) * NT + i] : 0.f);
             }
     const MaskBits mb = make_mask_bits(a.shift);
-    const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    const int w0 = (wm.bx * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
         // No guarded loads: `valid ? *p : 0` compiles to one basic block per load (each ending in a full s_waitcnt) and a load
@@ -268,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
     char* sK = wbase + wave * (2 * TILE + PTILE);                  // [64 x 32] K tile
     char* sX = sK + TILE;                                          // [64 x 32] dO, then Q
     char* sP = sX + TILE;                                          // [64 x 64] P, then dS
-    const int head = blockIdx.y, C = a.heads * DH, pitch = 3 * C;
+    const WgMap wm = wg_map(a);
+    if (wm.bx < 0) return;
+    const int head = wm.head, C = a.heads * DH, pitch = 3 * C;
     for (int e = threadIdx.x; e < NT * 64; e += 256) {
         const int i = e >> 6, j = e & 63;
         sBias[i * BP + j] = (j < NT) ? a.bias_t[((size_t)head * NT + j) * NT + i] : -INFINITY;
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) dbacc[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int w0 = (blockIdx.x * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    const int w0 = (wm.bx * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
         f32x4_t s[4][4], dp[4][4];
@@ -487,8 +506,8 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     a.n_win_total = d->n_img * (d->H / WS) * (d->W / WS);
     const long tiles = (long)a.n_win_total * d->heads;
     a.wpw = (int)std::max<long>(1, std::min<long>(32, tiles / 8192));
-    const int gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
-    dim3 grid(gx, d->heads), block(256);
+    a.gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
+    dim3 grid(((a.gx + 7) / 8) * 8 * d->heads), block(256);
     if (!backward) {
         hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
     } else {

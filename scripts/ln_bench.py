@@ -3,9 +3,7 @@ python scripts/ln_bench.py [M] [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from idvs.morec_amd import ops, _lib
-if os.environ.get('MOREC_LIB_VARIANT'):
-    _lib.LIB_PATH = os.environ['MOREC_LIB_VARIANT']
+from idvs.morec_amd import ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 51200
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 768

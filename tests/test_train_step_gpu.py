@@ -270,4 +270,6 @@ def test_short_last_batch_runs_through_the_same_step():
     l_short = float(ts.forward_backward(tdev(ids[:4]).view(-1), tdev(it3[:4].reshape(-1, T2)), tdev(lm[:4])))   # ... then 4 of 9
     ts_b.step(tdev(ids).view(-1), tdev(items), tdev(lm))
     l_ref = float(ts_b.forward_backward(tdev(ids[:4].copy()).view(-1), tdev(it3[:4].reshape(-1, T2).copy()), tdev(lm[:4].copy())))
-    assert np.isfinite(l_short) and abs(l_short - l_ref) < 1e-6
+    # two identical runs agree to fp32 rounding, not bit for bit: the first step's parameter gradients are accumulated with
+    # float atomics (LayerNorm / bias column sums), whose order differs from launch to launch
+    assert np.isfinite(l_short) and abs(l_short - l_ref) < 2e-5
