@@ -15,6 +15,7 @@
 // Outputs are produced transposed (O^T, dQ^T, dK^T, dV^T) so that a lane owns 4 consecutive head columns of one token
 // row: 8-byte global stores.
 #include <algorithm>
+#include <type_traits>
 #include "common.hpp"
 
 namespace {
@@ -40,6 +41,7 @@ struct SwinMArgs {
     float scale;
     int n_win_total, wpw;  // windows per wavefront
     int gx;                // window groups (4 wavefronts x wpw windows each)
+    unsigned qkv_bytes;    // size of qkv / dqkv in bytes (bwd: buffer-descriptor extent, < 4 GiB)
 };
 
 __device__ __forceinline__ f32x4_t mfma(const uint4& a_rows, const uint4& b_rows, f32x4_t acc) {
@@ -273,10 +275,99 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     }
 }
 
+// Backward softmax for NTI of the four query blocks (ti = TB .. TB + NTI - 1): with all four blocks at once the live set (P 64 +
+// dP 64 + dbias 64 + operand fragments) spilled 42 registers.  s: [tj][t] accumulators of S^T for those blocks.
+template <int TB, int NTI, typename BiasF>
+__device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, BiasF bias4, const LaneGeom& G, const MaskBits& mb) {
+    const bool masked = G.edge_r || G.edge_c;
+    const uint32_t er = G.edge_r ? 0xffffu : 0u, ec = G.edge_c ? 0xffffu : 0u;
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) {
+        const int ti = TB + t;
+        float m = -INFINITY;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const f32x4_t b = bias4(tj, ti);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[tj][t][r] = fmaf(s[tj][t][r], scale, b[r]);
+                m = fmaxf(m, s[tj][t][r]);
+            }
+        }
+        if (masked) {   // wave-uniform (see softmax_rows)
+            const uint32_t bits = ((((mb.ai >> ti) & 1u) ? ~mb.aj : mb.aj) & er) | ((((mb.bi >> ti) & 1u) ? ~mb.bj : mb.bj) & ec);
+            m = -INFINITY;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[tj][t][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][t][r]);
+                    m = fmaxf(m, s[tj][t][r]);
+                }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[tj][t][r] - m);
+                s[tj][t][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;     // padded query rows: probability 0
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[tj][t][r] *= inv;
+    }
+}
+
+template <int NTI>
+__device__ __forceinline__ uint4 pack_part(const f32x4_t (&p)[4][NTI], int t, int sk) {
+    uint4 f;
+    f.x = pack_bf16x2(p[2 * sk][t][0], p[2 * sk][t][1]);
+    f.y = pack_bf16x2(p[2 * sk][t][2], p[2 * sk][t][3]);
+    f.z = pack_bf16x2(p[2 * sk + 1][t][0], p[2 * sk + 1][t][1]);
+    f.w = pack_bf16x2(p[2 * sk + 1][t][2], p[2 * sk + 1][t][3]);
+    return f;
+}
+
+// The 16 operand rows (q, k, v, dO: 16 bytes each per lane and 16-token block) of one (window, head).  Unguarded loads: padded
+// tokens re-read token 0's rows (see the forward kernel).
+struct BwdFrags { uint4 q[4], k[4], v[4], o[4]; };
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+// Buffer descriptors + 32-bit byte offsets for every global access of the backward kernel (the launcher checks the tensors are
+// below 4 GiB): with flat 64-bit addresses hipcc kept two dozen precomputed row pointers alive across the softmax -- 50 spilled registers.
+struct BwdBufs { __amdgpu_buffer_rsrc_t qkv, dctx, dqkv; };
+__device__ __forceinline__ void load_bwd_frags(const BwdBufs& B, const LaneGeom& G, int head, int C, int pitch, int g4, BwdFrags& f) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t ro = (uint32_t)G.row[k] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2);
+        f.q[k] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(B.qkv, ro, 0, 0));
+        f.k[k] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(B.qkv, ro, C * 2, 0));
+        f.v[k] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(B.qkv, ro, C * 4, 0));
+        f.o[k] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(B.dctx, (uint32_t)G.row[k] * (uint32_t)(C * 2) + (uint32_t)((head * DH + 8 * g4) * 2), 0, 0));
+    }
+}
+// out[row][col .. col + 3] = v * mul (bf16), row / col in elements of a [rows][pitch] matrix; soff = wave-uniform byte offset
+__device__ __forceinline__ void store4_buf(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, int soff, const f32x4_t& v, float mul) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    u32x2_t o;
+    o[0] = pack_bf16x2(v[0] * mul, v[1] * mul);
+    o[1] = pack_bf16x2(v[2] * mul, v[3] * mul);
+    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff, 0);
+}
+
 // dbias accumulates in registers (LDS float atomics cost 2x the rest of the kernel) and is reduced once per workgroup.
-// Register budget for two wavefronts per SIMD (<= 256 VGPRs): dbias 64 + P 64 + dP/dS 64 leaves room for two operand
-// fragment sets, so q / dctx fragments are not kept across phases: dO goes to its LDS tile as soon as dP is issued and q is
-// re-read (L2-resident) for the dK product.
+// ONE global round trip per window: all sixteen operand rows are requested together -- for the NEXT window, while this window's
+// dK product (the last phase, when the softmax registers are dead) runs -- and q stays in registers for the dK product instead
+// of being re-read.  (Three dependent round trips per window -- q/k, then v/dO, then q again -- with two wavefronts per SIMD
+// to hide them left the kernel at 2 TB/s whatever the stage: profiles/r02_swin_attn.txt.)
 __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sBias = reinterpret_cast<float*>(smem);                 // [NT (query i)][BP] shared by the block's 4 wavefronts
@@ -300,75 +391,69 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) dbacc[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int w0 = (wm.bx * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    BwdBufs bufs;
+    bufs.qkv = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, (int)a.qkv_bytes, 0x00020000);
+    bufs.dqkv = __builtin_amdgcn_make_buffer_rsrc((void*)a.dqkv, 0, (int)a.qkv_bytes, 0x00020000);
+    bufs.dctx = __builtin_amdgcn_make_buffer_rsrc((void*)a.dctx, 0, (int)(a.qkv_bytes / 3), 0x00020000);
+    BwdFrags fr;
+    if (w0 < w1) {
+        const LaneGeom G0 = window_geom(a, w0);
+        load_bwd_frags(bufs, G0, head, C, pitch, g4, fr);
+    }
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
-        f32x4_t s[4][4], dp[4][4];
-        {   // unguarded loads (padded tokens re-read token 0's rows, see the forward kernel), all issued before the LDS writes
-            uint4 qf[4], kf[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bf16* base = a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4;
-                qf[k] = *reinterpret_cast<const uint4*>(base);
-                kf[k] = *reinterpret_cast<const uint4*>(base + C);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = kf[k];
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+        for (int k = 0; k < 4; ++k) {
+            *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = fr.k[k];
+            *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = fr.o[k];
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the v / dctx fragments from being loaded while q / k are still live
-        {
-            uint4 vf[4], of[4];
+        uint4 dsf[4][2];
+        // one 16-query block at a time (see softmax_part); dO rows of the block come back from the tile just written
+        wave_lds_fence();
+        auto block = [&](auto TBc) {
+            constexpr int TB = decltype(TBc)::value;
+            f32x4_t s[4][1], dp[4][1];
+            const uint4 ob = *reinterpret_cast<const uint4*>(sX + (c + 16 * TB) * TROW + 16 * g4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                vf[k] = *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + 2 * C + head * DH + 8 * g4);
-                of[k] = *reinterpret_cast<const uint4*>(a.dctx + (size_t)G.row[k] * C + head * DH + 8 * g4);
+            for (int tj = 0; tj < 4; ++tj) {
+                s[tj][0] = mfma(fr.k[tj], fr.q[TB], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                dp[tj][0] = mfma(fr.v[tj], ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = of[k];
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) dp[tj][ti] = mfma(vf[tj], of[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
-        }
-        // padded query rows (i >= NT) read the last real bias row; softmax_rows zeroes their probabilities
-        softmax_rows(s, a.scale, [&](int tj, int ti) {
-            return *reinterpret_cast<const f32x4_t*>(sBias + min(16 * ti + c, NT - 1) * BP + 16 * tj + 4 * g4);
-        }, G, mb);
-        // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys and padded queries (P = 0 on both).
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+            // padded query rows (i >= NT) read the last real bias row; softmax_part zeroes their probabilities
+            softmax_part<TB, 1>(s, a.scale, [&](int tj, int ti) {
+                return *reinterpret_cast<const f32x4_t*>(sBias + min(16 * ti + c, NT - 1) * BP + 16 * tj + 4 * g4);
+            }, G, mb);
+            // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys and padded queries (P = 0 on both).
             float delta = 0.f;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) delta = fmaf(s[tj][ti][r], dp[tj][ti][r], delta);
+                for (int r = 0; r < 4; ++r) delta = fmaf(s[tj][0][r], dp[tj][0][r], delta);
             delta += __shfl_xor(delta, 16, 64);
             delta += __shfl_xor(delta, 32, 64);
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ds = s[tj][ti][r] * (dp[tj][ti][r] - delta);
-                    dp[tj][ti][r] = ds;
-                    dbacc[tj][ti][r] += ds;
+                    const float ds = s[tj][0][r] * (dp[tj][0][r] - delta);
+                    dp[tj][0][r] = ds;
+                    dbacc[tj][TB][r] += ds;
                 }
-        }
-        // P to the row-major LDS tile [i][j] (for dV); dS fragments stay in registers (for dQ) and follow P into the tile (for dK)
-        uint4 dsf[4][2];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+            // P to the row-major LDS tile [i][j] (for dV); dS fragments stay in registers (for dQ) and follow P into the tile (for dK)
+            char* prow = sP + (16 * TB + c) * PROW;
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
-                dsf[ti][sk] = pack_frag(dp, ti, sk);
-                const uint4 pfr = pack_frag(s, ti, sk);
-                char* prow = sP + (16 * ti + c) * PROW;
+                dsf[TB][sk] = pack_part<1>(dp, 0, sk);
+                const uint4 pfr = pack_part<1>(s, 0, sk);
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);      // the next block starts when this one's registers are free
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{});
         wave_lds_fence();
         // dQ^T[d][i] = scale * sum_j K[j][d] dS[i][j]
         {
@@ -390,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                 if (G.valid[ti]) {
 #pragma unroll
                     for (int td = 0; td < 2; ++td)
-                        store4_bf16(a.dqkv + (size_t)G.row[ti] * pitch + head * DH + 16 * td + 4 * g4, acc[td][ti], a.scale);
+                        store4_buf(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), 32 * td, acc[td][ti], a.scale);
                 }
         }
         // dV^T[d][j] = sum_i dO[i][d] P[i][j]: both operands are transposed reads (dO tile, P tile)
@@ -417,18 +502,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                 if (G.valid[tj]) {
 #pragma unroll
                     for (int td = 0; td < 2; ++td)
-                        store4_bf16(a.dqkv + (size_t)G.row[tj] * pitch + 2 * C + head * DH + 16 * td + 4 * g4, acc[td][tj], 1.0f);
+                        store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 4 + 32 * td, acc[td][tj], 1.0f);
                 }
         }
         wave_lds_fence();
-        // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]
-        {
-            uint4 qk[4];
+        // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]: Q (still in registers) and dS replace dO and P in their tiles
 #pragma unroll
-            for (int k = 0; k < 4; ++k) qk[k] = *reinterpret_cast<const uint4*>(a.qkv + (size_t)G.row[k] * pitch + head * DH + 8 * g4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = qk[k];
-        }
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = fr.q[k];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             char* prow = sP + (16 * ti + c) * PROW;
@@ -439,6 +519,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
             }
         }
         wave_lds_fence();
+        {   // the next window's operand rows (the last window re-reads itself: no guarded loads), in flight during the dK product
+            const LaneGeom Gn = window_geom(a, min(g + 1, w1 - 1));
+            load_bwd_frags(bufs, Gn, head, C, pitch, g4, fr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         {
             f32x4_t acc[2][4];
 #pragma unroll
@@ -462,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                 if (G.valid[tj]) {
 #pragma unroll
                     for (int td = 0; td < 2; ++td)
-                        store4_bf16(a.dqkv + (size_t)G.row[tj] * pitch + C + head * DH + 16 * td + 4 * g4, acc[td][tj], a.scale);
+                        store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 2 + 32 * td, acc[td][tj], a.scale);
                 }
         }
         wave_lds_fence();
@@ -508,6 +593,9 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     a.wpw = (int)std::max<long>(1, std::min<long>(32, tiles / 8192));
     a.gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
     dim3 grid(((a.gx + 7) / 8) * 8 * d->heads), block(256);
+    const unsigned long long qkv_bytes = (unsigned long long)d->n_img * d->H * d->W * 3 * d->heads * DH * 2;
+    if (backward && qkv_bytes >= 0xffffffffull) return MOREC_E_UNSUPPORTED;     // 32-bit buffer offsets in the backward kernel
+    a.qkv_bytes = (unsigned)qkv_bytes;
     if (!backward) {
         hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
     } else {
