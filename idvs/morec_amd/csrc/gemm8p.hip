@@ -59,6 +59,13 @@ __device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uin
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, o0, kbyte, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, o1, kbyte, 0, 0);
 }
+struct Ctx;
+// The same for a K-tile that may be the LAST one of a K that is not a multiple of 64: `m` = all ones when it is (wave-uniform),
+// and the lanes whose 16-byte slot lies past K carry 0x80000000 in c.pz[]: the offset leaves the descriptor's range and the DMA
+// writes zeros.  One v_and_or_b32 per instruction; with K % 64 == 0 pz is 0 and nothing changes.
+__device__ __forceinline__ void dma2z(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, const uint32_t (&pz)[2], uint32_t m, int kbyte, char* dst) {
+    dma2(rs, o0 | (pz[0] & m), o1 | (pz[1] & m), kbyte, dst);
+}
 
 struct Ctx {
     __amdgpu_buffer_rsrc_t ra, rb;               // descriptors of A / B, based at the tile's first row
@@ -66,6 +73,7 @@ struct Ctx {
     int dA1, dA2, dB1, dB2;                      // wave-uniform LDS offsets (within a buffer) of those pieces
     int aoff, boff;                              // LDS offsets (within a buffer) of the wave's first A row / first B row
     int loff[4];                                 // per-lane fragment offset of MFMA k-step ks: row (lane & 31), swizzled slot
+    uint32_t pz[2];                              // 0x80000000 where this lane's slot of piece j lies past K in the LAST K-tile, else 0
 };
 
 __device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -103,8 +111,11 @@ __device__ __forceinline__ void vm_wait_tail() {
 }
 
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
+// last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
 template <int REM, int SLACK = 0, bool ZERO = false>
-__device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2]) {
+__device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
+    const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
+    const uint32_t m2 = last2 ? 0xffffffffu : 0u;
     static_assert(SLACK == 0 || REM == 2, "slack only on a steady K-tile");
     char* cur = smem + cb;
     char* oth = smem + (cb ^ BUF_BYTES);
@@ -122,7 +133,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
-    if constexpr (REM >= 1) dma2(c.rb, c.b2[0], c.b2[1], kb + KB, oth + OP_BYTES + c.dB2);
+    if constexpr (REM >= 1) dma2z(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
@@ -131,7 +142,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     // ---- phase 1: B-second fragments; refill A-second of t+1
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb1[ks] = lds16(smem + adb[ks] + 32 * KB);
-    if constexpr (REM >= 1) dma2(c.ra, c.a2[0], c.a2[1], kb + KB, oth + c.dA2);
+    if constexpr (REM >= 1) dma2z(c.ra, c.a2[0], c.a2[1], c.pz, m1, kb + KB, oth + c.dA2);
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
@@ -142,14 +153,14 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + (64 + mi * 32) * KB);
-    if constexpr (REM >= 2) dma2(c.ra, c.a1[0], c.a1[1], kb + 2 * KB, cur + c.dA1);
+    if constexpr (REM >= 2) dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m2, kb + 2 * KB, cur + c.dA1);
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
     mfma_quadrant<2, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
-    if constexpr (REM >= 2) dma2(c.rb, c.b1[0], c.b1[1], kb + 2 * KB, cur + OP_BYTES + c.dB1);
+    if constexpr (REM >= 2) dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
@@ -160,7 +171,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 // ---- DMA / fragment context of one tile.  At, Bt = first row of the tile's A / B panel; rows_a, rows_b = rows that exist from
 // there on (M - m0, N - n0; rows past them are clamped to the last valid one).  `tid` is an opaque copy of threadIdx.x: the
 // context is recomputed per tile (a few dozen integer ops) instead of being kept alive across the epilogue.
-__device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const bf16* Bt, int rows_a, int rows_b, int lda, int ldb) {
+__device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const bf16* Bt, int rows_a, int rows_b, int lda, int ldb, int krem) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -175,6 +186,7 @@ __device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const 
         c.a2[j] = (uint32_t)min(ra + 64 + rl, rows_a - 1) * (uint32_t)(lda * 2) + slot * 16;
         c.b1[j] = (uint32_t)min(rb + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
         c.b2[j] = (uint32_t)min(rb + 32 + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
+        c.pz[j] = slot * 8 >= krem ? 0x80000000u : 0u;          // krem = elements of K in the unit's last K-tile (64: all of it)
     }
     // descriptors: raw (stride 0), extent = the rows of this tile that exist (every offset above stays inside it)
     const long abytes = (long)min(256, rows_a) * lda * 2, bbytes = (long)min(256, rows_b) * ldb * 2;
@@ -191,13 +203,14 @@ __device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const 
 // Prologue of a tile: K-tile 0 entirely, the first halves of K-tile 1 (12 LDS-DMA instructions per lane).  LDS must be free
 // of readers: called before the first tile and, for the NEXT tile, right after a main loop (every wave is past its last barrier)
 // -- i.e. ahead of the finished tile's epilogue, whose slices live outside the two K-tile buffers.
-__device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem) {
+__device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk) {
+    const uint32_t m = nk == 2 ? 0xffffffffu : 0u;
     dma2(c.ra, c.a1[0], c.a1[1], 0, smem + c.dA1);
     dma2(c.rb, c.b1[0], c.b1[1], 0, smem + OP_BYTES + c.dB1);
     dma2(c.rb, c.b2[0], c.b2[1], 0, smem + OP_BYTES + c.dB2);
     dma2(c.ra, c.a2[0], c.a2[1], 0, smem + c.dA2);
-    dma2(c.ra, c.a1[0], c.a1[1], KB, smem + BUF_BYTES + c.dA1);
-    dma2(c.rb, c.b1[0], c.b1[1], KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
+    dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m, KB, smem + BUF_BYTES + c.dA1);
+    dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m, KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
     pin();
 }
 
@@ -220,7 +233,7 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     int cb = 0;
     int t = 0;
     if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<2, SLACK, true>(smem, c, cb, 0, acc);
+        ktile<2, SLACK, true>(smem, c, cb, 0, acc, nk == 3);
         cb ^= BUF_BYTES;
         t = 1;
     } else {
@@ -233,7 +246,7 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
-        ktile<2>(smem, c, cb, t * KB, acc);
+        ktile<2>(smem, c, cb, t * KB, acc, t + 3 == nk);
         cb ^= BUF_BYTES;
         if (t == 1) G8_MSTAMP(12);
     }
@@ -283,6 +296,7 @@ constexpr int LDS_TOTAL = LDS_BYTES + 8 * SLICE;       // 160 KiB: the whole LDS
 struct TileXY {
     int wg, m0, n0;
     int k0, nkt, tail, chunk;
+    int krem;      // elements of K inside the unit's last K-tile (64 unless the unit ends at a K that is not a multiple of 64)
 };
 
 template <typename TO, int ACT, bool CS>
@@ -307,8 +321,8 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
             bias_l = bp[min(n0 + ((tid_m >> 6) & 3) * 64 + (tid_m & 63), p.N - 1)];
         }
         Ctx c;
-        make_ctx(c, tid_m, Acur, Bcur, p.M - m0, p.N - n0, p.lda, p.ldb);
-        if (first) issue_prologue(c, smem);      // later tiles: issued by the previous tile's body, ahead of its epilogue
+        make_ctx(c, tid_m, Acur, Bcur, p.M - m0, p.N - n0, p.lda, p.ldb, cur.krem);
+        if (first) issue_prologue(c, smem, cur.nkt);      // later tiles: issued by the previous tile's body, ahead of its epilogue
         // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
         constexpr int NST = 16 * (int)sizeof(TO) / 2;
         const int younger = (first || (p.debug & 3) || (p.debug & 64)) ? 0 : (p.aux_out ? 2 * NST : NST);
@@ -467,8 +481,8 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         int tid_n = threadIdx.x;
         asm volatile("" : "+v"(tid_n));
         Ctx cn;
-        make_ctx(cn, tid_n, Anext, Bnext, p.M - nxt.m0, p.N - nxt.n0, p.lda, p.ldb);
-        issue_prologue(cn, smem);
+        make_ctx(cn, tid_n, Anext, Bnext, p.M - nxt.m0, p.N - nxt.n0, p.lda, p.ldb, nxt.krem);
+        issue_prologue(cn, smem, nxt.nkt);
     }
     if (p.debug & 2) {      // ablation: no epilogue (the store keeps the accumulators alive)
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][3] + acc[2][0][7] + acc[3][1][15] + bv[0][0].x;
@@ -632,7 +646,9 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const bf16* A = reinterpret_cast<const bf16*>(p.A);
     const bf16* B = reinterpret_cast<const bf16*>(p.B);
-    const int nk = ((p.debug & 4) ? 128 : p.K) / KE;
+    const int Keff = (p.debug & 4) ? 128 : p.K;
+    const int nk = (Keff + KE - 1) / KE;
+    const int krem_all = Keff - (nk - 1) * KE;
     // Work list of workgroup b (G = gridDim.x): F = nwg / G full rounds of tiles b, b + G, ...; then the R = nwg % G tail tiles.
     // When at most half of the workgroups would have a tail tile (2 R <= G) and K is long (>= 24 K-tiles: below that the exchange
     // costs what the split saves), every tail tile is cut in two K ranges taken by workgroups r and r + R: the last, partly
@@ -644,13 +660,14 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     auto unit_at = [&](int i) {
         TileXY t;
         int vb = (int)blockIdx.x + i * G;
-        t.k0 = 0; t.nkt = nk; t.tail = -1; t.chunk = 0;
+        t.k0 = 0; t.nkt = nk; t.tail = -1; t.chunk = 0; t.krem = krem_all;
         if (i >= F && split) {
             t.chunk = (int)blockIdx.x >= R ? 1 : 0;
             t.tail = (int)blockIdx.x - t.chunk * R;
             vb = F * G + t.tail;
             t.k0 = t.chunk ? nk0 : 0;
             t.nkt = t.chunk ? nk - nk0 : nk0;
+            t.krem = t.chunk ? krem_all : KE;
         }
         t.wg = xcd_remap(vb, nwg);
         t.m0 = (t.wg / p.tiles_n) * TM;
@@ -746,7 +763,7 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     (void)gemm8p_mode();
     if (g_mode8p == 1) return G8_NOT_TAKEN;
     if (d->in_dtype != MOREC_BF16 || a.accumulate != 0 || !a.vec_store || d->split_k > 1) return G8_NOT_TAKEN;
-    if (d->K % KE || d->K < 2 * KE || d->N < 64 || d->M < 1) return G8_NOT_TAKEN;
+    if (d->K % 8 || d->K <= KE || d->N < 64 || d->M < 1) return G8_NOT_TAKEN;      // 16-byte slots; at least two K-tiles (the last may be partial)
     const long tiles = (long)((d->M + TM - 1) / TM) * ((d->N + TN - 1) / TN);
     if (a.colsum && d->M < 128) return G8_NOT_TAKEN;      // partial-row workspace is sized per 64 rows
     // automatic: enough tiles to fill the 256 CUs, and at most a quarter of the tile columns past N (N = 192, 384, 576 of the Swin

@@ -94,7 +94,8 @@ def main():
     ok = True
     if "--no-check" not in sys.argv:
         for M, N, K in [(256, 256, 128), (1000, 512, 192), (3001, 768, 256), (4096, 2304, 768), (2500, 768, 3072), (777, 320, 128), (5000, 1152, 384),
-                        (25000, 768, 3072), (23000, 1024, 1536)]:   # the last two: > 256 tiles with a tail round that is split along K
+                        (25000, 768, 3072), (23000, 1024, 1536),
+                        (5000, 384, 96), (3001, 288, 96), (4096, 256, 200), (2500, 768, 72), (1111, 512, 136)]:   # K not a multiple of 64: partial last K-tile   # the last two: > 256 tiles with a tail round that is split along K
             for kind in ("plain", "bias", "alpha", "gelu", "relu", "dgelu", "drelu", "dgelu_cs", "drelu_cs"):
                 ok &= check_case(M, N, K, kind)
             ok &= check_case(M, N, K, "plain", torch.float32)
