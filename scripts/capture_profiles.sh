@@ -19,3 +19,16 @@ for spec in "51200 2304 768 bias" "51200 3072 768 gelu" "51200 3072 768 dmul" "5
   python $R/scripts/pmc_summary.py /tmp/prof/sq_results.db "%gemm%8p%"
 done
 } > $O/${TAG}_gemm_pmc_sq.txt 2>&1
+# Swin-T step: kernel trace
+rm -f /tmp/prof/ks_results.db
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ks -- python $R/bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof_swin_line.json 2> /dev/null
+python $R/scripts/prof_summary.py /tmp/prof/ks_results.db 6 "$TAG swin_tiny B=64 (704 images/step): rocprofv3 --kernel-trace --stats -- bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 (6 steps traced)" > $O/${TAG}_swin_tiny_kernel_stats.csv
+# scoring kernels at the one-GPU and the 8-rank pooled column count: HBM bytes per launch
+{
+for c in FETCH_SIZE WRITE_SIZE; do
+  echo "# rocprofv3 --kernel-trace --pmc $c -- python scripts/ce_pooled_bench.py   (per-dispatch sums; FETCH_SIZE / WRITE_SIZE in KiB units as the guide's HBM section prescribes)"
+  rm -f /tmp/prof/ce_results.db
+  timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof -o ce -- python $R/scripts/ce_pooled_bench.py > $O/${TAG}_ce_pooled_bench.txt 2>&1
+  python $R/scripts/pmc_summary.py /tmp/prof/ce_results.db "%ce_%"
+done
+} > $O/${TAG}_scoring_pmc.txt 2>&1
