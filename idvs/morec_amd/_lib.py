@@ -38,6 +38,11 @@ class AttnDesc(C.Structure):
                 ("seed", C.c_uint64), ("cu_seqlens", C.c_void_p)]
 
 
+class TransposeItem(C.Structure):      # morec_transpose_item
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_src", C.c_int),
+                ("ld_dst", C.c_int), ("tile0", C.c_int), ("reserved", C.c_int)]
+
+
 class CeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("D", C.c_int), ("Nc", C.c_int), ("col_offset", C.c_int),
                 ("dtype", C.c_int), ("dE_fp32", C.c_int)]
@@ -59,6 +64,7 @@ _SIGS = {
     "morec_gemm_tn": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "morec_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "morec_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "morec_transpose_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

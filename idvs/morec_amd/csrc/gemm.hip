@@ -420,10 +420,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
 
 // vectorised variant (4 elements per global access); needs C % 4 == 0 and both pitches % 4 == 0
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void transpose4_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C,
-                                                         int ld_in, int ld_out) {
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+__device__ __forceinline__ void transpose4_tile(const TI* __restrict__ in, TO* __restrict__ out, int R, int C, int ld_in, int ld_out,
+                                                int r0, int c0, float (&tile)[64][65]) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -443,6 +441,43 @@ __global__ __launch_bounds__(256) void transpose4_kernel(const TI* __restrict__ 
             io<TO>::store4(out + (size_t)c * ld_out + r, v);
         }
     }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose4_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C,
+                                                         int ld_in, int ld_out) {
+    __shared__ float tile[64][65];
+    transpose4_tile<TI, TO>(in, out, R, C, ld_in, ld_out, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+
+// Many matrices in one launch (the Linear weights' W^T copies of a step: 60 launches of 5-6 us each before).  Block b belongs
+// to the item whose [tile0, tile0 + tiles) range holds it; the table lives in device memory and is built once by the caller.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose4_batch_kernel(const morec_transpose_item* __restrict__ items, int n_items) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {        // last item with tile0 <= b (wave-uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const morec_transpose_item it = items[lo];
+    const int t = b - it.tile0, tiles_x = (it.cols + 63) / 64;
+    transpose4_tile<T, T>(reinterpret_cast<const T*>(it.src), reinterpret_cast<T*>(it.dst), it.rows, it.cols, it.ld_src, it.ld_dst,
+                          (t / tiles_x) * 64, (t % tiles_x) * 64, tile);
+}
+
+extern "C" int morec_transpose_batch(const morec_transpose_item* items, int n_items, int n_tiles, int dtype, void* stream) {
+    if (!items || n_items <= 0 || n_tiles <= 0) return MOREC_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MOREC_BF16)
+        hipLaunchKernelGGL((transpose4_batch_kernel<bf16>), dim3(n_tiles), dim3(256), 0, s, items, n_items);
+    else if (dtype == MOREC_F32)
+        hipLaunchKernelGGL((transpose4_batch_kernel<float>), dim3(n_tiles), dim3(256), 0, s, items, n_items);
+    else
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
 }
 
 extern "C" int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype,

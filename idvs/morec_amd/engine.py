@@ -58,12 +58,16 @@ class PreparedLinear:
     wt: torch.Tensor     # [in, pad8(out)] compute dtype (zero padded)
 
 
-def prepare_linear(weight: torch.Tensor, dtype: torch.dtype, shadow: torch.Tensor | None = None) -> PreparedLinear:
-    """``shadow``: an up-to-date copy of ``weight`` already in the compute dtype (the AdamW kernel's bf16 shadow)."""
+def prepare_linear(weight: torch.Tensor, dtype: torch.dtype, shadow: torch.Tensor | None = None,
+                   shadow_t: torch.Tensor | None = None) -> PreparedLinear:
+    """``shadow``: an up-to-date copy of ``weight`` already in the compute dtype (the AdamW kernel's bf16 shadow);
+    ``shadow_t``: its transpose, already refreshed for this step (``TrainStep``'s one batched transpose launch)."""
     if shadow is not None and shadow.dtype == dtype:
         w = shadow
     else:
         w = weight if weight.dtype == dtype else ops.cast(weight.contiguous(), dtype)
+    if shadow_t is not None and shadow_t.dtype == dtype and w is shadow:
+        return PreparedLinear(w, shadow_t)
     wt = ops.transpose(w.contiguous(), out_dtype=dtype)
     return PreparedLinear(w.contiguous(), wt)
 
@@ -236,11 +240,11 @@ def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE, shadow: dict
         wqkv = p.get(a + "qkv_fused")   # arena view over the three adjacent projections, if the caller has one
         if wqkv is None:
             wqkv = torch.cat([p[a + "w_Q.weight"], p[a + "w_K.weight"], p[a + "w_V.weight"]], 0)
-        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(a + "qkv_fused")), bqkv=None,
-                           o=prepare_linear(p[a + "fc.weight"], dtype, sh.get(a + "fc.weight")), bo=None,
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(a + "qkv_fused"), sh.get(a + "qkv_fused" + "^T")), bqkv=None,
+                           o=prepare_linear(p[a + "fc.weight"], dtype, sh.get(a + "fc.weight"), sh.get(a + "fc.weight" + "^T")), bo=None,
                            ln1_g=p[a + "layer_norm.weight"], ln1_b=p[a + "layer_norm.bias"],
-                           f1=prepare_linear(p[f + "w_1.weight"], dtype, sh.get(f + "w_1.weight")), b1=p[f + "w_1.bias"],
-                           f2=prepare_linear(p[f + "w_2.weight"], dtype, sh.get(f + "w_2.weight")), b2=p[f + "w_2.bias"],
+                           f1=prepare_linear(p[f + "w_1.weight"], dtype, sh.get(f + "w_1.weight"), sh.get(f + "w_1.weight" + "^T")), b1=p[f + "w_1.bias"],
+                           f2=prepare_linear(p[f + "w_2.weight"], dtype, sh.get(f + "w_2.weight"), sh.get(f + "w_2.weight" + "^T")), b2=p[f + "w_2.bias"],
                            ln2_g=p[f + "layer_norm.weight"], ln2_b=p[f + "layer_norm.bias"]))
     return layers
 
@@ -304,13 +308,13 @@ def bert_prepare(p: dict, n_layers: int, dtype, prefix: str = TE, shadow: dict |
         if wqkv is None:
             wqkv = torch.cat([p[L + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], 0)
             bqkv = torch.cat([p[L + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
-        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(L + "qkv_fused.weight")), bqkv=bqkv,
-                           o=prepare_linear(p[L + "attention.output.dense.weight"], dtype, sh.get(L + "attention.output.dense.weight")), bo=p[L + "attention.output.dense.bias"],
+        layers.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(L + "qkv_fused.weight"), sh.get(L + "qkv_fused.weight" + "^T")), bqkv=bqkv,
+                           o=prepare_linear(p[L + "attention.output.dense.weight"], dtype, sh.get(L + "attention.output.dense.weight"), sh.get(L + "attention.output.dense.weight" + "^T")), bo=p[L + "attention.output.dense.bias"],
                            ln1_g=p[L + "attention.output.LayerNorm.weight"], ln1_b=p[L + "attention.output.LayerNorm.bias"],
-                           f1=prepare_linear(p[L + "intermediate.dense.weight"], dtype, sh.get(L + "intermediate.dense.weight")), b1=p[L + "intermediate.dense.bias"],
-                           f2=prepare_linear(p[L + "output.dense.weight"], dtype, sh.get(L + "output.dense.weight")), b2=p[L + "output.dense.bias"],
+                           f1=prepare_linear(p[L + "intermediate.dense.weight"], dtype, sh.get(L + "intermediate.dense.weight"), sh.get(L + "intermediate.dense.weight" + "^T")), b1=p[L + "intermediate.dense.bias"],
+                           f2=prepare_linear(p[L + "output.dense.weight"], dtype, sh.get(L + "output.dense.weight"), sh.get(L + "output.dense.weight" + "^T")), b2=p[L + "output.dense.bias"],
                            ln2_g=p[L + "output.LayerNorm.weight"], ln2_b=p[L + "output.LayerNorm.bias"]))
-    return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype, sh.get(prefix + "fc.weight")))
+    return dict(layers=layers, fc=prepare_linear(p[prefix + "fc.weight"], dtype, sh.get(prefix + "fc.weight"), sh.get(prefix + "fc.weight" + "^T")))
 
 
 def token_packing(mask: torch.Tensor):

@@ -163,6 +163,34 @@ def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, see
     return dz, (dz if dzd is None else dzd)
 
 
+class TransposeBatch:
+    """dst_i = src_i^T for a fixed list of (src [R, C], dst [C, ld >= R]) pairs in ONE launch (``morec_transpose_batch``).  The
+    tensors must stay where they are (the device table holds their addresses): persistent weight shadows and their W^T copies."""
+
+    @staticmethod
+    def eligible(src, dst):
+        R, C_ = src.shape
+        return (src.dim() == 2 and src.is_contiguous() and dst.stride(1) == 1 and src.dtype == dst.dtype and C_ % 4 == 0
+                and dst.stride(0) % 4 == 0 and dst.stride(0) >= ((R + 3) & ~3) and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0)
+
+    def __init__(self, pairs):
+        assert pairs, "empty transpose batch"
+        items = (_lib.TransposeItem * len(pairs))()
+        tile0 = 0
+        for i, (src, dst) in enumerate(pairs):
+            assert TransposeBatch.eligible(src, dst), "morec_transpose_batch: shape / alignment rules (include/morec_hip.h)"
+            R, C_ = src.shape
+            items[i] = _lib.TransposeItem(src.data_ptr(), dst.data_ptr(), R, C_, C_, dst.stride(0), tile0, 0)
+            tile0 += ((R + 63) // 64) * ((C_ + 63) // 64)
+        self.n_items, self.n_tiles, self.dtype = len(pairs), tile0, pairs[0][0].dtype
+        self.keep = pairs
+        host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.table = host.to(pairs[0][0].device)
+
+    def run(self):
+        check(_lib.lib().morec_transpose_batch(_p(self.table), self.n_items, self.n_tiles, code(self.dtype), _stream()), "morec_transpose_batch")
+
+
 def pos_grad_(dz, dpos, period):
     M, N = dz.shape
     check(_lib.lib().morec_pos_grad(_p(dz), _p(dpos), M, N, period, code(dz.dtype), _stream()), "morec_pos_grad")

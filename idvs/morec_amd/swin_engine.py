@@ -112,15 +112,15 @@ def swin_prepare(p: dict, shape: SwinShape, dtype, prefix: str = IN, shadow: dic
             if wqkv is None:
                 wqkv = torch.cat([p[A + f"{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0)
                 bqkv = torch.cat([p[A + f"{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")], 0)
-            blocks.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(A + "qkv_fused.weight")), bqkv=bqkv,
-                               o=prepare_linear(p[A + "o_proj.weight"], dtype, sh.get(A + "o_proj.weight")),
-                               f1=prepare_linear(p[L + "mlp.fc1.weight"], dtype, sh.get(L + "mlp.fc1.weight")),
-                               f2=prepare_linear(p[L + "mlp.fc2.weight"], dtype, sh.get(L + "mlp.fc2.weight"))))
+            blocks.append(dict(qkv=prepare_linear(wqkv, dtype, sh.get(A + "qkv_fused.weight"), sh.get(A + "qkv_fused.weight" + "^T")), bqkv=bqkv,
+                               o=prepare_linear(p[A + "o_proj.weight"], dtype, sh.get(A + "o_proj.weight"), sh.get(A + "o_proj.weight" + "^T")),
+                               f1=prepare_linear(p[L + "mlp.fc1.weight"], dtype, sh.get(L + "mlp.fc1.weight"), sh.get(L + "mlp.fc1.weight" + "^T")),
+                               f2=prepare_linear(p[L + "mlp.fc2.weight"], dtype, sh.get(L + "mlp.fc2.weight"), sh.get(L + "mlp.fc2.weight" + "^T"))))
         prep["stages"].append(blocks)
         if s < len(shape.depths) - 1:
             k = sw + f"encoder.layers.{s}.downsample.reduction.weight"
-            prep["merges"].append(prepare_linear(p[k], dtype, sh.get(k)))
-    prep["cls"] = prepare_linear(p[prefix + "classifier.weight"], dtype, sh.get(prefix + "classifier.weight"))
+            prep["merges"].append(prepare_linear(p[k], dtype, sh.get(k), sh.get(k + "^T")))
+    prep["cls"] = prepare_linear(p[prefix + "classifier.weight"], dtype, sh.get(prefix + "classifier.weight"), sh.get(prefix + "classifier.weight" + "^T"))
     return prep
 
 

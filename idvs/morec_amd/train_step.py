@@ -172,6 +172,7 @@ class TrainStep:
         self.groups.append(dict(arena=ParamArena([(n, named[n]) for n in g1], self.device, use_shadow), lr=lr, wd=l2_weight))
         self.frozen = {n: p.data for n, p in named.items() if n not in set(g0) | set(g1)}
         self._build_views()
+        self._build_transposed_shadows()
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
@@ -259,6 +260,50 @@ class TrainStep:
                 if a0.shadow is not None:
                     self.sh[Lp + "qkv_fused.weight"] = a0.span(a0.shadow, wn, (3 * H, H))
 
+    def _build_transposed_shadows(self):
+        """Persistent W^T copies (compute dtype) of every Linear weight the engines' ``*_prepare`` ask a shadow for, refreshed by
+        ONE ``morec_transpose_batch`` launch per step instead of one ``morec_transpose`` launch and allocation per weight (60 per
+        step at BERT-base).  ``self.sh[name + "^T"]`` is what ``engine.prepare_linear`` picks up.  bf16 mode only (no shadows in
+        the exact-fp32 mode: it keeps the per-weight path)."""
+        self._wt_batch = None
+        if not self.sh:
+            return
+        m, asked = self.model, []
+
+        class _Recorder(dict):
+            def get(self, key, default=None):
+                if not key.endswith("^T"):
+                    asked.append(key)
+                return dict.get(self, key, default)
+
+        rec = _Recorder(self.sh)
+        if self.vision:
+            swin_engine.swin_prepare(self.p, self.swin_shape, self.dtype, swin_engine.IN, rec)
+        elif m.use_modal:
+            engine.bert_prepare(self.p, self.bert_layers, self.dtype, engine.TE, rec)
+        engine.sasrec_prepare(self.p, m.args.transformer_block, self.dtype, engine.UE, rec)
+        todo, total = [], 0
+        for k in dict.fromkeys(asked):
+            t = self.sh.get(k)
+            if t is None or t.dim() != 2 or t.dtype != self.dtype or not t.is_contiguous():
+                continue
+            out_f, in_f = t.shape
+            ld = (out_f + 7) // 8 * 8
+            todo.append((k, t, in_f, ld, total))
+            total += (in_f * ld + 7) // 8 * 8
+        if not todo:
+            return
+        store = torch.zeros(total, device=self.device, dtype=self.dtype)      # pad columns stay zero
+        pairs = []
+        for k, t, in_f, ld, off in todo:
+            dst = store[off:off + in_f * ld].view(in_f, ld)
+            if ops.TransposeBatch.eligible(t, dst):
+                self.sh[k + "^T"] = dst
+                pairs.append((t, dst))
+        if pairs:
+            self._wt_store = store
+            self._wt_batch = ops.TransposeBatch(pairs)
+
     # -----------------------------------------------------------------------------------------------
     def forward_backward(self, sample_items_id, sample_items, log_mask):
         """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync).  Under data
@@ -266,6 +311,8 @@ class TrainStep:
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
+        if self._wt_batch is not None:
+            self._wt_batch.run()          # W^T of every Linear weight from the shadows AdamW (or sync_shadow) last wrote
         for grp in self.groups:
             grp["arena"].grad.zero_()
         self._pending, self._reduced = [], []

@@ -96,6 +96,22 @@ size_t morec_gemm_tn_workspace_bytes(int N, int K, int split_m);
  * in_dtype/out_dtype select a fused conversion (f32 -> bf16 weight shadows). */
 int morec_transpose(const void* in, void* out, int R, int C, int ld_in, int ld_out, int in_dtype, int out_dtype,
                     void* stream);
+
+/* Many transposes in ONE launch -- the W^T copies of every Linear weight that dX = dY . W needs once per optimisation step
+ * (T/run.py:246: the weights change once per step; HF Linear backward reads W itself through cuBLAS' transposed operand).
+ * items: DEVICE array of n_items entries sorted by tile0; entry i owns the 64 x 64 tiles [tile0_i, tile0_{i+1}) of the launch's
+ * n_tiles blocks, tiles of one matrix row-major over ceil(rows / 64) x ceil(cols / 64).  dst[c][r] = src[r][c]; every matrix:
+ * cols % 4 == 0, ld_src % 4 == 0, ld_dst % 4 == 0, ld_dst >= rows rounded up to 4, 16-byte aligned bases (same rules as the
+ * vectorised path of morec_transpose; the CALLER checks them -- the table is not readable from the host side of this call). */
+typedef struct {
+    const void* src;
+    void* dst;
+    int rows, cols;       /* of src */
+    int ld_src, ld_dst;   /* elements */
+    int tile0;            /* first block of this matrix */
+    int reserved;
+} morec_transpose_item;
+int morec_transpose_batch(const morec_transpose_item* items, int n_items, int n_tiles, int dtype, void* stream);
 /* elementwise convert n elements */
 int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream);
 /* out = dy * act'(pre), elementwise (act = MOREC_ACT_GELU | MOREC_ACT_RELU); T/model/encoders.py:70 backward */

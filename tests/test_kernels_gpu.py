@@ -188,6 +188,16 @@ def test_transpose_cast_colsum(dt):
     assert rel(out, x4.double().sum(0)) < 1e-5
     xt4 = ops.transpose(x4)          # vectorised path (C % 4 == 0), R % 8 != 0 -> zero pad
     assert xt4.shape == (172, 1304) and torch.equal(xt4[:, :1300], x4.t()) and (xt4[:, 1300:] == 0).all()
+    # many matrices, one launch (the per-step W^T refresh): same results as the single-matrix entry point, pads untouched
+    shapes = [(2304, 768), (768, 768), (3072, 768), (768, 3072), (100, 64), (1300, 172), (8, 4)]
+    srcs = [rnd(r, c, dt=dt, seed=20 + i) for i, (r, c) in enumerate(shapes)]
+    dsts = [torch.zeros((c, (r + 7) // 8 * 8), device=DEV, dtype=dt) for r, c in shapes]
+    tb = ops.TransposeBatch(list(zip(srcs, dsts)))
+    tb.run()
+    for (r, c), x_, y_ in zip(shapes, srcs, dsts):
+        assert torch.equal(y_[:, :r], x_.t()) and (y_[:, r:] == 0).all()
+        assert torch.equal(y_, ops.transpose(x_))
+    assert not ops.TransposeBatch.eligible(rnd(10, 6, dt=dt), torch.zeros(6, 16, device=DEV, dtype=dt))     # C % 4 != 0: single-matrix path
 
 
 @pytest.mark.parametrize("dt", DT)
