@@ -556,6 +556,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
     const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
+#pragma unroll 4
         for (int r = r0 + rl; r < r1; r += 16) {
             float v[4];
             io<T>::load4(in + (size_t)r * ld + n, v);
@@ -577,8 +578,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
 }
 
 int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s) {
-    const int rpb = 512;
-    dim3 grid((N + 63) / 64, (rows + rpb - 1) / rpb);
+    // folds of per-tile / per-sequence partial rows: a few MB spread over >= 512 blocks (with 512 rows per block the
+    // [2560 x 2304] attention-bias partials ran on 180 blocks of 32 dependent loads per lane: 16 us for 24 MB)
+    const int cb = (N + 63) / 64;
+    int rpb = (int)(((long)rows * cb / 512 + 15) & ~15L);
+    rpb = rpb < 16 ? 16 : rpb > 512 ? 512 : rpb;
+    if ((long)rows * N <= (1L << 20) && rows <= 512) rpb = 512;     // small folds: one block per column group, i.e. a fixed summation order
+    dim3 grid(cb, (rows + rpb - 1) / rpb);
     hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, in, out, rows, N, N, rpb);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
