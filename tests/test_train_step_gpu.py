@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _setup(dtype, use_modal=True, seed=0):
+def _setup(dtype, use_modal=True, seed=0, S=10, D=128, B=9, item_num=200):
     from idvs.morec_amd.model import BertShape, HipBertModel, Model
     from idvs.morec_amd.utils.detgen import det_param
-    S, D, T, item_num, B = 10, 128, 30, 200, 9
+    T = 30
     shape = BertShape(vocab_size=1500, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
                       intermediate_size=512, max_position_embeddings=64)
     args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
@@ -83,6 +83,37 @@ def test_train_step_vs_oracle(use_modal):
     # two Adam steps move each weight by <= 2*lr; eps-dominated elements may differ by a fraction of that
     assert worst < 2.5e-4, worst
     print("train_step vs oracle: losses", losses, ref_losses, "worst param diff", worst)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_id_tower_at_launcher_width_vs_oracle(dtype):
+    """IDRec at the embedding width the reference's launcher sweeps from (T/train_id.py:22-26: embedding_dim 512 ... 4096, S = 20;
+    BASELINE.json configs[0]) -- the goldens g1 / g4 hold D = 64 only.  One fused step against the oracle: loss, then every parameter."""
+    import morec_oracle as orc
+    from idvs.morec_amd.train_step import TrainStep
+    S, D = 20, 512
+    model, ids, items, lm, pop, _ = _setup(dtype, use_modal=False, seed=5, S=S, D=D, B=24, item_num=3000)
+    p_ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.02)
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    loss = float(ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm)))
+    ref = orc.model_forward(p_ref, torch.from_numpy(ids).view(-1), torch.from_numpy(items), torch.from_numpy(lm), pop,
+                            max_seq_len=S, embedding_dim=D, n_heads=2, use_modal=False, bert_heads=4)
+    ref.backward()
+    assert abs(loss - ref.item()) < (5e-5 if dtype == "fp32" else 2e-2), (loss, ref.item())
+    worst = 0.0
+    for k, v in p_ref.items():
+        if v.grad is None or k not in ts.g:
+            continue
+        g_ref = v.grad.clone()
+        if k == "id_embedding.weight":
+            g_ref[0] = 0          # padding_idx
+        a, b = ts.g[k].detach().double().cpu(), g_ref.double()
+        den = float(b.norm()) + 1e-12
+        err = float((a - b).norm()) / den
+        worst = max(worst, err)
+        assert err < (5e-4 if dtype == "fp32" else 1e-1) or den < 1e-6, (k, err)      # bf16: measured worst 6.1e-2 (an FFN weight behind ReLU)
+    print(f"IDRec D=512 {dtype}: loss {loss:.6f} vs {ref.item():.6f}, worst relative gradient error {worst:.2e}")
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
