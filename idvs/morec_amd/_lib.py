@@ -96,6 +96,7 @@ _SIGS = {
     "morec_probe": (C.c_int, [_P, _P]),
     "morec_swin_attn_fwd": (C.c_int, [C.POINTER(SwinAttnDesc), _P, _P, _P, _P]),
     "morec_swin_attn_bwd": (C.c_int, [C.POINTER(SwinAttnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "morec_swin_attn_bwd_dbias": (C.c_int, [C.POINTER(SwinAttnDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "morec_swin_bias_expand": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "morec_swin_bias_reduce": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "morec_swin_patchify": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

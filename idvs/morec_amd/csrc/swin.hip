@@ -475,7 +475,9 @@ SwinAttnArgs make_args(const morec_swin_attn_desc* d, int& gx) {
 
 // bf16 fast path on the matrix cores (swin_attn_mfma.hip); MOREC_E_UNSUPPORTED = shape / dtype outside it
 int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
-                                void* dqkv, float* dbias_t, bool backward, hipStream_t s);
+                                void* dqkv, float* dbias_t, bool backward, hipStream_t s, float* csum = nullptr, long csum_rows = 0,
+                                int* csum_rows_needed = nullptr);
+int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
 
 extern "C" int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx,
                                    void* stream) {
@@ -635,4 +637,29 @@ extern "C" int morec_droppath_scale(float* out, int n, float p, uint64_t seed, v
                        make_drop(p, seed));
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
+}
+
+// morec_swin_attn_bwd + the bias gradient of the fused q|k|v projection (HF SwinSelfAttention query / key / value biases,
+// modeling_swin.py:407-409): dbqkv[3 C] (fp32) += column sums of dqkv.  With ws (ws_bytes >= morec-chosen rows x 3 C floats; 64 MiB
+// always suffices for the shapes of this library) the bf16 MFMA path sums inside the attention kernel -- fp32 sums of the
+// UNROUNDED rows -- and one small kernel folds the per-wavefront rows; otherwise: the plain backward followed by morec_colsum.
+extern "C" int morec_swin_attn_bwd_dbias(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, const void* ctx,
+                                         const void* dctx, void* dqkv, float* dbias_t, float* dbqkv, float* ws, size_t ws_bytes,
+                                         void* stream) {
+    int rc = check_attn(d);
+    if (rc) return rc;
+    if (!qkv || !bias_t || !ctx || !dctx || !dqkv || !dbqkv) return MOREC_E_ARG;
+    const int C3 = 3 * d->heads * d->dh;
+    const long rows = (long)d->n_img * d->H * d->W;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ws) {
+        int need = 0;
+        rc = morec_swin_attn_mfma_launch(d, qkv, bias_t, const_cast<void*>(ctx), dctx, dqkv, dbias_t, true, s, ws,
+                                         (long)(ws_bytes / (C3 * sizeof(float))), &need);
+        if (rc == MOREC_OK) return colsum_f32_launch(ws, dbqkv, need, C3, s);
+        if (rc != MOREC_E_UNSUPPORTED) return rc;
+    }
+    rc = morec_swin_attn_bwd(d, qkv, bias_t, ctx, dctx, dqkv, dbias_t, stream);
+    if (rc) return rc;
+    return morec_colsum(dqkv, dbqkv, (int)rows, C3, C3, d->dtype, stream);
 }

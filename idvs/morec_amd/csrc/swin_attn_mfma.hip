@@ -15,6 +15,7 @@
 // Outputs are produced transposed (O^T, dQ^T, dK^T, dV^T) so that a lane owns 4 consecutive head columns of one token
 // row: 8-byte global stores.
 #include <algorithm>
+#include <stdlib.h>
 #include <type_traits>
 #include "common.hpp"
 
@@ -42,6 +43,7 @@ struct SwinMArgs {
     int n_win_total, wpw;  // windows per wavefront
     int gx;                // window groups (4 wavefronts x wpw windows each)
     unsigned qkv_bytes;    // size of qkv / dqkv in bytes (bwd: buffer-descriptor extent, < 4 GiB)
+    float* csum;           // bwd, optional: [gx * 4 wavefronts][3 C] fp32 column sums of the wavefront's dq / dk / dv rows
 };
 
 __device__ __forceinline__ f32x4_t mfma(const uint4& a_rows, const uint4& b_rows, f32x4_t acc) {
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
         // No guarded loads: `valid ? *p : 0` compiles to one basic block per load (each ending in a full s_waitcnt) and a load
         // next to an LDS store stays in program order.  Padded tokens re-read token 0's rows (G.row is clamped); a padded key has
         // bias -inf (probability exactly 0), a padded query row is zeroed in softmax_rows and never stored.  All twelve loads of
-        // the window are issued before the first LDS write.
+        // the window are issued before the first LDS write.  (Requesting the NEXT window's rows a window ahead, as the backward
+        // does, needs 48 more registers: with the 64 bias registers that is one wave per SIMD, and the forward -- short dependency
+        // chains, 3.5 TB/s with two waves -- measured 4-30 % slower that way.)
         uint4 qf[4], kf[4], vf[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -338,6 +342,15 @@ __device__ __forceinline__ uint4 pack_part(const f32x4_t (&p)[4][NTI], int t, in
 
 // The 16 operand rows (q, k, v, dO: 16 bytes each per lane and 16-token block) of one (window, head).  Unguarded loads: padded
 // tokens re-read token 0's rows (see the forward kernel).
+// sum over the 16 lanes of a DPP row (every lane ends up with the total): quad butterflies, then the two mirrors
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+
 struct BwdFrags { uint4 q[4], k[4], v[4], o[4]; };
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
@@ -368,7 +381,8 @@ __device__ __forceinline__ void store4_buf(const __amdgpu_buffer_rsrc_t& rs, uin
 // dK product (the last phase, when the softmax registers are dead) runs -- and q stays in registers for the dK product instead
 // of being re-read.  (Three dependent round trips per window -- q/k, then v/dO, then q again -- with two wavefronts per SIMD
 // to hide them left the kernel at 2 TB/s whatever the stage: profiles/r02_swin_attn.txt.)
-__global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
+template <bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sBias = reinterpret_cast<float*>(smem);                 // [NT (query i)][BP] shared by the block's 4 wavefronts
     char* wbase = reinterpret_cast<char*>(sBias + NT * BP);
@@ -391,6 +405,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) dbacc[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int w0 = (wm.bx * 4 + wave) * a.wpw, w1 = min(a.n_win_total, w0 + a.wpw);
+    // q|k|v bias gradient: column sums of this wavefront's dq / dk / dv rows ([tensor][td], lane = 4 head columns of 16 token rows),
+    // summed BEFORE the bf16 rounding of the stored rows; rows of padded tokens are exactly zero (P = dS = 0 there)
+    f32x4_t cs[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int td = 0; td < 2; ++td) cs[t][td] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     BwdBufs bufs;
     bufs.qkv = __builtin_amdgcn_make_buffer_rsrc((void*)a.qkv, 0, (int)a.qkv_bytes, 0x00020000);
     bufs.dqkv = __builtin_amdgcn_make_buffer_rsrc((void*)a.dqkv, 0, (int)a.qkv_bytes, 0x00020000);
@@ -402,6 +423,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
     }
     for (int g = w0; g < w1; ++g) {
         const LaneGeom G = window_geom(a, g);
+        [[maybe_unused]] BwdFrags fr_next;
+        if (WIDE) {
+            const LaneGeom Gn = window_geom(a, min(g + 1, w1 - 1));
+            load_bwd_frags(bufs, Gn, head, C, pitch, g4, fr_next);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = fr.k[k];
@@ -448,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
             }
-            __builtin_amdgcn_sched_barrier(0);      // the next block starts when this one's registers are free
+            if (!WIDE) __builtin_amdgcn_sched_barrier(0);      // the next block starts when this one's registers are free
         };
         block(std::integral_constant<int, 0>{});
         block(std::integral_constant<int, 1>{});
@@ -477,6 +503,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                     for (int td = 0; td < 2; ++td)
                         store4_buf(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), 32 * td, acc[td][ti], a.scale);
                 }
+            if (a.csum) {
+#pragma unroll
+                for (int td = 0; td < 2; ++td)
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) cs[0][td] += acc[td][ti] * a.scale;
+            }
         }
         // dV^T[d][j] = sum_i dO[i][d] P[i][j]: both operands are transposed reads (dO tile, P tile)
         {
@@ -504,6 +536,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                     for (int td = 0; td < 2; ++td)
                         store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 4 + 32 * td, acc[td][tj], 1.0f);
                 }
+            if (a.csum) {
+#pragma unroll
+                for (int td = 0; td < 2; ++td)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) cs[2][td] += acc[td][tj];
+            }
         }
         wave_lds_fence();
         // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]: Q (still in registers) and dS replace dO and P in their tiles
@@ -519,9 +557,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
             }
         }
         wave_lds_fence();
-        {   // the next window's operand rows (the last window re-reads itself: no guarded loads), in flight during the dK product
+        if (!WIDE) {   // the next window's operand rows (the last window re-reads itself: no guarded loads), in flight during the dK product
             const LaneGeom Gn = window_geom(a, min(g + 1, w1 - 1));
             load_bwd_frags(bufs, Gn, head, C, pitch, g4, fr);
+        } else {
+            fr = fr_next;     // requested at the top of this window (a second register set: one wave per SIMD has 512 registers)
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -549,8 +589,25 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
                     for (int td = 0; td < 2; ++td)
                         store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 2 + 32 * td, acc[td][tj], a.scale);
                 }
+            if (a.csum) {
+#pragma unroll
+                for (int td = 0; td < 2; ++td)
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) cs[1][td] += acc[td][tj] * a.scale;
+            }
         }
         wave_lds_fence();
+    }
+    if (a.csum) {   // one row per wavefront slot: [slot][tensor * C + head * 32 + 16 td + 4 g + e]; empty slots write zeros
+        float* wrow = a.csum + (size_t)(wm.bx * 4 + wave) * (3 * C) + head * DH + 4 * g4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                float4 v;
+                v.x = row16_sum(cs[t][td][0]); v.y = row16_sum(cs[t][td][1]); v.z = row16_sum(cs[t][td][2]); v.w = row16_sum(cs[t][td][3]);
+                if (c == 0) *reinterpret_cast<float4*>(wrow + t * C + 16 * td) = v;
+            }
     }
     if (a.dbias_t) {
         // reduce the 4 wavefronts' register accumulators through LDS (the per-wave tiles are free now), then one global
@@ -580,8 +637,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a)
 }  // namespace
 
 // bf16, window 7, head width 32 only; anything else returns MOREC_E_UNSUPPORTED and the caller falls back to swin.hip's kernels
+// csum / csum_rows (backward, optional): scratch for the per-wavefront column sums of dqkv and the number of rows it holds;
+// *csum_rows_needed reports how many the launch geometry needs (the caller folds that many rows)
 int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
-                                void* dqkv, float* dbias_t, bool backward, hipStream_t s) {
+                                void* dqkv, float* dbias_t, bool backward, hipStream_t s, float* csum, long csum_rows, int* csum_rows_needed) {
     if (d->dtype != MOREC_BF16 || d->window != WS || d->dh != DH) return MOREC_E_UNSUPPORTED;
     if ((d->heads * DH) % 8) return MOREC_E_UNSUPPORTED;
     SwinMArgs a{};
@@ -592,6 +651,9 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     const long tiles = (long)a.n_win_total * d->heads;
     a.wpw = (int)std::max<long>(1, std::min<long>(32, tiles / 8192));
     a.gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
+    if (csum_rows_needed) *csum_rows_needed = a.gx * 4;
+    a.csum = (backward && csum && csum_rows >= (long)a.gx * 4) ? csum : nullptr;
+    if (backward && csum && !a.csum) return MOREC_E_UNSUPPORTED;
     dim3 grid(((a.gx + 7) / 8) * 8 * d->heads), block(256);
     const unsigned long long qkv_bytes = (unsigned long long)d->n_img * d->H * d->W * 3 * d->heads * DH * 2;
     if (backward && qkv_bytes >= 0xffffffffull) return MOREC_E_UNSUPPORTED;     // 32-bit buffer offsets in the backward kernel
@@ -602,10 +664,14 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
         const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, grid, block, lds, s, a);
+        static int wide = -1;
+        if (wide < 0) { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); wide = e ? atoi(e) : 1; }
+        if (wide) hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, grid, block, lds, s, a);
+        else hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<false>, grid, block, lds, s, a);
     }
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;

@@ -346,11 +346,18 @@ def swin_attn_fwd(desc, qkv, bias_t):
     return ctx
 
 
-def swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t=None):
+def swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t=None, dbqkv=None):
+    """``dbqkv``: fp32 [3 C] gradient buffer of the fused q|k|v bias, accumulated into (column sums of dqkv)."""
     _dev(dctx), _dev(ctx)
     dqkv = torch.empty_like(qkv)
-    check(_lib.lib().morec_swin_attn_bwd(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _p(dctx), _p(dqkv), _p(dbias_t),
-                                         _stream()), "morec_swin_attn_bwd")
+    if dbqkv is None:
+        check(_lib.lib().morec_swin_attn_bwd(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _p(dctx), _p(dqkv), _p(dbias_t),
+                                             _stream()), "morec_swin_attn_bwd")
+    else:
+        n_win = desc.n_img * (desc.H // desc.window) * (desc.W // desc.window)
+        ws = torch.empty((n_win, qkv.shape[1]), device=qkv.device, dtype=torch.float32)
+        check(_lib.lib().morec_swin_attn_bwd_dbias(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _p(dctx), _p(dqkv), _p(dbias_t),
+                                                   _p(dbqkv), _p(ws), ws.numel() * 4, _stream()), "morec_swin_attn_bwd_dbias")
     return dqkv
 
 

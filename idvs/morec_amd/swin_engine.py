@@ -250,14 +250,13 @@ def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             linear_wgrad_(da, ctx, grads[A + "o_proj.weight"])
             dctx = ops.gemm_nt(da, w["o"].wt, K=da.shape[1], N=C)
             dbias_t = torch.zeros_like(bias_t)
-            dqkv = ops.swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t)
-            ops.swin_bias_reduce_(dbias_t, grads[A + "relative_position_bias.relative_position_bias_table"], desc.window)
             gw, gb = grads.get(A + "qkv_fused.weight"), grads.get(A + "qkv_fused.bias")
             fused = gw is not None
             if not fused:
-                gw = torch.zeros((3 * C, C), device=dqkv.device, dtype=torch.float32)
-                gb = torch.zeros(3 * C, device=dqkv.device, dtype=torch.float32)
-            ops.colsum_(dqkv, gb)
+                gw = torch.zeros((3 * C, C), device=dctx.device, dtype=torch.float32)
+                gb = torch.zeros(3 * C, device=dctx.device, dtype=torch.float32)
+            dqkv = ops.swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t, dbqkv=gb)      # + d(q|k|v bias) = column sums of dqkv
+            ops.swin_bias_reduce_(dbias_t, grads[A + "relative_position_bias.relative_position_bias_table"], desc.window)
             linear_wgrad_(dqkv, xn, gw)
             if not fused:
                 for i, n in enumerate(("q_proj", "k_proj", "v_proj")):

@@ -193,6 +193,11 @@ int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qkv, const fl
 /* dqkv from dctx (P recomputed; ctx = saved forward output); dbias_t (may be NULL) += dS summed over windows. */
 int morec_swin_attn_bwd(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, const void* ctx,
                         const void* dctx, void* dqkv, float* dbias_t, void* stream);
+/* The same backward plus the bias gradient of the fused q|k|v projection (modeling_swin.py:407-409): dbqkv[3 heads dh] (fp32) +=
+ * column sums of dqkv.  ws: optional scratch (n_windows x 3 heads dh floats is always enough) -- with it the bf16 path sums
+ * inside the attention kernel (fp32 sums of the rows BEFORE their bf16 rounding) instead of re-reading dqkv. */
+int morec_swin_attn_bwd_dbias(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, const void* ctx,
+                              const void* dctx, void* dqkv, float* dbias_t, float* dbqkv, float* ws, size_t ws_bytes, void* stream);
 /* bias_t[h][j][i] = table[rel_index(i, j)][h] (SwinRelativePositionBias :329-370) and its transpose-scatter gradient */
 int morec_swin_bias_expand(const float* table, float* bias_t, int window, int heads, void* stream);
 int morec_swin_bias_reduce(const float* dbias_t, float* dtable, int window, int heads, void* stream);

@@ -89,6 +89,15 @@ def test_window_attention(dt, shift, H, W, heads, n_img):
     tolg = 5e-5 if dt == "fp32" else 3e-2
     assert froerr(dqkv.float().cpu().numpy(), q32.grad.numpy()) < tolg
     assert froerr(dtab.cpu().numpy(), t32.grad.numpy()) < tolg
+    # the same backward with the fused q|k|v bias gradient: same dqkv, same dbias_t, dbqkv += column sums of dqkv (the MFMA path
+    # sums the rows before their bf16 rounding: agreement with the sums of the STORED rows to rounding noise, not bit for bit)
+    dbias2, dbq = torch.zeros_like(bias_t), torch.full((3 * C,), 0.5, device=DEV)
+    dqkv2 = ops.swin_attn_bwd(desc, qd, bias_t, ctx, dctx.to(DEV), dbias2, dbqkv=dbq)
+    assert torch.equal(dqkv2, dqkv)
+    assert froerr(dbias2.cpu().numpy(), dbias_t.cpu().numpy()) < 1e-5
+    want = 0.5 + dqkv.double().sum(0).cpu().numpy()
+    assert froerr(dbq.cpu().numpy(), want) < (1e-5 if dt == "fp32" else 3e-3)
+    assert froerr(dbq.cpu().numpy() - 0.5, q32.grad.double().sum(0).numpy()) < tolg
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
