@@ -362,52 +362,53 @@ extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void*
     return MOREC_E_DTYPE;
 }
 
+// One instantiation's launch.  Rows per block: ONE round of blocks at the occupancy this variant really gets (LDS partial sets and
+// registers: 2 blocks per CU at H = 768, 4 at the Swin stage widths -- a grid sized for 2 left half of the wave slots of the
+// C = 96 launch empty), never fewer than 64 rows so that the per-block column flush (3 N atomics) stays small.
+// (64-row blocks at M = 51200, H = 768: 800 blocks = 1.56 rounds, 12 % slower than one round.)
+template <typename T, int V, int L, bool FULL>
+static void ln_bwd_launch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd, const float* gamma,
+                          void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M, int N, DropRng din, DropRng dout,
+                          const void* dres, const float* rowscale, int rps, hipStream_t s) {
+    const size_t lds = ((dgamma || dbias) ? (size_t)12 * (64 / L) * N : 0) * sizeof(float) + N * sizeof(float);
+    static size_t lds_seen = ~(size_t)0;
+    static int slots = 0;
+    if (lds != lds_seen) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V, L, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, n_cu = 0, nb = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ln_bwd_kernel<T, V, L, FULL>, 256, lds) != hipSuccess || nb <= 0) {
+            (void)hipGetLastError();
+            nb = 2;
+        }
+        slots = nb * n_cu;
+        lds_seen = lds;
+    }
+    const int rpb = std::max(64, (((M + slots - 1) / slots) + 15) & ~15);
+    dim3 grid((M + rpb - 1) / rpb), block(256);
+    hipLaunchKernelGGL((ln_bwd_kernel<T, V, L, FULL>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b, (const T*)z, mean, rstd, gamma,
+                       (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, dout, (const T*)dres, rowscale, rps);
+}
+
 template <typename T>
 static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd,
                            const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M,
                            int N, DropRng din, DropRng dout, const void* dres, const float* rowscale, int rps, hipStream_t s) {
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
-    // rows per block: enough blocks to fill the chip, few enough that the per-block column flush (N atomics x 3) stays small
-    // rows per block: ONE round of blocks at two per CU (LDS and registers allow two), never fewer than 64 rows so that the
-    // per-block column flush (3 N atomics) stays small.  (64-row blocks at M = 51200: 800 blocks = 1.56 rounds, 12 % slower.)
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, n_cu = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        slots = 2 * n_cu;
-    }
-    const int rpb = std::max(64, (((M + slots - 1) / slots) + 7) & ~7);
-    dim3 grid((M + rpb - 1) / rpb), block(256);
-#define LN_BWD_L(V, L)                                                                                          \
-    do {                                                                                                        \
-        const size_t lds = ((dgamma || dbias) ? (size_t)12 * (64 / L) * N : 0) * sizeof(float) + N * sizeof(float); \
-        if (lds > 48 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V, L>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-        hipLaunchKernelGGL((ln_bwd_kernel<T, V, L>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b,       \
-                           (const T*)z, mean, rstd, gamma, (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, \
-                           dout, (const T*)dres, rowscale, rps);                                                \
-    } while (0)
-#define LN_BWD(V) LN_BWD_L(V, 64)
-    if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16);
-    else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32);
-    else if (N == 96 * vio<T>::EV) {
-        const size_t lds = ((dgamma || dbias) ? (size_t)12 * 2 * N : 0) * sizeof(float) + N * sizeof(float);
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, 3, 32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ln_bwd_kernel<T, 3, 32, true>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b, (const T*)z, mean, rstd, gamma,
-                           (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, dout, (const T*)dres, rowscale, rps);
-    }
-    else if (vpl <= 1) LN_BWD(1);
-    else if (vpl <= 2) LN_BWD(2);
-    else if (vpl <= 3) LN_BWD(3);
-    else if (vpl <= 4) LN_BWD(4);
-    else if (vpl <= 8) LN_BWD(8);
-    else if (vpl <= 16) LN_BWD(16);
+#define LN_BWD_L(V, L, F) ln_bwd_launch<T, V, L, F>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rps, s)
+    if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16, false);
+    else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32, false);
+    else if (N == 96 * vio<T>::EV) LN_BWD_L(3, 32, true);
+    else if (vpl <= 1) LN_BWD_L(1, 64, false);
+    else if (vpl <= 2) LN_BWD_L(2, 64, false);
+    else if (vpl <= 3) LN_BWD_L(3, 64, false);
+    else if (vpl <= 4) LN_BWD_L(4, 64, false);
+    else if (vpl <= 8) LN_BWD_L(8, 64, false);
+    else if (vpl <= 16) LN_BWD_L(16, 64, false);
     else return MOREC_E_UNSUPPORTED;
-#undef LN_BWD
 #undef LN_BWD_L
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;

