@@ -448,6 +448,18 @@ def main():
         out["padded_token_layout"] = padded_info
     if dedup_info is not None:
         out["with_item_dedup"] = dedup_info
+    # secondary line (never `value`): the vision variant of the same path (V/train_swin_tiny.py:22-41: Swin-T, B = 64/GPU, 704 images
+    # per step), measured by a child run of this file so that the driver's record carries it
+    if not vision and not id_tower and a.dtype == "bf16" and not a.no_secondary and world == 1:
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2",
+                                "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=240)
+            vj = json.loads(r.stdout.strip().splitlines()[-1])
+            out["vision_swin_tiny"] = {"ms_per_step": vj["ms_per_step"], "user_seq_per_s": vj["value"], "images_per_s": round(vj["value"] * 11, 1),
+                                       "config": vj["config"]["workload"], "note": "python bench.py --tower swin_tiny --batch 64 (6 steps)"}
+        except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
+            out["vision_swin_tiny"] = {"error": f"{type(e).__name__}: {e}"}
     if fp32_info is not None:
         out["fp32_parity_mode"] = fp32_info
         out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 5e-3, gradient norms 2.5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 / < 1e-2 / 0.9 %)"
