@@ -755,7 +755,11 @@ extern "C" int morec_tuning_set(const char* key, int value) {
 }
 
 int gemm8p_mode() {
-    if (g_mode8p < 0) { const char* e = getenv("MOREC_GEMM8P"); g_mode8p = e ? atoi(e) : 0; }
+    if (g_mode8p < 0) {
+        const char* e = getenv("MOREC_GEMM8P");
+        g_mode8p = e ? atoi(e) : 0;
+        if (const char* d = getenv("MOREC_GEMM8P_DEBUG")) g_debug8p = atoi(d);     // ablation bits for whole-step A/B runs
+    }
     return g_mode8p;
 }
 
