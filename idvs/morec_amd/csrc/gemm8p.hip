@@ -330,50 +330,48 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
     }
     G8_STAMPW(1, cur.wg);
     if (cur.tail >= 0) {
-        // ---- tail split: this workgroup holds the sums over PART of K.  chunk 1 (the producer: the shorter K range, so that it
-        // is normally done first) parks its accumulators in p.tail_ws -- lane-linear, 32 x [512 lanes x 16 B]: every store / load
-        // instruction moves one contiguous 8 KiB -- and raises the tile's flag; chunk 0 (the consumer) waits for the flag, adds
-        // the parked half to its registers and runs the epilogue.  The exchange uses agent-scope (sc1) stores and loads, which
-        // go through to the memory side of the per-XCD L2s: "store complete" (vmcnt 0) is "visible to the other XCDs".  (A release
-        // fence instead -- __threadfence: buffer_wbl2 -- writes back EVERY dirty line of the XCD's L2, i.e. the output tiles of
-        // the rounds before: 60 us per launch.)  The consumer only ever waits for a workgroup of its own grid; sum order is fixed
-        // (consumer + producer), so results are bit-identical from run to run.
+        // ---- tail split: this workgroup holds the sums over PART of K.  Both parts park their accumulators in p.tail_ws -- lane-linear,
+        // 32 x [512 lanes x 16 B]: every store / load instruction moves one contiguous 8 KiB -- and take a ticket; the SECOND arrival
+        // adds the other part to its registers and runs the epilogue, the first one is done.  Nobody ever waits for another
+        // workgroup (no co-residency assumption: two such grids sharing a GPU cannot deadlock each other), and a + b does not depend
+        // on who arrives last: results are bit-identical from run to run.  The exchange uses agent-scope (sc1) stores and loads,
+        // which go through to the memory side of the per-XCD L2s: "store complete" (vmcnt 0) is "visible to the other XCDs".  (A
+        // release fence instead -- __threadfence: buffer_wbl2 -- writes back EVERY dirty line of the XCD's L2, i.e. the output
+        // tiles of the rounds before: 60 us per launch.)  The part with the shorter K range normally arrives first, so the
+        // longer one finds the data waiting.
         int tid_t = threadIdx.x;
         asm volatile("" : "+v"(tid_t));
-        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tail_ws + (size_t)cur.tail * (TM * TN)), 0, TM * TN * 4, 0x00020000);
-        const bool producer = cur.chunk == 1;
-        if (producer) {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tail_ws + (size_t)(cur.tail * 2 + cur.chunk) * (TM * TN)), 0,
+                                                                            TM * TN * 4, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        u32x4_t v;
+                for (int g = 0; g < 4; ++g) {
+                    u32x4_t v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * g + e]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rw, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
-                    }
-            vm_wait<0>();
-        }
+                    for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][4 * g + e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rw, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
+                }
+        vm_wait<0>();
         __syncthreads();
-        if (threadIdx.x == 0) {
-            if (producer) {
-                __hip_atomic_store(p.tail_cnt + cur.tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                while (__hip_atomic_load(p.tail_cnt + cur.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-                __hip_atomic_store(p.tail_cnt + cur.tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-            }
-        }
+        int* flag = reinterpret_cast<int*>(smem + LDS_BYTES);      // first word of wave 0's (idle) epilogue slice
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(p.tail_cnt + cur.tail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (producer) return;      // (one exit behind the common barriers: an exit inside the store branch made hipcc spill 130 registers)
+        const int ticket = __builtin_amdgcn_readfirstlane(*flag);
+        __syncthreads();
+        if (ticket == 0) return;
+        if (threadIdx.x == 0) __hip_atomic_store(p.tail_cnt + cur.tail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.tail_ws + (size_t)(cur.tail * 2 + (cur.chunk ^ 1)) * (TM * TN)), 0,
+                                                                            TM * TN * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {       // 8 x 16 B per lane in flight per round trip (16 would spill the accumulators)
             u32x4_t v[2][4];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) v[j][g] = __builtin_amdgcn_raw_buffer_load_b128(rw, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
+                for (int g = 0; g < 4; ++g) v[j][g] = __builtin_amdgcn_raw_buffer_load_b128(rr, tid_t * 16, ((i * 2 + j) * 4 + g) * (THREADS * 16), 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -652,10 +650,10 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     // Work list of workgroup b (G = gridDim.x): F = nwg / G full rounds of tiles b, b + G, ...; then the R = nwg % G tail tiles.
     // When at most half of the workgroups would have a tail tile (2 R <= G) and K is long (>= 24 K-tiles: below that the exchange
     // costs what the split saves), every tail tile is cut in two K ranges taken by workgroups r and r + R: the last, partly
-    // filled round costs ~0.56 of a tile time + the exchange instead of a whole one (600 tiles on 256 CUs: 2.6 instead of 3).
+    // filled round costs ~0.54 of a tile time + the exchange instead of a whole one (600 tiles on 256 CUs: 2.6 instead of 3).
     const int G = gridDim.x, F = nwg / G, R = nwg - F * G;
     const bool split = p.tail_ws != nullptr && F >= 1 && R >= 1 && 2 * R <= G && nk >= 24;
-    const int nk0 = (nk + p.tail_bias) / 2;   // the consumer's share: a little more than half (the producer's exchange hides behind it); flat optimum 2..6
+    const int nk0 = (nk + p.tail_bias) / 2;   // part 0's share: a little more than half, so that part 1's data is normally waiting when part 0 arrives; flat optimum 2..6
     const int n_units = F + ((int)blockIdx.x < (split ? 2 * R : R) ? 1 : 0);
     auto unit_at = [&](int i) {
         TileXY t;
@@ -692,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
 }
 
 // Tail-split scratch: per stream (launches on one stream are ordered, so they can share it; two streams must not), sized for the
-// largest split (n_cu / 2 tail tiles x 256 KiB = 32 MiB at 256 CUs) + the arrival counters, allocated on first use
+// largest split (n_cu / 2 tail tiles x 2 parts x 256 KiB = 64 MiB at 256 CUs) + the arrival counters, allocated on first use
 // and kept.  More than 8 streams: the ninth runs without the split.
 static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
     struct Slot { hipStream_t s; float* ws; int* cnt; int dev; };
@@ -703,7 +701,7 @@ static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
     for (int i = 0; i < n_slots; ++i)
         if (slots[i].s == s && slots[i].dev == dev) { a.tail_ws = slots[i].ws; a.tail_cnt = slots[i].cnt; return; }
     if (n_slots == 8) return;
-    const size_t ws_bytes = (size_t)(n_cu / 2) * TM * TN * sizeof(float), cnt_bytes = (size_t)n_cu * sizeof(int);
+    const size_t ws_bytes = (size_t)n_cu * TM * TN * sizeof(float), cnt_bytes = (size_t)n_cu * sizeof(int);
     char* base = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&base), ws_bytes + cnt_bytes) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipMemset(base + ws_bytes, 0, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(base); return; }
@@ -741,7 +739,7 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // 0: automatic (eligible large problems), 1: never, 2: every eligible problem regardless of size
-static int g_mode8p = -1, g_debug8p = 0, g_tail_bias = 4;
+static int g_mode8p = -1, g_debug8p = 0, g_tail_bias = 2;
 static unsigned long long g_stamps = 0;
 extern "C" int morec_tuning_set(const char* key, int value) {
     if (!key) return MOREC_E_ARG;

@@ -22,9 +22,9 @@ struct GemmArgs {
     unsigned long long* stamps;   // gemm8p: per-workgroup s_memtime stamps (debug bit 8), else null
     int debug;       // gemm8p ablation bits (tuning key "gemm8p_debug"; 0 in production)
     float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
-    float* tail_ws;  // gemm8p tail split: fp32 partial tiles [tail tiles][256 x 256], or null (no split)
+    float* tail_ws;  // gemm8p tail split: fp32 partial tiles [tail tiles][2 parts][256 x 256], or null (no split)
     int tail_bias;   // gemm8p tail split: the consumer takes (nk + tail_bias) / 2 of the nk K-tiles
-    int* tail_cnt;   // gemm8p tail split: one ready flag per tail tile (zero between launches)
+    int* tail_cnt;   // gemm8p tail split: one arrival counter per tail tile (zero between launches)
 };
 
 // gemm8p.hip: runs the launch on the eight-phase kernel when the problem is eligible (returns MOREC_OK / an error) or
