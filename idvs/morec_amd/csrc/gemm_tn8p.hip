@@ -44,7 +44,7 @@ struct TnArgs8 {
     const bf16* DY;
     const bf16* X;
     float* out;        // slab base ([zs][N][K]) or C itself when there is one chunk
-    int M, N, K, ldy, ldx, ldo, mchunk, tiles_n, tiles_k;
+    int M, N, K, ldy, ldx, ldo, mchunk, tiles_n, tiles_k, zs;
     size_t slab_stride;
 };
 
@@ -260,11 +260,18 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
 
 __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wg = xcd_remap(blockIdx.x, p.tiles_n * p.tiles_k);
+    // Work items in (token chunk, n-tile, k-tile) order, k fastest, dealt to the XCDs in CONTIGUOUS runs (xcd_remap over the whole
+    // launch): the tiles of one chunk -- which share its DY panel (across k-tiles) and its X panel (across n-tiles) and walk the
+    // tokens in lockstep -- then sit behind ONE L2.  With the chunk on the grid's z axis they were spread over all eight XCDs and
+    // every L2 fetched its own copy of the panels: 2.5x the algorithmic bytes from HBM (profiles/r02d_gemm_pmc.json), which made
+    // this kernel bandwidth-bound (3.4 k cycles per 64-token stage against 2.3 k for the NT kernel's K-tile).
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int item = xcd_remap(blockIdx.x, tiles * p.zs);
+    const int z = item / tiles, wg = item - z * tiles;
     const int n0 = (wg / p.tiles_k) * 256, k0 = (wg % p.tiles_k) * 256;
-    const int mbeg = blockIdx.z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
+    const int mbeg = z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
     tn_body(p, smem, p.DY + (size_t)mbeg * p.ldy + n0, p.X + (size_t)mbeg * p.ldx + k0, n0, k0, mbeg, mend,
-            p.out + (size_t)blockIdx.z * p.slab_stride);
+            p.out + (size_t)z * p.slab_stride);
 }
 }  // namespace
 
@@ -288,13 +295,13 @@ int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_
     if ((long)M * ldy * 2 >= 0x7fffffffL || (long)M * ldx * 2 >= 0x7fffffffL) return G8_NOT_TAKEN;   // 32-bit stage offsets
     TnArgs8 a;
     a.DY = DY; a.X = X; a.out = out; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.ldo = ldo; a.mchunk = mchunk;
-    a.tiles_n = tiles_n; a.tiles_k = tiles_k; a.slab_stride = slab_stride;
+    a.tiles_n = tiles_n; a.tiles_k = tiles_k; a.zs = zs; a.slab_stride = slab_stride;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn8p_kernel, dim3(tiles_n * tiles_k, 1, zs), dim3(THREADS), LDS_TOTAL, s, a);
+    hipLaunchKernelGGL(gemm_tn8p_kernel, dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
