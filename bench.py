@@ -372,7 +372,7 @@ def main():
                          "frac_of_f32_mfma_peak": round(tf32 / MFMA_PEAK_TFLOPS["f32"], 4),
                          "note": "compute_dtype=fp32: every GEMM on exact-fp32 MFMA; the mode whose loss matches the reference goldens "
                                  "to < 1e-4 (tests/test_model_gpu.py g6). tests/test_bench_mode_parity_gpu.py bounds the bf16 mode "
-                                 "against it at this configuration: step-0 loss 5e-3 (measured 1.3e-3), gradient norms 2.5e-2 (measured < 1e-2), 20-step loss curve 2 % (measured 0.9 %)"}
+                                 "against it at this configuration: step-0 loss 3e-2 (measured 1.3e-3 ... 1.5e-2: rounding-pattern dependent), gradient norms 5e-2 (measured 0.6e-2 ... 2.3e-2), 20-step loss curve 2 % (measured 0.9 %)"}
             (ts, ) = saved
             del ts32, model32
             torch.cuda.empty_cache()
@@ -462,7 +462,7 @@ def main():
             out["vision_swin_tiny"] = {"error": f"{type(e).__name__}: {e}"}
     if fp32_info is not None:
         out["fp32_parity_mode"] = fp32_info
-        out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 5e-3, gradient norms 2.5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 / < 1e-2 / 0.9 %)"
+        out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 3e-2, gradient norms 5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 ... 1.5e-2 depending on the GEMM summation order / 0.6e-2 ... 2.3e-2 / 0.9 %)"
     if a.dedup:
         out["config"]["item_dedup"] = True
     if vision:
