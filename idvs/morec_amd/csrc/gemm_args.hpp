@@ -23,6 +23,7 @@ struct GemmArgs {
     int debug;       // gemm8p ablation bits (tuning key "gemm8p_debug"; 0 in production)
     float* colsum;   // CS kernels: fp32 workspace [partial rows][N] of per-wave-block / per-tile column sums of C
     float* tail_ws;  // gemm8p tail split: fp32 partial tiles [tail tiles][2 parts][256 x 256], or null (no split)
+    int tail_split;  // gemm8p: 1 = split the tail round along K (opt-in)
     int tail_bias;   // gemm8p tail split: the consumer takes (nk + tail_bias) / 2 of the nk K-tiles
     int* tail_cnt;   // gemm8p tail split: one arrival counter per tail tile (zero between launches)
 };

@@ -2,6 +2,7 @@
 import os, sys, runpy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from idvs.morec_amd import _lib
+_lib.lib().morec_tuning_set(b"gemm8p_tail_split", 1)
 M = sys.argv[1] if len(sys.argv) > 1 else "51200"
 for dbg, bias, name in ((128, 6, "tail split off"), (0, 2, "on, bias 2"), (0, 4, "on, bias 4"), (0, 6, "on, bias 6"), (0, 8, "on, bias 8"), (0, 10, "on, bias 10")):
     print("====", name, flush=True)

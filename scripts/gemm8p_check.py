@@ -8,6 +8,7 @@ from idvs.morec_amd._lib import ACT_GELU, ACT_RELU, ACT_NONE
 
 dev, dt = "cuda", torch.bfloat16
 L = _lib.lib()
+L.morec_tuning_set(b"gemm8p_tail_split", 1)     # exercise the (opt-in) K split of the tail round on the shapes that qualify
 
 
 def mode(m):

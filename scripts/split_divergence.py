@@ -11,6 +11,7 @@ from idvs.morec_amd.train_step import TrainStep
 import test_bench_mode_parity_gpu as t
 
 L = _lib.lib()
+L.morec_tuning_set(b"gemm8p_tail_split", 1)
 B, S, T, D, item_num = 128, 20, 30, 512, 20000
 shape = BertShape.named("base")
 rng = np.random.default_rng(12345)

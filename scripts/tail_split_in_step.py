@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 from idvs.morec_amd import ops, _lib
 L = _lib.lib()
+L.morec_tuning_set(b"gemm8p_tail_split", 1)
 real = ops.gemm_nt
 seen = {}
 

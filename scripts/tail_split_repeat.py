@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from idvs.morec_amd import ops, _lib
 L = _lib.lib()
+L.morec_tuning_set(b"gemm8p_tail_split", 1)
 L.morec_tuning_set(b"gemm8p", 2)
 dev, dt = "cuda", torch.bfloat16
 for (M, N, K) in [(51200, 768, 3072), (50937, 768, 3072), (51200, 768, 2304)]:

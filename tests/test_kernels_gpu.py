@@ -468,3 +468,25 @@ def test_eval_rank():
     ok = targets != np.array([h[0] for h in histories])
     assert np.array_equal(rank.cpu().numpy()[ok], ref[ok])
     assert (rank.cpu().numpy()[~ok] > 10).all()
+
+
+def test_gemm8p_tail_split_opt_in():
+    """The K split of the eight-phase GEMM's tail round (opt-in tuning key): as close to an fp32 product as the unsplit launch, and
+    bit-identical from run to run (600 tiles on 256 CUs: 88 tail tiles, each summed by two workgroups)."""
+    from idvs.morec_amd import _lib
+    L = _lib.lib()
+    M, N, K = 51200, 768, 3072
+    a = rnd(M, K, dt=torch.bfloat16, scale=0.5); b = rnd(N, K, dt=torch.bfloat16, scale=0.5, seed=3)
+    try:
+        assert L.morec_tuning_set(b"gemm8p_tail_split", 0) == 0
+        base = ops.gemm_nt(a, b)
+        assert L.morec_tuning_set(b"gemm8p_tail_split", 1) == 0
+        o1, o2 = ops.gemm_nt(a, b), ops.gemm_nt(a, b)
+    finally:
+        L.morec_tuning_set(b"gemm8p_tail_split", 0)
+    assert torch.equal(o1, o2)
+    exact = a.float() @ b.float().t()
+    e_split, e_base = (o1.float() - exact).abs(), (base.float() - exact).abs()
+    assert float(e_split.max()) <= float(e_base.max()) * 1.001 + 1e-6
+    assert abs(float(e_split.mean()) / float(e_base.mean()) - 1.0) < 1e-3
+    assert int((o1 != base).sum()) < 1e-3 * o1.numel()          # the same numbers up to the summation order
