@@ -355,7 +355,7 @@ def swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias_t=None, dbqkv=None):
                                              _stream()), "morec_swin_attn_bwd")
     else:
         n_win = desc.n_img * (desc.H // desc.window) * (desc.W // desc.window)
-        ws = torch.empty((n_win, qkv.shape[1]), device=qkv.device, dtype=torch.float32)
+        ws = torch.empty(((n_win + 3) // 4 * 4, qkv.shape[1]), device=qkv.device, dtype=torch.float32)     # one row per wavefront slot (4 per block)
         check(_lib.lib().morec_swin_attn_bwd_dbias(C.byref(desc), _p(qkv), _p(bias_t), _p(ctx), _p(dctx), _p(dqkv), _p(dbias_t),
                                                    _p(dbqkv), _p(ws), ws.numel() * 4, _stream()), "morec_swin_attn_bwd_dbias")
     return dqkv
