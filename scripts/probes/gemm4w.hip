@@ -1,31 +1,25 @@
-// gemm4w.hip -- EXPERIMENT, not part of the library build (it was compiled as idvs/morec_amd/csrc/gemm4w.hip behind gemm8p_try_launch;
-// gemm_args.hpp declared gemm4w_try_launch).  Correct on every shape of scripts/gemm8p_check.py and bit-identical to gemm8p, but
-// NOT faster: 1.69 us per K-tile on a main-loop-dominated launch (gemm8p 1.72, vendor library 1.40), slower on the step's shapes
-// (qkv 189 vs 170 us, fc2 248 vs 208) where gemm8p's tail split and store-overlap waits count.  Both main loops are POWER-limited at
-// ~1.27 PFLOP/s sustained; a third less LDS traffic and a quarter of the barriers did not move that, so LDS reads are not what the
-// socket power goes into.  (The vendor kernel is hand-written: Custom_Cijk_..._MT256x256x64_MI16x16x1, stream-K for the BERT shapes.)
+// gemm4w.hip -- EXPERIMENT, not part of the library build (it was compiled as idvs/morec_amd/csrc/gemm4w.hip behind gemm8p_try_launch for
+// the linear epilogue; gemm_args.hpp declared gemm4w_try_launch).  The architecture of the vendor library's hand-written kernel
+// (Custom_Cijk_..._MT256x256x64_MI16x16x1: 256 threads, 128 x 128 outputs per wave, LDS-DMA into two 64-KiB K-tile buffers, 32 ds_read_b128 +
+// 16 DMA per wave and K-tile): ONE wave per SIMD on v_mfma_f32_16x16x32_bf16, 8 x 8 accumulator blocks of 16 x 16 (256 AGPRs), two barriers
+// per K-tile, every LDS read / DMA issued in the shadow of the wave's own MFMAs (sched_group_barrier: two MFMA, one other).
+// Correct on every shape of scripts/gemm8p_check.py.  Measured (1 x MI355X, power-limited at 1.38 kW):
+//      main-loop-dominated 4096 x 4096 x 8192:  this kernel 1.31 PFLOP/s (1.27 with v_mfma_f32_32x32x16_bf16 and 4 x 4 blocks of 32 x 32),
+//                                               gemm8p 1.25-1.34, vendor library 1.45-1.57
+//      the step's shapes (M = 51200):           qkv 188 us (gemm8p 170), fc2 255 (214), d_qkv 194 (164): the eight-wave kernel hides
+//                                               prologue and epilogue far better (two wave rows, counted waits under the next tile).
+// So neither the wave tile (a third less LDS traffic), nor the barrier count (2 vs 8), nor the MFMA shape explains the vendor kernel's
+// 15 % -- what is left is its hand-scheduled instruction stream.  Kept as the starting point for that work.
 //
-// NT GEMM main loop with ONE wave per SIMD: 256 x 256 output tile, four waves as 2 (m) x 2 (n) of 128 x 128 outputs
-// each (256 accumulator registers of the wave's 512), K advanced 64 elements per K-tile through two 64-KiB LDS buffers filled
-// by LDS-DMA (the buffer layout and swizzle of gemm8p.hip), two s_barriers per K-tile.
-//
-// Why a second main loop beside gemm8p.hip: the encoder GEMMs run POWER-limited (1.38 kW socket power; scripts/clock_probe.py:
-// 1660 MHz under the eight-phase kernel, 1776 MHz under the vendor library, which is also 10 % better per cycle).  With 128 x 64
-// outputs per wave the eight-phase kernel reads 192 KiB of LDS fragments per K-tile and crosses eight barriers; with
-// 128 x 128 per wave the same K-tile needs 128 KiB and two barriers.  Same arithmetic, same operand order (the accumulator
-// layout of gemm8p.hip, so results are bit-identical to it): fewer LDS bytes, instructions and barrier crossings per MFMA.
-//
-// Pipeline (K-tile t lives in buffer t & 1; an iteration = half a K-tile = two MFMA k-steps of 16 = 32 MFMA per wave):
-//      even iteration 2t    : read the second half's fragments | 16 MFMA | lgkmcnt(0), s_barrier: buffer dead -> issue K-tile t + 2 | 16 MFMA
-//      odd  iteration 2t + 1: 16 MFMA | vmcnt(16): K-tile t + 1 landed, s_barrier | read its first half's fragments | 16 MFMA
-// A refill is issued three iterations (3 x 1024 MFMA cycles) before its first read; the DMA queue is never drained inside a tile.
-// Persistent workgroups; the next tile's first two K-tiles are requested before the finished tile's epilogue.
+// Pipeline (K-tile t lives in buffer t & 1; an iteration = one 32-deep MFMA k-step = 64 MFMA per wave):
+//      even iteration 2t    : read the second k-step's fragments | 32 MFMA | lgkmcnt(0), s_barrier: buffer dead -> issue K-tile t + 2 | 32 MFMA
+//      odd  iteration 2t + 1: 32 MFMA | vmcnt(16): K-tile t + 1 landed, s_barrier | read its first k-step's fragments | 32 MFMA
 #include <stdlib.h>
 #include "gemm_core.hpp"
 #include "gemm_args.hpp"
 
 namespace {
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr int TM = 256, TN = 256, KE = 64;       // tile; K elements per K-tile
@@ -55,7 +49,7 @@ struct Ctx4 {
     __amdgpu_buffer_rsrc_t ra, rb;   // descriptors of A / B, based at the tile's first row
     uint32_t va[8], vb[8];           // per-lane source byte offsets of the wave's eight 8-row pieces of A / of B
     int dpa, dpb;                    // wave-uniform LDS offsets (within a buffer) of the wave's first A / B piece
-    int la[4], lb[4];                // per-lane fragment offsets (within a buffer) of MFMA k-step ks: A rows of wave row wr, B rows of wave column wc
+    int la[2], lb[2];                // per-lane fragment offsets (within a buffer) of the 32-deep MFMA k-step 0 / 1: A rows of wave row wr, B rows of wave column wc
 };
 
 __device__ __forceinline__ void make_ctx4(Ctx4& c, int tid, const bf16* At, const bf16* Bt, int rows_a, int rows_b, int lda, int ldb) {
@@ -77,12 +71,12 @@ __device__ __forceinline__ void make_ctx4(Ctx4& c, int tid, const bf16* At, cons
     c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, 0, (int)min(bbytes, 0x7fffffffL), 0x00020000);
     c.dpa = wave * 64 * KB;
     c.dpb = OPB + wave * 64 * KB;
-    const int r5 = lane & 31, fr = (r5 >> 1) & 7;
+    const int c15 = lane & 15, g = lane >> 4, fr = (c15 >> 1) & 7;      // row blocks start at multiples of 16: (row >> 1) & 7 = (c15 >> 1) & 7
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int ps = (2 * ks + (lane >> 5)) ^ fr;
-        c.la[ks] = (wr * 128 + r5) * KB + (ps << 4);
-        c.lb[ks] = OPB + (wc * 128 + r5) * KB + (ps << 4);
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ps = (4 * ks + g) ^ fr;
+        c.la[ks] = (wr * 128 + c15) * KB + (ps << 4);
+        c.lb[ks] = OPB + (wc * 128 + c15) * KB + (ps << 4);
     }
 }
 
@@ -95,37 +89,28 @@ __device__ __forceinline__ void issue_ktile(const Ctx4& c, char* buf, int kbyte)
 }
 
 struct Frags {
-    uint4 a[2][4], b[2][4];     // two MFMA k-steps: A rows Mi * 32 + (lane & 31), B rows Ni * 32 + (lane & 31); 8 k per lane and step
+    uint4 a[8], b[8];     // one 32-deep k-step: A rows mi * 16 + (lane & 15), B rows ni * 16 + (lane & 15); lane group g holds k = 8 g .. 8 g + 7
 };
-// fragments of k-steps 2 half, 2 half + 1 of the K-tile in `buf`
-__device__ __forceinline__ void read_frags(Frags& f, const char* buf, const Ctx4& c, int half) {
+__device__ __forceinline__ void read_frags(Frags& f, const char* buf, const Ctx4& c, int ks) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int i = 0; i < 8; ++i) f.a[i] = lds16(buf + c.la[ks] + i * (16 * KB));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[s][i] = lds16(buf + c.la[2 * half + s] + i * (32 * KB));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f.b[s][i] = lds16(buf + c.lb[2 * half + s] + i * (32 * KB));
-    }
+    for (int i = 0; i < 8; ++i) f.b[i] = lds16(buf + c.lb[ks] + i * (16 * KB));
 }
-template <bool ZERO>
-__device__ __forceinline__ void mfma16(f32x16_t (&acc)[4][4], const Frags& f, int s) {
+// 32 MFMA: accumulator blocks mi = M0 .. M0 + 3 (all eight ni).  B fragment as the instruction's first operand: the lane ends up
+// owning ONE m (mi * 16 + (lane & 15)) and runs of 4 consecutive n (ni * 16 + 4 (lane >> 4) + r).
+template <bool ZERO, int M0>
+__device__ __forceinline__ void mfma32(f32x4_t (&acc)[8][8], const Frags& f) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = M0; mi < M0 + 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {   // operand-swapped (as gemm8p): the lane ends up owning ONE m and runs of 4 consecutive n
-            f32x16_t cin = acc[mi][ni];
-            if constexpr (ZERO) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) cin[v] = 0.f;
-            }
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f.b[s][ni]), __builtin_bit_cast(bf16x8_t, f.a[s][mi]),
-                                                                   cin, 0, 0, 0);
+        for (int ni = 0; ni < 8; ++ni) {
+            f32x4_t cin = acc[mi][ni];
+            if constexpr (ZERO) cin = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, f.b[ni]), __builtin_bit_cast(bf16x8_t, f.a[mi]), cin, 0, 0, 0);
         }
 }
 
-// Even iteration: first half (k-steps 0, 1) of the K-tile in buffer `cur`; fc = its fragments.  The second half's fragments are
-// read up front (same buffer: nothing to wait for); after the barrier the buffer is dead and, with ISSUE, refilled with the
-// K-tile two ahead (kb_issue = its K byte offset).
 // One wave per SIMD has no partner whose MFMAs cover its LDS / DMA issue: every other instruction has to be issued in the shadow
 // of an MFMA of the SAME wave (32 cycles each).  sched_group_barrier pins the interleave: one MFMA, one LDS read (or one
 // LDS-DMA), sixteen times.
@@ -133,42 +118,42 @@ template <int OTHER>     // 0x100: DS read, 0x020: VMEM read
 __device__ __forceinline__ void interleave16() {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(OTHER, 1, 0);
     }
 }
 
 template <bool ZERO, bool ISSUE>
-__device__ __forceinline__ void iter_even(char* cur, const Ctx4& c, int kb_issue, f32x16_t (&acc)[4][4], const Frags& fc, Frags& fn) {
+__device__ __forceinline__ void iter_even(char* cur, const Ctx4& c, int kb_issue, f32x4_t (&acc)[8][8], const Frags& fc, Frags& fn) {
     read_frags(fn, cur, c, 1);
-    mfma16<ZERO>(acc, fc, 0);
+    mfma32<ZERO, 0>(acc, fc);
     interleave16<0x100>();
     pin();
     lgkm_wait0();            // this wave's reads of the buffer are done
     bar();                   // ... everybody's
     if constexpr (ISSUE) issue_ktile(c, cur, kb_issue);
-    mfma16<false>(acc, fc, 1);
+    mfma32<ZERO, 4>(acc, fc);
     if constexpr (ISSUE) interleave16<0x020>();
     pin();
 }
-// Odd iteration: second half of the K-tile (fc = its fragments, read during the even iteration).  WAIT: the vmcnt that retires the
-// NEXT K-tile (in buffer `oth`), whose first-half fragments are read behind the barrier.
+// Odd iteration: second k-step of the K-tile (fc = its fragments, read during the even iteration).  WAIT: the vmcnt that retires the
+// NEXT K-tile (in buffer `oth`), whose first k-step's fragments are read behind the barrier.
 template <int WAIT, bool NEXT>
-__device__ __forceinline__ void iter_odd(char* oth, const Ctx4& c, f32x16_t (&acc)[4][4], const Frags& fc, Frags& fn) {
-    mfma16<false>(acc, fc, 0);
+__device__ __forceinline__ void iter_odd(char* oth, const Ctx4& c, f32x4_t (&acc)[8][8], const Frags& fc, Frags& fn) {
+    mfma32<false, 0>(acc, fc);
     if constexpr (NEXT) {
         pin();
         vm_wait<WAIT>();
         bar();
         read_frags(fn, oth, c, 0);
     }
-    mfma16<false>(acc, fc, 1);
+    mfma32<false, 4>(acc, fc);
     if constexpr (NEXT) interleave16<0x100>();
     pin();
 }
 
 // acc = A-panel . B-panel^T over nk K-tiles (nk >= 3), K-tiles 0 and 1 already requested.
-__device__ __forceinline__ void mainloop4w(const Ctx4& c, int nk, char* smem, f32x16_t (&acc)[4][4]) {
+__device__ __forceinline__ void mainloop4w(const Ctx4& c, int nk, char* smem, f32x4_t (&acc)[8][8]) {
     Frags f0, f1;
     vm_wait<GROUP>();          // K-tile 0 (younger stores of the previous epilogue only make this stricter)
     bar();
@@ -206,7 +191,7 @@ __device__ __forceinline__ void tile_body4(const GemmArgs& p, char* smem, int nk
                                            const bool first) {
     static_assert(sizeof(TO) == 2, "bf16 outputs");
     const int m0 = cur.m0, n0 = cur.n0;
-    f32x16_t acc[4][4];
+    f32x4_t acc[8][8];
     float bias_l[2];
     {
         int tid_m = threadIdx.x;
@@ -225,10 +210,11 @@ __device__ __forceinline__ void tile_body4(const GemmArgs& p, char* smem, int nk
         }
         mainloop4w(c, nk, smem, acc);
     }
-    // ---- epilogue (wave-private; see gemm8p.hip): acc[Mi][Ni][4 g + r] = C[m0 + wr*128 + Mi*32 + (lane & 31)][n0 + wc*128 + Ni*32 + 8 g + 4 (lane >> 5) + r]
+    // ---- epilogue (wave-private; see gemm8p.hip): acc[mi][ni][r] = C[m0 + wr*128 + mi*16 + (lane & 15)][n0 + wc*128 + ni*16 + 4 (lane >> 4) + r].
+    // A pass moves 32 rows (two mi) x 64 columns (four ni) through the wave's [32 rows][128 B] slice.
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
-    const int lane = tid_e & 63, r5 = lane & 31, h = lane >> 5;
+    const int lane = tid_e & 63, c15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid_e >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     char* ws = smem + LDS_RING + wave * SLICE;
@@ -240,7 +226,8 @@ __device__ __forceinline__ void tile_body4(const GemmArgs& p, char* smem, int nk
     };
     const int rs_row = lane >> 3, rs_slot = lane & 7;
     const int rs_off = rs_row * 128 + ((rs_slot ^ (rs_row & 7)) << 4);
-    auto cell = [&](int q) { return reinterpret_cast<TO*>(ws + r5 * 128 + ((q ^ (r5 & 7)) << 4) + 8 * h); };
+    // row `row` of the slice, columns 16 nq + 4 g .. + 3 of the pass: 16-byte slot 2 nq + (g >> 1), second half of the slot for odd g
+    auto cell = [&](int row, int nq) { return reinterpret_cast<TO*>(ws + row * 128 + (((2 * nq + (g >> 1)) ^ (row & 7)) << 4) + 8 * (g & 1)); };
     const int nw = n0 + wc * 128;
     const long tile_bytes = (long)min(256, p.M - m0) * p.ldc * 2;
     const int ext = (int)min(tile_bytes, 0x7fffffffL);
@@ -251,16 +238,14 @@ __device__ __forceinline__ void tile_body4(const GemmArgs& p, char* smem, int nk
         const int n = nw + hf * 64 + rs_slot * 8;
         lo[hf] = n < p.N ? (uint32_t)((rs_row * p.ldc + n) * 2) : 0x80000000u;
     }
-    // bias of the lane's 16 column groups through the slice (fetched ahead of the main loop)
-    float4 bv[4][4];
+    // bias of the lane's 8 column groups through the slice (fetched ahead of the main loop)
+    float4 bv[8];
     {
         reinterpret_cast<float*>(ws)[lane] = p.bias ? bias_l[0] : 0.f;
         reinterpret_cast<float*>(ws)[64 + lane] = p.bias ? bias_l[1] : 0.f;
         wfence();
 #pragma unroll
-        for (int Ni = 0; Ni < 4; ++Ni)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(ws + (Ni * 32 + g * 8 + 4 * h) * 4);
+        for (int ni = 0; ni < 8; ++ni) bv[ni] = *reinterpret_cast<const float4*>(ws + (ni * 16 + 4 * g) * 4);
         wfence();
     }
     pin();
@@ -273,28 +258,30 @@ __device__ __forceinline__ void tile_body4(const GemmArgs& p, char* smem, int nk
         issue_ktile(cn, smem + BUFB, KB);
     }
 #pragma unroll
-    for (int Mi = 0; Mi < 4; ++Mi)
+    for (int mp = 0; mp < 4; ++mp)          // pairs of 16-row blocks
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             pin();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int Ni = 2 * hf + q / 4, g = q % 4;
-                const float4 b = bv[Ni][g];
-                float v[4];
-                v[0] = fmaf(acc[Mi][Ni][4 * g + 0], p.alpha, b.x);
-                v[1] = fmaf(acc[Mi][Ni][4 * g + 1], p.alpha, b.y);
-                v[2] = fmaf(acc[Mi][Ni][4 * g + 2], p.alpha, b.z);
-                v[3] = fmaf(acc[Mi][Ni][4 * g + 3], p.alpha, b.w);
-                io<TO>::store4(cell(q), v);
-            }
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int nq = 0; nq < 4; ++nq) {
+                    const int mi = 2 * mp + mh, ni = 4 * hf + nq;
+                    const float4 b = bv[ni];
+                    float v[4];
+                    v[0] = fmaf(acc[mi][ni][0], p.alpha, b.x);
+                    v[1] = fmaf(acc[mi][ni][1], p.alpha, b.y);
+                    v[2] = fmaf(acc[mi][ni][2], p.alpha, b.z);
+                    v[3] = fmaf(acc[mi][ni][3], p.alpha, b.w);
+                    io<TO>::store4(cell(mh * 16 + c15, nq), v);
+                }
             wfence();
             u32x4_t qv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const u32x4_t*>(ws + rs_off + i * 1024);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(qv[i], rC, lo[hf] + (uint32_t)((wr * 128 + Mi * 32 + 8 * i) * p.ldc * 2), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(qv[i], rC, lo[hf] + (uint32_t)((wr * 128 + mp * 32 + 8 * i) * p.ldc * 2), 0, 0);
             wfence();
         }
 }
