@@ -263,8 +263,8 @@ __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     // Work items in (token chunk, n-tile, k-tile) order, k fastest, dealt to the XCDs in CONTIGUOUS runs (xcd_remap over the whole
     // launch): the tiles of one chunk -- which share its DY panel (across k-tiles) and its X panel (across n-tiles) and walk the
     // tokens in lockstep -- then sit behind ONE L2.  With the chunk on the grid's z axis they were spread over all eight XCDs and
-    // every L2 fetched its own copy of the panels (2.5x the algorithmic bytes in FETCH_SIZE, profiles/r02d-era PMC).  The launch
-    // time did not change with the mapping (the re-fetches were being served by the memory-side cache); kept for the traffic.
+    // every L2 fetched its own copy of the panels: FETCH_SIZE 778 MB per launch against 364 MB now (= the operands;
+    // profiles/r02e_gemm_pmc.json).  The launch time did not change (the re-fetches were served by the memory-side cache).
     const int tiles = p.tiles_n * p.tiles_k;
     const int item = xcd_remap(blockIdx.x, tiles * p.zs);
     const int z = item / tiles, wg = item - z * tiles;
