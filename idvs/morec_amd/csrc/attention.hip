@@ -355,7 +355,8 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     return MOREC_OK;
 }
 
-// morec_attn_bwd + the bias gradient of the fused q|k|v projection: dbias[3 H] += column sums of the dqkv rows as stored.
+// morec_attn_bwd + the bias gradient of the fused q|k|v projection: dbias[3 H] += column sums of the dqkv rows (MFMA path: fp32
+// sums of the rows before their bf16 rounding; the fallback sums the stored rows).
 // On the MFMA path every (sequence, head) wavefront leaves its own column sums in ws ([n_seq][3 H] fp32) and one small kernel
 // folds them -- instead of a second pass over the [rows x 3 H] tensor (54 us of a 115 us attention backward at 51200 rows,
 // profiles/r02b_bench_kernel_stats.csv).  Other shapes / dtypes: the plain backward followed by morec_colsum.

@@ -28,7 +28,7 @@ struct AttnMArgs {
     const float* key_keep;
     bf16* ctx;          // fwd: output; bwd: dctx input
     bf16* dqkv;
-    float* csum;        // bwd, optional: [n_seq][3 H] fp32 column sums of this sequence's dqkv rows (as stored), folded by the caller
+    float* csum;        // bwd, optional: [n_seq][3 H] fp32 column sums of this sequence's dqkv rows (before their bf16 rounding), folded by the caller
     int n_seq, T, n_heads, dh, causal;
     float scale, mask_value;
     DropRng drop;
@@ -270,10 +270,10 @@ __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ,
 #pragma unroll
                 for (int db = 0; db < NB; ++db)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        cq[db][e] += bf2f(f2bf(dq[db][e]));
-                        ck[db][e] += bf2f(f2bf(dk[db][e]));
-                        cv[db][e] += bf2f(f2bf(dv[db][e]));
+                    for (int e = 0; e < 4; ++e) {      // fp32 sums of the rows BEFORE their bf16 rounding (three VALU ops per value cheaper)
+                        cq[db][e] += dq[db][e];
+                        ck[db][e] += dk[db][e];
+                        cv[db][e] += dv[db][e];
                     }
             }
         }

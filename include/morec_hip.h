@@ -168,7 +168,8 @@ int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_k
 int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx, void* dqkv,
                    void* stream);
 /* The same backward plus the bias gradient of the fused q|k|v projection (HF BertSelfAttention query/key/value biases;
- * T/model/modules.py:30-32 has none): dbias[3 H] (fp32) += column sums of the `rows` dqkv rows as stored.  ws: optional
+ * T/model/modules.py:30-32 has none): dbias[3 H] (fp32) += column sums of the `rows` dqkv rows (the bf16 MFMA path sums them in fp32
+ * before the rows are rounded to bf16; otherwise the stored rows are summed).  ws: optional
  * scratch of n_seq * 3 H floats -- with it the bf16 path sums inside the attention kernel instead of re-reading dqkv. */
 int morec_attn_bwd_dbias(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx, void* dqkv,
                          int rows, float* dbias, float* ws, size_t ws_bytes, void* stream);

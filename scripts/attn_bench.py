@@ -37,8 +37,11 @@ def main():
         d = ops.attn_desc(n_seq, 30, heads, dh, False, dh ** -0.5, -10000.0, torch.bfloat16, 0.1, 77, cu_seqlens=cu)
         tf = timeit(lambda: ops.attn_fwd(d, qkv, keep))
         tb = timeit(lambda: ops.attn_bwd(d, qkv, keep, dctx))
+        dbias = torch.zeros(3 * H, device="cuda")
+        tbb = timeit(lambda: ops.attn_bwd(d, qkv, keep, dctx, dbias=dbias))
         bf, bb = M * H * 2 * 4, M * H * 2 * 7
-        print(f"{label}: M={M}  fwd {tf:.1f} us ({bf / tf / 1e3:.0f} GB/s)  bwd {tb:.1f} us ({bb / tb / 1e3:.0f} GB/s)")
+        print(f"{label}: M={M}  fwd {tf:.1f} us ({bf / tf / 1e3:.0f} GB/s)  bwd {tb:.1f} us ({bb / tb / 1e3:.0f} GB/s)  "
+              f"bwd + q|k|v bias gradient {tbb:.1f} us (incl. the fold of the per-sequence sums)")
 
 
 if __name__ == "__main__":

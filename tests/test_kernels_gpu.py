@@ -281,7 +281,9 @@ def test_attention(dt, cfg):
     dqkv2 = ops.attn_bwd(desc, qkv, keep, dctx, dbias=dbias)
     assert torch.equal(dqkv2, dqkv)
     want = 0.25 + dqkv.double().sum(0)
-    assert (dbias.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    # fp32: sums of the stored rows; bf16 MFMA path: fp32 sums of the rows before their bf16 rounding (rounding noise apart)
+    assert (dbias.double() - want).abs().max().item() <= (1e-5 if dt == torch.float32 else 3e-3) * max(1.0, want.abs().max().item())
+    assert rel(dbias - 0.25, qd.grad.sum(0)) < (1e-4 if dt == torch.float32 else 3e-2)
 
 
 @pytest.mark.parametrize("dt", DT)
