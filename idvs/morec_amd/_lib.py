@@ -107,6 +107,14 @@ _SIGS = {
     "morec_bias_residual": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_droppath_scale": (C.c_int, [_P, C.c_int, C.c_float, C.c_uint64, _P]),
     "morec_image_resize_u8": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "morec_comm_available": (C.c_int, []),
+    "morec_comm_unique_id": (C.c_int, [_P]),
+    "morec_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
+    "morec_comm_destroy": (C.c_int, [_P]),
+    "morec_comm_last_error": (C.c_char_p, [_P]),
+    "morec_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "morec_comm_reduce_scatter_f32": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "morec_comm_all_reduce_f32": (C.c_int, [_P, _P, C.c_size_t, _P]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -8,6 +8,7 @@ extern "C" const char* morec_strerror(int code) {
         case MOREC_E_ALIGN: return "MOREC_E_ALIGN: pointer/pitch not 16-byte aligned or size not a vector multiple";
         case MOREC_E_UNSUPPORTED: return "MOREC_E_UNSUPPORTED: shape outside kernel limits";
         case MOREC_E_DTYPE: return "MOREC_E_DTYPE: unsupported dtype combination";
+        case MOREC_E_COMM: return "MOREC_E_COMM: an RCCL call failed (morec_comm_last_error)";
         default: break;
     }
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));

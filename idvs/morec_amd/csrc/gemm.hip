@@ -281,12 +281,10 @@ static int launch_gemm_act(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
     const int zs = (d->K + kchunk - 1) / kchunk;
     a.tiles_m = (d->M + G::TM - 1) / G::TM;
     a.tiles_n = (d->N + G::TN - 1) / G::TN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO, ACT, CS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        attr_set = true;
-    }
+    // one-time attribute set-up behind a function-local static: thread-safe first call (C++11), re-entrant afterwards
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<G, TI, TO, ACT, CS>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)attr_rc;
     dim3 grid(a.tiles_m * a.tiles_n, 1, zs);
     hipLaunchKernelGGL((gemm_nt_kernel<G, TI, TO, ACT, CS>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     MOREC_CHECK_LAUNCH();

@@ -25,6 +25,7 @@
 // retires it (its own pieces) + the barrier behind that wait (everybody else's).
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "gemm_core.hpp"
 #include "gemm_args.hpp"
 
@@ -667,9 +668,26 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
             t.nkt = t.chunk ? nk - nk0 : nk0;
             t.krem = t.chunk ? krem_all : KE;
         }
+        // Tile order: XCD x walks a CONTIGUOUS run of order indices (xcd_remap).  Plain order = row-major over (m, n): the
+        // 32 tiles an XCD works on at a time are 32 / tiles_n M-panels x ALL N-panels, i.e. the whole of B streams through its
+        // 4-MiB L2 once per round (N = 3072, K = 768: 4.7 MB -- nothing survives to the next round: profiles/r02e_gemm_pmc.json,
+        // 573 MB fetched for 89 MB of operands).  With column groups of p.ngroup N-tiles (order: group, m, n within the group) the
+        // XCD's block is (32 / ngroup) x ngroup panels -- fewest distinct panels per round when it is about square -- and an XCD
+        // only ever touches the B panels of one or two groups.
         t.wg = xcd_remap(vb, nwg);
-        t.m0 = (t.wg / p.tiles_n) * TM;
-        t.n0 = (t.wg % p.tiles_n) * TN;
+        int tm, tn;
+        if (p.ngroup <= 0 || p.ngroup >= p.tiles_n) {
+            tm = t.wg / p.tiles_n;
+            tn = t.wg % p.tiles_n;
+        } else {
+            const int per = p.ngroup * p.tiles_m, ng = (p.tiles_n + p.ngroup - 1) / p.ngroup;
+            const int g = min(t.wg / per, ng - 1), r = t.wg - g * per;
+            const int w = g == ng - 1 ? p.tiles_n - g * p.ngroup : p.ngroup;
+            tm = r / w;
+            tn = g * p.ngroup + r % w;
+        }
+        t.m0 = tm * TM;
+        t.n0 = tn * TN;
         return t;
     };
     TileXY cur = unit_at(0);
@@ -696,6 +714,8 @@ static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
     struct Slot { hipStream_t s; float* ws; int* cnt; int dev; };
     static Slot slots[8];
     static int n_slots = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
     for (int i = 0; i < n_slots; ++i)
@@ -711,23 +731,32 @@ static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
     ++n_slots;
 }
 
+int g_reserve_cus = 0;      // tuning key "gemm8p_reserve_cus"
+int g_ngroup = 0;           // tuning key "gemm8p_ngroup": 0 = row-major tile order, -1 = automatic column groups, n = groups of n N-tiles
+
 template <typename TO, int ACT, bool CS>
 int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     a.tiles_m = (d->M + TM - 1) / TM;
     a.tiles_n = (d->N + TN - 1) / TN;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
+    static const int n_cu_dev = [] {      // thread-safe one-time set-up (function-local static)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TO, ACT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_TOTAL);
-        int dev = 0;
+        int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        n_cu &= ~7;      // a multiple of the 8 XCDs: workgroup b and its later tiles b + k * grid stay on XCD b % 8
-        if (n_cu < 8) n_cu = 8;
-        attr_set = true;
-    }
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n &= ~7;      // a multiple of the 8 XCDs: workgroup b and its later tiles b + k * grid stay on XCD b % 8
+        return n < 8 ? 8 : n;
+    }();
+    // morec_tuning_set("gemm8p_reserve_cus", r): leave r CUs (rounded to a multiple of 8) out of the persistent grid -- room for the
+    // workgroups of a concurrent RCCL ring kernel when the step runs data-parallel (a persistent 160-KiB-LDS workgroup per CU
+    // otherwise owns the whole chip until its launch ends)
+    int n_cu = n_cu_dev - (g_reserve_cus & ~7);
+    if (n_cu < 8) n_cu = 8;
     const int nwg = a.tiles_m * a.tiles_n;
+    {   // column groups of the tile order: automatic = groups of about 6 N-tiles (a 32-CU XCD then works on a ~5 x 6 block)
+        const int ng = (a.tiles_n + 5) / 6;
+        a.ngroup = g_ngroup < 0 ? (a.tiles_n + ng - 1) / ng : g_ngroup;
+    }
     a.tail_ws = nullptr;
     a.tail_cnt = nullptr;
     // Tail split: OPT-IN (tuning key "gemm8p_tail_split" / MOREC_GEMM8P_TAIL_SPLIT=1).  It is as accurate as the unsplit sum (same
@@ -750,6 +779,8 @@ extern "C" int morec_tuning_set(const char* key, int value) {
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_split")) { g_tail_split = value != 0; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_ngroup")) { g_ngroup = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_reserve_cus")) { g_reserve_cus = value < 0 ? 0 : value > 128 ? 128 : value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_bias")) { g_tail_bias = value < 0 ? 0 : value > 16 ? 16 : value; return MOREC_OK; }
     // device buffer (16 x 8 bytes per workgroup) that receives s_memtime stamps of wave 0: address in two halves
     if (!strcmp(key, "gemm8p_stamps_lo")) { g_stamps = (g_stamps & 0xffffffff00000000ull) | (unsigned)value; return MOREC_OK; }
@@ -763,6 +794,8 @@ int gemm8p_mode() {
         g_mode8p = e ? atoi(e) : 0;
         if (const char* d = getenv("MOREC_GEMM8P_DEBUG")) g_debug8p = atoi(d);     // ablation bits for whole-step A/B runs
         if (const char* t = getenv("MOREC_GEMM8P_TAIL_SPLIT")) g_tail_split = atoi(t) != 0;
+        if (const char* n = getenv("MOREC_GEMM8P_NGROUP")) g_ngroup = atoi(n);
+        if (const char* r = getenv("MOREC_GEMM8P_RESERVE_CUS")) { const int v = atoi(r); g_reserve_cus = v < 0 ? 0 : v > 128 ? 128 : v; }
     }
     return g_mode8p;
 }

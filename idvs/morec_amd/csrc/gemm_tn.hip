@@ -204,11 +204,8 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
         r8 = gemm_tn8p_try_launch(a.DY, a.X, C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, reinterpret_cast<hipStream_t>(stream));
     if (r8 != G8_NOT_TAKEN && r8 != MOREC_OK) return r8;
     if (r8 == G8_NOT_TAKEN) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);
-            attr_set = true;
-        }
+        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);   // thread-safe one-time set-up
+        (void)attr_rc;
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
                            reinterpret_cast<hipStream_t>(stream), a);
         MOREC_CHECK_LAUNCH();

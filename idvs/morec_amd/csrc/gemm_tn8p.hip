@@ -296,11 +296,8 @@ int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_
     TnArgs8 a;
     a.DY = DY; a.X = X; a.out = out; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.ldo = ldo; a.mchunk = mchunk;
     a.tiles_n = tiles_n; a.tiles_k = tiles_k; a.zs = zs; a.slab_stride = slab_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        attr_set = true;
-    }
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // thread-safe one-time set-up
+    (void)attr_rc;
     hipLaunchKernelGGL(gemm_tn8p_kernel, dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;

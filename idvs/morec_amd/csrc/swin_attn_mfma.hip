@@ -662,14 +662,13 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
         hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
     } else {
         const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static const bool attr_set = [&] {      // thread-safe one-time set-up (the LDS size is a compile-time function of the tile constants)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        static int wide = -1;
-        if (wide < 0) { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); wide = e ? atoi(e) : 1; }
+            return true;
+        }();
+        (void)attr_set;
+        static const int wide = [] { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); return e ? atoi(e) : 1; }();
         if (wide) hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, grid, block, lds, s, a);
         else hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<false>, grid, block, lds, s, a);
     }

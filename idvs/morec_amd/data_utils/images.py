@@ -171,6 +171,8 @@ class LmdbItemImages:
         """item ids (any shape, numpy) -> uint8 [*ids.shape, R, R, 3] on ``device``."""
         from .. import ops
         flat = np.asarray(ids).reshape(-1)
-        imgs = self.store.batch([self.keys.get(int(i)) if int(i) != 0 else None for i in flat])
+        # id 0 = the padding slot (no image; masked everywhere in the loss); any OTHER id without an LMDB key is a corrupt / mismatched
+        # item list and raises KeyError like the reference's ``self.item_id_to_keys[item_id]`` (V/data_utils/dataset.py:93,162)
+        imgs = self.store.batch([self.keys[int(i)] if int(i) != 0 else None for i in flat])
         out = ops.image_resize_u8(imgs, self.R, device)
         return out.view(*np.asarray(ids).shape, self.R, self.R, 3)

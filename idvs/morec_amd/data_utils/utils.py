@@ -13,10 +13,12 @@ def _unwrap(model):
     return model.module if hasattr(model, "module") else model
 
 
-def save_model(now_epoch, model, model_dir, optimizer, rng_state, cuda_rng_state, scaler=None, Log_file=None):
+def save_model(now_epoch, model, model_dir, optimizer, rng_state, cuda_rng_state, scaler=None, Log_file=None, extra=None):
+    """``extra``: additional top-level entries (ignored by the reference's loader, ``T/run.py:130-139``) -- e.g. the call counter of the
+    library's counter-based dropout streams, which torch's RNG state does not cover."""
     os.makedirs(model_dir, exist_ok=True)
     ckpt_path = os.path.join(model_dir, f"epoch-{now_epoch}.pt")
-    torch.save({"model_state_dict": _unwrap(model).state_dict(),
+    torch.save({**(extra or {}), "model_state_dict": _unwrap(model).state_dict(),
                 # torch.optim.AdamW or train_step.TrainStep (same state_dict form: TrainStep.optimizer_state_dict)
                 "optimizer": (optimizer.optimizer_state_dict() if hasattr(optimizer, "optimizer_state_dict") else optimizer.state_dict())
                 if optimizer is not None else None,

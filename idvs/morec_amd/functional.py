@@ -120,7 +120,9 @@ class IdEmbeddingFn(torch.autograd.Function):
         return None, dw, None
 
 
-def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
+def _all_gather_cat(t: torch.Tensor, world: int, comm=None) -> torch.Tensor:
+    if comm is not None:       # morec_comm_all_gather: RCCL on the compute stream (comm.MorecComm)
+        return comm.all_gather(t)
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
     if dist.get_backend() == "gloo" and t.is_cuda:   # gloo smoke tests on a GPU box: list form, staged through the host
         parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
@@ -130,7 +132,7 @@ def _all_gather_cat(t: torch.Tensor, world: int) -> torch.Tensor:
     return out
 
 
-def pool_exchange(E: torch.Tensor, ci, n_valid: torch.Tensor, world: int, rank: int):
+def pool_exchange(E: torch.Tensor, ci, n_valid: torch.Tensor, world: int, rank: int, comm=None):
     """The forward exchange of the pooled-negative step in TWO collectives instead of five: one all-gather of
     the encoded item vectors, one all-gather of a packed int32 record per rank -- slot ids | log-pop bits | validity | the
     rank's valid-row count -- whose last word also replaces the scalar all-reduce (every rank sums the same ``world`` counts in
@@ -138,8 +140,8 @@ def pool_exchange(E: torch.Tensor, ci, n_valid: torch.Tensor, world: int, rank: 
     Nc = ci.col_ids.shape[0]
     blob = torch.cat((ci.col_ids.to(torch.int32), ci.col_logpop.to(torch.float32).view(torch.int32), ci.col_valid.to(torch.int32),
                       n_valid.reshape(1).to(torch.float32).view(torch.int32))).view(1, -1)
-    g = _all_gather_cat(blob, world)                                   # [world, 3 Nc + 1]
-    Epool = _all_gather_cat(E, world)
+    g = _all_gather_cat(blob, world, comm)                             # [world, 3 Nc + 1]
+    Epool = _all_gather_cat(E, world, comm)
     pooled = engine.CeInputs(ci.row_ids, g[:, :Nc].reshape(-1).contiguous(),
                              g[:, Nc:2 * Nc].reshape(-1).contiguous().view(torch.float32).to(ci.col_logpop.dtype),
                              g[:, 2 * Nc:3 * Nc].reshape(-1).to(torch.uint8).contiguous(), ci.row_valid, ci.B, ci.S, rank * E.shape[0])
@@ -147,11 +149,11 @@ def pool_exchange(E: torch.Tensor, ci, n_valid: torch.Tensor, world: int, rank: 
     return Epool, pooled, n_glob
 
 
-def reduce_scatter_dE(dEpool: torch.Tensor, world: int, rank: int, out_dtype: torch.dtype) -> torch.Tensor:
+def reduce_scatter_dE(dEpool: torch.Tensor, world: int, rank: int, out_dtype: torch.dtype, comm=None) -> torch.Tensor:
     """The backward exchange: SUM of every rank's gradient w.r.t. the pooled item vectors, each rank keeping the rows it owns.
     Always reduced in fp32 (an 8-way sum in bf16 would round seven times), then returned in the compute dtype."""
     t = dEpool if dEpool.dtype == torch.float32 else (ops.cast(dEpool, torch.float32) if dEpool.is_cuda else dEpool.float())
-    d = _reduce_scatter_sum(t, world, rank)
+    d = comm.reduce_scatter_sum(t) if comm is not None else _reduce_scatter_sum(t, world, rank)
     if d.dtype == out_dtype:
         return d
     return ops.cast(d, out_dtype) if d.is_cuda else d.to(out_dtype)

@@ -77,12 +77,39 @@ def run_eval(model, item_content, user_history, users_eval, batch_size, item_num
     return hit10
 
 
-def model_dir_of(args):
-    """``T/run.py:326-331``: ./checkpoint/checkpoint_<item_tower>_<encoder>_freeze_<n>/cpt_<hyper-parameters>."""
-    enc = args.CV_model_load if getattr(args, "CV_model_load", "None") != "None" else args.bert_model_load
-    dir_label = f"{args.item_tower}_{enc}_freeze_{args.freeze_paras_before}"
-    label = f"bs_{args.batch_size}_ed_{args.embedding_dim}_lr_{args.lr}_Flr_{args.fine_tune_lr}_dp_{args.drop_rate}_L2_{args.l2_weight}"
+def model_dir_of(args, world: int = 1):
+    """The reference's checkpoint directory, label for label (``T/run.py:326-337``): ``<root>/checkpoint_<dir_label>/cpt_<model>_ed_<D>_bs_
+    <batch_size * gpus>_lr_<lr>_Flr_<fine_tune_lr>_L2_<l2>_FL2_<fine_tune_l2>`` with ``dir_label = <item_tower>_<model>_freeze_<n>``
+    for modal towers and ``<item_tower>`` / model ``id`` for the ID tower, so that ``--load_ckpt_name epoch-N.pt`` finds a checkpoint
+    the reference wrote in place (``--checkpoint_root .``).  ``world`` = number of ranks (the reference multiplies the per-GPU batch
+    size by ``torch.cuda.device_count()``)."""
+    if "modal" in args.item_tower:
+        enc = args.CV_model_load if getattr(args, "CV_model_load", "None") != "None" else args.bert_model_load
+        dir_label = f"{args.item_tower}_{enc}_freeze_{args.freeze_paras_before}"
+    else:
+        enc, dir_label = "id", str(args.item_tower)
+    label = (f"{enc}_ed_{args.embedding_dim}_bs_{args.batch_size * world}_lr_{args.lr}_Flr_{args.fine_tune_lr}"
+             f"_L2_{args.l2_weight}_FL2_{args.fine_tune_l2_weight}")
     return os.path.join(args.checkpoint_root, "checkpoint_" + dir_label, "cpt_" + label)
+
+
+def normalize_pretrained_bert_keys(sd: dict) -> dict:
+    """Key names of a stock ``bert-*`` checkpoint file -> ``BertModel.state_dict()`` names, as ``from_pretrained`` does at load time
+    (``T/run.py:51-53``): the ``bert.`` prefix of ``BertForPreTraining`` files is dropped, the TF-era LayerNorm names ``*.LayerNorm.gamma``
+    / ``*.LayerNorm.beta`` (what ``bert-base-uncased/pytorch_model.bin`` holds) become ``weight`` / ``bias``, and the pre-training
+    heads (``cls.*``) and the ``position_ids`` buffer are left out."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("bert."):
+            k = k[len("bert."):]
+        if k.startswith("cls.") or k.endswith("embeddings.position_ids"):
+            continue
+        if k.endswith("LayerNorm.gamma"):
+            k = k[: -len("gamma")] + "weight"
+        elif k.endswith("LayerNorm.beta"):
+            k = k[: -len("beta")] + "bias"
+        out[k] = v
+    return out
 
 
 def _load_pretrained_text_tower(bert, args):
@@ -98,9 +125,11 @@ def _load_pretrained_text_tower(bert, args):
             else:
                 from safetensors.torch import load_file
                 sd = load_file(path)
-            sd = {k[len("bert."):] if k.startswith("bert.") else k: v for k, v in sd.items()}
-            missing, unexpected = bert.load_state_dict(sd, strict=False)
-            Log.info("text tower: %s loaded (%d missing, %d unexpected keys)" % (path, len(missing), len(unexpected)))
+            missing, unexpected = bert.load_state_dict(normalize_pretrained_bert_keys(sd), strict=False)
+            missing = [k for k in missing if not k.startswith("pooler.")]      # the pooler is frozen and unused (T/run.py:67-69)
+            if missing:     # a tower that silently keeps part of its random initialisation is a different experiment: refuse
+                raise SystemExit(f"text tower: {path} does not provide {len(missing)} parameter(s) of the tower, e.g. {missing[:4]}")
+            Log.info("text tower: %s loaded (%d unexpected keys ignored)" % (path, len(unexpected)))
             return True
     Log.warning("text tower: no pretrained weights under %s -- RANDOM initialisation" % d)
     return False
@@ -169,7 +198,7 @@ def train(args, use_modal, local_rank):
     model = (BceModel(args, item_num, use_modal, bert) if bce else Model(args, item_num, use_modal, bert, pop)).to(local_rank)
     neg_rng = np.random.default_rng(777 + rank)
     users = list(users_train.keys())
-    model_dir = model_dir_of(args)
+    model_dir = model_dir_of(args, world)
     ckpt, start_epoch, is_early_stop = None, 0, True
     if "None" not in args.load_ckpt_name:                               # T/run.py:130-139: BEFORE the arenas / DDP are built
         ckpt_path = get_checkpoint(model_dir, args.load_ckpt_name)
@@ -181,6 +210,8 @@ def train(args, use_modal, local_rank):
             torch.set_rng_state(ckpt["rng_state"])
         if ckpt.get("cuda_rng_state") is not None and torch.cuda.is_available():
             torch.cuda.set_rng_state(ckpt["cuda_rng_state"])
+        if ckpt.get("morec_drop_calls") is not None:      # the library's counter-based dropout / DropPath streams continue where they stopped
+            model._drop_calls = int(ckpt["morec_drop_calls"])
         is_early_stop = False
         Log.info("model loaded from %s (epoch %d)" % (ckpt_path, start_epoch))
     if args.mode == "test":                                             # T/run_test.py:115-128
@@ -238,7 +269,7 @@ def train(args, use_modal, local_rank):
             else:
                 items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
             if args.fused_step:
-                loss = stepper.step(ids.view(-1), items, log_mask)
+                loss = stepper.global_loss(stepper.step(ids.view(-1), items, log_mask))    # pooled negatives: a rank's step returns its SHARE
             else:
                 optimizer.zero_grad()
                 loss = wrapped(ids.view(-1), items, log_mask, local_rank)
@@ -262,7 +293,8 @@ def train(args, use_modal, local_rank):
             best, max_epoch, early_stop_count = hit10, now_epoch, 0
             if use_modal and rank == 0:                                 # T/run.py:265-267: modal runs only, rank 0 only
                 save_model(now_epoch, model, model_dir, stepper if stepper is not None else optimizer, torch.get_rng_state(),
-                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None, None, Log)
+                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None, None, Log,
+                           extra={"morec_drop_calls": int(getattr(model, "_drop_calls", 0))})
         else:
             early_stop_count += 1
             if early_stop_count > early_stop_gap:

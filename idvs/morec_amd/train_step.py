@@ -128,7 +128,8 @@ def _order_swin(names):
 
 class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
-                 betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False):
+                 betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False,
+                 force_collectives: bool = False, comm: str | None = None):
         self.model = model
         # encode every DISTINCT item of the batch once (the reference re-encodes duplicates: Zipf-popular
         # items fill many of the B (S + 1) slots) and gather the vectors back to the slots; the slot gradients are
@@ -175,6 +176,22 @@ class TrainStep:
         self._build_transposed_shadows()
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # ``force_collectives``: issue every collective of the data-parallel step (pooled exchange, dE reduce-scatter, bucketed
+        # async gradient all-reduce, closing sweep) even on a ONE-rank group, where each of them is the identity -- so that the
+        # RCCL code paths can be executed and checked on a single GPU (tests/test_train_step_rccl_gpu.py)
+        if force_collectives and not (dist.is_available() and dist.is_initialized()):
+            raise ValueError("force_collectives needs an initialised process group")
+        self.collectives = self.world > 1 or bool(force_collectives)
+        # comm = "rccl" (or MOREC_COMM=rccl): the exchange of the pooled step (two all-gathers, the dE reduce-scatter) runs through
+        # the C-ABI's own RCCL communicator ON THE COMPUTE STREAM (morec_comm_*: no cross-stream events around three small
+        # collectives whose results the next kernel needs at once), and the gradient buckets through a second communicator on a
+        # side stream (they overlap the rest of the backward pass).  Default: torch.distributed's collectives.
+        comm = comm if comm is not None else os.environ.get("MOREC_COMM", "")
+        self.comm = self.comm_grad = self._grad_stream = None
+        if comm == "rccl" and self.collectives and self.device.type == "cuda":
+            from .comm import MorecComm
+            self.comm, self.comm_grad = MorecComm(), MorecComm()
+            self._grad_stream = torch.cuda.Stream(device=self.device)
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
         self.overlap_reduce = os.environ.get("MOREC_OVERLAP_REDUCE", "1") != "0"
         self.buckets = self._bucket_plan()
@@ -354,12 +371,12 @@ class TrainStep:
         ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
         n_valid = ci.row_valid.sum(dtype=torch.float32)
         Epool = E
-        if self.world > 1 and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
-            Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank)
-        loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.world > 1 and self.pool))
+        if self.collectives and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
+            Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank, self.comm)
+        loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.collectives and self.pool))
         gscale = (1.0 / n_valid).reshape(1)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
-        dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype) if (self.world > 1 and self.pool) else dEpool
+        dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype, self.comm) if (self.collectives and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
         dE.view(B, S + 1, D)[:, :-1, :].add_(dx.view(B, S, D))      # the two sources of dE (T/model/model.py:39-41,49)
         if dedup:   # slot gradients -> distinct-item gradients (fp32 accumulation), back to the compute dtype for the encoder
@@ -385,7 +402,12 @@ class TrainStep:
 
     def _reduce_slice(self, gi, lo, hi):
         t = self.groups[gi]["arena"].grad[lo:hi]
-        if dist.get_backend() == "gloo":
+        if self.comm_grad is not None:     # own RCCL communicator on a side stream, behind the kernels already queued on this one
+            self._grad_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._grad_stream):
+                self.comm_grad.all_reduce_sum_(t)
+            self._pending.append(None)
+        elif dist.get_backend() == "gloo":
             self._all_reduce(t)
         else:   # RCCL: enqueued behind the kernels already on this stream, runs on the communicator's own stream
             self._pending.append(dist.all_reduce(t, async_op=True))
@@ -393,7 +415,7 @@ class TrainStep:
 
     def _on_ready(self, key):
         """Backward-pass callback of the engines: start reducing the gradients that have just become final."""
-        if self.world == 1 or not self.overlap_reduce:
+        if not self.collectives or not self.overlap_reduce:
             return
         if key == "head":      # the recommender group (SASRec, fc, id table) is complete once the tower's backward is under way
             gi = len(self.groups) - 1
@@ -404,7 +426,7 @@ class TrainStep:
     def reduce_gradients(self):
         """SUM over ranks (the 1/n_valid_global factor is already inside the loss gradient): closes the bucketed
         reduction started during the backward pass -- reduces every slice not yet issued, then joins the async work."""
-        if self.world > 1:
+        if self.collectives:
             for gi, grp in enumerate(self.groups):
                 done = sorted((lo, hi) for g_, lo, hi in self._reduced if g_ == gi)
                 pos = 0
@@ -414,7 +436,10 @@ class TrainStep:
                         self._reduce_slice(gi, pos, lo)
                     pos = hi
             for w in self._pending:
-                w.wait()
+                if w is not None:
+                    w.wait()
+            if self._grad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._grad_stream)
             self._pending = []
             if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
                 for grp in self.groups:
@@ -495,9 +520,12 @@ class TrainStep:
     def global_loss(self, loss):
         """With pooled negatives ``step`` returns THIS rank's share ``loss_sum_local / n_valid_global`` (the shares add up to
         the loss of the single-process step at batch N*B); this is the SUM over ranks, for logging."""
-        if self.world > 1 and self.pool:
-            t = loss.detach().clone().reshape(1)
-            self._all_reduce(t)
+        if self.collectives and self.pool:
+            t = loss.detach().float().clone().reshape(1)
+            if self.comm is not None:
+                self.comm.all_reduce_sum_(t)
+            else:
+                self._all_reduce(t)
             return t[0]
         return loss
 

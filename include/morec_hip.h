@@ -9,14 +9,27 @@
  *
  * Conventions
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named h_*;
- *   - the caller owns every buffer (PyTorch caching allocator); the library allocates nothing and
- *     keeps no global state; every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *   - the caller owns every buffer (PyTorch caching allocator); every call is asynchronous on `stream` (a hipStream_t passed as
+ *     void*) and does no host synchronisation;
  *   - return 0 on success, a negative MOREC_E_* for bad arguments, a positive value = hipError_t;
- *   - dtype codes: MOREC_F32 = 0 (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32), MOREC_BF16 = 1
- *     (bf16 operands, fp32 accumulate, v_mfma_f32_16x16x32_bf16);
+ *   - dtype codes: MOREC_F32 = 0 (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32), MOREC_BF16 = 1 (bf16 operands, fp32 accumulate:
+ *     v_mfma_f32_32x32x16_bf16 in the 256 x 256 eight-phase GEMMs, v_mfma_f32_16x16x32_bf16 in attention, scoring and the
+ *     small-problem GEMMs);
  *   - row-major matrices with explicit leading dimensions in ELEMENTS; every base pointer and
  *     every row pitch must be 16-byte aligned (MOREC_E_ALIGN otherwise);
  *   - item ids are int32 on the device (the host narrows the int64 ids PyTorch provides).
+ *
+ * State the library keeps (everything else is stateless and re-entrant; first-call set-up of a kernel's launch attributes is
+ * behind thread-safe function-local statics).  One process drives one GPU (the reference's process model, T/run.py:305-321):
+ *   1. process-wide kernel-SELECTION knobs, morec_tuning_set() and the environment variables read once at the first GEMM
+ *      launch: MOREC_GEMM8P (0 automatic | 1 never | 2 always the eight-phase kernel), MOREC_GEMM8P_TAIL_SPLIT (0 | 1),
+ *      MOREC_GEMM8P_NGROUP (tile order), MOREC_GEMM8P_RESERVE_CUS, MOREC_GEMM8P_DEBUG (ablation bits), MOREC_GEMM_TILE /
+ *      MOREC_GEMM_EPI (two-buffer kernel variants), MOREC_SWIN_BWD_WIDE.  Every selectable kernel computes the same function
+ *      to the same accuracy; "gemm8p_tail_split" = 1 is the only knob that changes the fp32 SUMMATION ORDER (and with it the
+ *      last-bit rounding pattern of bf16 outputs), which is why it is off unless asked for.  Set knobs before the first
+ *      launch or between steps, not concurrently with launches;
+ *   2. with "gemm8p_tail_split" = 1 only: one device scratch allocation per stream (the only memory the library ever allocates);
+ *   3. morec_comm handles (below): created and destroyed by the caller.
  */
 #ifndef MOREC_HIP_H
 #define MOREC_HIP_H
@@ -36,6 +49,7 @@ extern "C" {
 #define MOREC_E_ALIGN (-2)       /* pointer or pitch not 16-byte aligned / size not a multiple of the vector width */
 #define MOREC_E_UNSUPPORTED (-3) /* shape outside what the kernel was written for */
 #define MOREC_E_DTYPE (-4)
+#define MOREC_E_COMM (-5)        /* an RCCL call failed: morec_comm_last_error() */
 
 #define MOREC_ACT_NONE 0
 #define MOREC_ACT_GELU 1 /* exact erf GELU (HF BertIntermediate; T/model/encoders.py:59 nn.GELU) */
@@ -44,8 +58,13 @@ extern "C" {
 
 const char* morec_strerror(int code);
 int morec_version(void);
-/* Process-wide kernel-selection knobs (measurement / A-B aid, no arithmetic meaning: every selectable kernel computes the same
- * function).  key "gemm8p": 0 = automatic, 1 = never use the 256 x 256 eight-phase GEMM, 2 = use it wherever it is eligible.
+/* Process-wide kernel-selection knobs (measurement / A-B aid; see "State the library keeps" above).  Keys:
+ *   "gemm8p"             0 = automatic, 1 = never use the 256 x 256 eight-phase GEMM, 2 = use it wherever it is eligible;
+ *   "gemm8p_tail_split"  1 = split the last, partly filled round of tiles along K between two workgroups (K >= 1536);
+ *   "gemm8p_tail_bias"   share of K the first part takes in that split;
+ *   "gemm8p_ngroup"      tile order: 0 = row-major, -1 = automatic column groups, n = column groups of n N-tiles;
+ *   "gemm8p_reserve_cus" CUs (multiple of 8) left out of the persistent grid for a concurrent RCCL kernel;
+ *   "gemm8p_debug", "gemm8p_stamps_lo/hi"  ablation bits / device address of a cycle-stamp buffer (diagnostics).
  * Returns MOREC_E_UNSUPPORTED for an unknown key.  No reference counterpart (the reference has no kernels). */
 int morec_tuning_set(const char* key, int value);
 
@@ -328,6 +347,30 @@ int morec_probe(int32_t* out, void* stream);
  * ToTensor + Normalize(0.5, 0.5) are fused into morec_swin_patchify_u8.
  * ------------------------------------------------------------------------------------------ */
 int morec_image_resize_u8(const uint8_t* src, const int64_t* meta, const int32_t* tables, uint8_t* out, int n, int R, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step on the CALLER's stream (RCCL over xGMI, resolved with dlopen from the
+ * librccl.so.1 already mapped in the process -- PyTorch's -- and never linked).  They replace, stream-ordered with the kernels
+ * around them, what the reference gets from DistributedDataParallel's NCCL hooks (T/run.py:148,321) plus the exchange the
+ * pooled-negative step adds:  all-gather of the encoded item vectors E [Nc, D] and of the packed (ids | log-pop | validity |
+ * n_valid) record, reduce-scatter(SUM) of dE_pool [world Nc, D] in fp32, all-reduce(SUM) of a gradient bucket in fp32.
+ * h_id128: HOST buffer of 128 bytes (ncclUniqueId): rank 0 fills it with morec_comm_unique_id and hands it to the other ranks
+ * out of band (torch.distributed store / broadcast, MPI, a file); morec_comm_create is collective over the `world` ranks and
+ * needs this process's device to be current.  One handle per (process, device); calls on one handle must not overlap in time
+ * on different streams.  Errors: MOREC_E_UNSUPPORTED = no RCCL library found, MOREC_E_COMM = RCCL reported a failure.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct morec_comm morec_comm;
+int morec_comm_available(void);                       /* 1 when librccl.so.1 and every entry point needed were found */
+int morec_comm_unique_id(void* h_id128);
+int morec_comm_create(morec_comm** out, const void* h_id128, int rank, int world);
+int morec_comm_destroy(morec_comm* comm);
+const char* morec_comm_last_error(const morec_comm* comm);
+/* recv[r * bytes_per_rank ...] = rank r's send[0 .. bytes_per_rank)   (ncclAllGather, byte-typed) */
+int morec_comm_all_gather(morec_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+/* recv[i] = sum_r send_r[rank * count_per_rank + i]                   (ncclReduceScatter, fp32 SUM) */
+int morec_comm_reduce_scatter_f32(morec_comm* comm, const float* send, float* recv, size_t count_per_rank, void* stream);
+/* buf[i] = sum_r buf_r[i], in place                                   (ncclAllReduce, fp32 SUM) */
+int morec_comm_all_reduce_f32(morec_comm* comm, float* buf, size_t count, void* stream);
 
 #ifdef __cplusplus
 }

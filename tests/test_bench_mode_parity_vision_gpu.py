@@ -1,0 +1,78 @@
+"""-m gpu: the BENCHMARKED vision mode (bf16 operands: what ``bench.py --tower swin_tiny`` times and the default line carries as
+``vision_swin_tiny``) against the PARITY mode (exact-fp32 MFMA, pinned to the reference golden g13 at 3e-6 on the loss) on the
+SAME kernels the bench runs: Swin-T at 224 x 224, S = 10, D = 2048 (``V/train_swin_tiny.py:22-41``, ``V/parameters.py:34-39``),
+16 user sequences = 176 images, so that the stage-1 / stage-2 products (552 k / 138 k rows) run on ``gemm8p_kernel`` /
+``gemm_tn8p_kernel`` exactly as in the 704-image bench step (the golden tests are 8 images: two-buffer kernels).
+Dropout and DropPath off (their RNG streams cannot be matched between two modes either); same synthetic images and weights.
+
+Stated tolerance of the bf16 vision mode (asserted below, measured values printed): step-0 loss 3e-2, gradient norms of both
+optimizer groups 5e-2, 10-step loss curve 1.5e-1 absolute / 3 % of the loss."""
+import dataclasses
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dtype, shape, D, S, item_num, pop, state=None):
+    from idvs.morec_amd.model import Model
+    from idvs.morec_amd.model.swin import HipSwinForImageClassification
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 CV_model_load="swin_tiny", compute_dtype=dtype)
+    torch.manual_seed(12345)
+    m = Model(args, item_num, True, HipSwinForImageClassification(shape, D), pop)
+    if state is not None:
+        m.load_state_dict(state)
+    return m.to("cuda").train()
+
+
+def test_bf16_vision_bench_mode_tracks_fp32_parity_mode():
+    from idvs.morec_amd.swin_engine import SwinShape
+    from idvs.morec_amd.train_step import TrainStep
+    B, S, D, item_num, steps = 16, 10, 2048, 600, 10
+    shape = dataclasses.replace(SwinShape.named("swin_tiny"), drop_path_rate=0.0)
+    rng = np.random.default_rng(4321)
+    ids_all = rng.integers(1, item_num + 1, size=(steps, B, S + 1)).astype(np.int64)
+    counts = np.bincount(ids_all.reshape(-1), minlength=item_num + 1).astype(np.float64) + 1.0
+    pop = counts / counts[1:].sum()
+    pop[0] = 1.0
+    gen = torch.Generator(device="cuda").manual_seed(4321)
+    catalog = torch.randn((item_num + 1, 3, shape.image_size, shape.image_size), device="cuda", generator=gen)
+    catalog[0].zero_()
+    m32 = _build("fp32", shape, D, S, item_num, pop)
+    state = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    m16 = _build("bf16", shape, D, S, item_num, pop, state)
+    kw = dict(lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False)
+
+    def batch(i):
+        ids = torch.from_numpy(ids_all[i]).cuda().view(-1)
+        return ids, catalog[ids], torch.ones(B, S, device="cuda")
+
+    curves, gnorms = {}, {}
+    for name, model in (("fp32", m32), ("bf16", m16)):
+        ts = TrainStep(model, **kw)
+        curves[name] = []
+        for i in range(steps):
+            loss = ts.forward_backward(*batch(i))
+            if i == 0:
+                gnorms[name] = [float(g["arena"].grad.double().norm()) for g in ts.groups]
+            ts.reduce_gradients()
+            ts.optimizer_step()
+            curves[name].append(float(loss))
+        del ts
+        torch.cuda.empty_cache()
+    c32, c16 = np.array(curves["fp32"]), np.array(curves["bf16"])
+    d0 = abs(c16[0] - c32[0])
+    dcurve = float(np.abs(c16 - c32).max())
+    gn = [abs(a - b) / b for a, b in zip(gnorms["bf16"], gnorms["fp32"])]
+    print(f"vision bench-mode parity (Swin-T, {B * (S + 1)} images), bf16 vs fp32 mode: step-0 loss {c16[0]:.5f} vs {c32[0]:.5f} (|d| {d0:.2e}); "
+          f"gradient-norm rel. diff {['%.2e' % x for x in gn]}; {steps}-step loss curve max |d| {dcurve:.2e}; "
+          f"loss {c32[0]:.4f} -> {c32[-1]:.4f} (fp32), {c16[0]:.4f} -> {c16[-1]:.4f} (bf16)")
+    assert np.isfinite(c16).all() and np.isfinite(c32).all()
+    assert d0 < 3e-2, d0
+    assert max(gn) < 5e-2, gn
+    assert dcurve < 1.5e-1, dcurve
+    assert float(np.abs(c16 - c32).max() / c32.min()) < 3e-2

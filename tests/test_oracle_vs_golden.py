@@ -209,3 +209,37 @@ def test_g7_eval(golden_dir):
     assert np.abs(ndcg - g["ndcg_per_user"]).max() < 1e-6
     h, n = orc.hit_ndcg_at_k(ranks)
     assert abs(h - float(g["hit10"])) < 1e-6 and abs(n - float(g["ndcg10"])) < 1e-6
+
+
+def test_g17_modal_eval(golden_dir):
+    """HR@10 / nDCG@10 THROUGH the text tower (``T/data_utils/metrics.py:60-74`` with ``use_modal=True`` -> ``:77-107``): the
+    oracle's BERT item vectors, SASRec user states and rank bookkeeping against the values captured from the reference."""
+    g = _load(golden_dir, "g17_eval_modal.npz")
+    S, D, T, item_num, U = (int(v) for v in g["cfg"])
+    bert = BertShape.named("micro")
+    shapes = model_param_shapes(max_seq_len=S, embedding_dim=D, n_blocks=2, item_num=item_num, use_modal=True, bert=bert)
+    p = det_state(shapes)
+    with torch.no_grad():
+        emb = orc.text_encoder_forward(p, torch.from_numpy(g["content"]), bert.num_attention_heads)
+    real = np.arange(item_num + 1) != 0      # row 0 = the all-[PAD] padding item: implementation-defined vector (SURVEY §8c hazard 1)
+    assert np.abs(emb.numpy()[real] - g["item_embeddings"][real]).max() < 2e-6
+    emb = torch.from_numpy(g["item_embeddings"])     # ranks from the reference's own vectors (row 0 is masked / dropped anyway)
+    scores, hists, targets = [], [], []
+    with torch.no_grad():
+        for u in range(U):
+            seq = g[f"seq.{u}"]
+            tokens, target = seq[:-1], int(seq[-1])
+            pad = S + 1 - len(seq)
+            x = emb[torch.from_numpy(np.concatenate([np.zeros(pad, dtype=np.int64), tokens]))][None]
+            lm = torch.tensor([[0.0] * pad + [1.0] * len(tokens)])
+            prec = orc.sasrec_forward(p, x, lm, 2)[:, -1]
+            scores.append((prec @ emb.t())[0].numpy())
+            hists.append(tokens)
+            targets.append(target)
+    ranks = orc.eval_ranks(np.stack(scores), hists, np.asarray(targets))
+    hit = (ranks <= 10).astype(np.float32)
+    ndcg = np.where(ranks <= 10, 1.0 / np.log2(ranks + 1.0), 0.0)
+    assert np.array_equal(hit, g["hit_per_user"])
+    assert np.abs(ndcg - g["ndcg_per_user"]).max() < 1e-6
+    h, n = orc.hit_ndcg_at_k(ranks)
+    assert abs(h - float(g["hit10"])) < 1e-6 and abs(n - float(g["ndcg10"])) < 1e-6

@@ -36,3 +36,50 @@ def test_bert_grad_from_follows_the_freeze_index():
     assert not bert_needs_grad_buffer(emb[0], 10) and not bert_needs_grad_buffer(lay(9)[0], 10)
     assert bert_needs_grad_buffer(lay(10)[0], 10) and bert_needs_grad_buffer(head[0], 10) and bert_needs_grad_buffer(emb[0], -1)
     assert not bert_needs_grad_buffer(bm + "pooler.dense.bias", -1)
+
+
+def test_pretrained_bert_key_normalisation_and_checkpoint_dir():
+    """a stock bert-base-uncased file names its LayerNorm parameters ``*.LayerNorm.gamma`` / ``.beta`` under a ``bert.``
+    prefix (HF renames them at load time, ``T/run.py:51-53``); the tower must load ALL of them, and a file that misses a parameter is
+    refused instead of silently keeping the random initialisation.  The checkpoint directory is the reference's (``T/run.py:326-337``)."""
+    import types
+
+    import pytest
+    import torch
+
+    from idvs.morec_amd import run
+    from idvs.morec_amd.model import BertShape, HipBertModel
+    shape = BertShape(vocab_size=50, hidden_size=16, num_hidden_layers=2, num_attention_heads=2, intermediate_size=32, max_position_embeddings=12)
+    src, dst = HipBertModel(shape), HipBertModel(shape)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.uniform_(-1, 1)
+    stock = {}
+    for k, v in src.state_dict().items():
+        k = k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+        stock["bert." + k] = v.clone()
+    stock["cls.predictions.bias"] = torch.zeros(50)
+    stock["bert.embeddings.position_ids"] = torch.arange(12)[None]
+    sd = run.normalize_pretrained_bert_keys(stock)
+    assert set(sd) == set(src.state_dict())
+    missing, unexpected = dst.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a file without the LayerNorm parameters is refused by the driver's loader
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "bert_x"))
+        torch.save({k: v for k, v in stock.items() if "LayerNorm" not in k}, os.path.join(d, "bert_x", "pytorch_model.bin"))
+        args = types.SimpleNamespace(pretrained_dir=d, bert_model_load="bert_x")
+        with pytest.raises(SystemExit):
+            run._load_pretrained_text_tower(HipBertModel(shape), args)
+        torch.save(stock, os.path.join(d, "bert_x", "pytorch_model.bin"))
+        assert run._load_pretrained_text_tower(HipBertModel(shape), args) is True
+    a = types.SimpleNamespace(item_tower="modal", bert_model_load="bert_base_uncased", CV_model_load="None", freeze_paras_before=165,
+                              embedding_dim=512, batch_size=128, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.02,
+                              checkpoint_root=".")
+    assert run.model_dir_of(a, 8) == "./checkpoint_modal_bert_base_uncased_freeze_165/cpt_bert_base_uncased_ed_512_bs_1024_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
+    a.item_tower = "id"
+    assert run.model_dir_of(a, 1) == "./checkpoint_id/cpt_id_ed_512_bs_128_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
