@@ -459,8 +459,10 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
     // ---- bias: one float per lane (column nw + lane), loaded AHEAD of the main loop (bias_l, above: its round trip hides under
     // the K-tiles and costs one register there), spread to the lanes' 8 column groups through the wave's slice.  (A load issued
     // here instead would be waited for in front of the first pass: 1.4 k cycles per tile, profiles/r02_gemm8p_stamps.txt.)
+    // (the activation-derivative epilogues never carry a bias -- dX = (dY W) * act' -- and need the 32 registers for the second
+    // prefetch set of their operand: the launcher refuses bias + dact for this kernel)
     float4 bv[2][4];
-    {
+    if constexpr (ACT < 3) {
         reinterpret_cast<float*>(ws)[lane] = p.bias ? bias_l : 0.f;
         wfence();
 #pragma unroll
@@ -468,9 +470,20 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[Ni][g] = *reinterpret_cast<const float4*>(ws + (Ni * 32 + g * 8 + 4 * h) * 4);
         wfence();
+    } else {
+#pragma unroll
+        for (int Ni = 0; Ni < 2; ++Ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[Ni][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    Vecs dq = Vecs();   // the activation-derivative operand, fetched one pass ahead
-    if constexpr (ACT >= 3) dq = rows_fetch(rD, 0, lo[0]);
+    // the activation-derivative operand, fetched TWO passes ahead (two register sets): a pass is ~1.2 k cycles of work, a global
+    // load queued behind the previous pass's output stores returns after 2-4 k (profiles/r02_gemm8p_stamps.txt: 5 k cycles per
+    // block with one pass of lead)
+    Vecs dq[2] = {Vecs(), Vecs()};
+    if constexpr (ACT >= 3) {
+        dq[0] = rows_fetch(rD, 0, lo[0]);
+        dq[1] = rows_fetch(rD, 1 / NPASS, lo[1 % NPASS]);
+    }
     pin();
 
     // ---- next tile: its prologue flies under this tile's epilogue.  Issued UNCONDITIONALLY (after the last tile it re-reads that
@@ -496,10 +509,10 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         for (int ps = 0; ps < NPASS; ++ps) {
             pin();      // nothing of this pass may be computed ahead of the previous one (128 fresh values on top of the accumulators)
             if constexpr (ACT >= 3) {
-                rows_put(dq);
                 constexpr int LAST = 4 * NPASS - 1;
-                const int nx = Mi * NPASS + ps + 1;
-                if (nx <= LAST) dq = rows_fetch(rD, nx / NPASS, lo[nx % NPASS]);
+                const int it = Mi * NPASS + ps, nx = it + 2;
+                rows_put(dq[it & 1]);
+                if (nx <= LAST) dq[it & 1] = rows_fetch(rD, nx / NPASS, lo[nx % NPASS]);
                 wfence();
             }
             if (aux) {      // second output first (wave-uniform branch): the pre-activation, or act'(pre) with aux_deriv
@@ -810,6 +823,7 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     // automatic: enough tiles to fill the 256 CUs, and at most a quarter of the tile columns past N (N = 192, 384, 576 of the Swin
     // stages: faster here than in the two-buffer kernel; N = 96 is not -- profiles/r02_swin_gemm_shapes_modes.txt)
     if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 134L)) return G8_NOT_TAKEN;
+    if (d->dact != MOREC_ACT_NONE && a.bias) return G8_NOT_TAKEN;      // no bias register set in the derivative epilogues
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
                      : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;
     a.debug = g_debug8p;

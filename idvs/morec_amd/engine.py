@@ -87,11 +87,49 @@ def _splitk(N: int, K: int, Mp: int) -> int:
     return max(1, min(round(512 / small), max(1, Mp // 512), 64))
 
 
+class WgradStream:
+    """Weight gradients on a SECOND HIP stream.  dW = dY^T X feeds nothing in the backward pass (only the gradient reduce / AdamW at
+    the end of the step), while the persistent 256 x 256 GEMMs of the dX chain leave the last, partly filled round of tiles with idle
+    CUs (600 tiles on 256 CUs = 2.34 rounds) and the slab folds / small kernels between them leave more: launched on their own stream
+    the dW workgroups start on every CU the dX chain does not use at that moment, and vice versa -- the hardware dispatcher fills
+    both kernels' tails with the other's tiles.  Ordering: the side stream waits for the producing kernels (event), inputs are
+    pinned to it (``record_stream``), ``join()`` (end of the backward pass, before anything reads the gradient arenas) makes the
+    main stream wait for it.  ``MOREC_WGRAD_STREAM=0`` keeps everything on one stream."""
+    enabled = os.environ.get("MOREC_WGRAD_STREAM", "1") != "0"
+    _streams: dict = {}
+    _dirty: set = set()
+
+    @classmethod
+    def get(cls, device):
+        if not cls.enabled or device.type != "cuda":
+            return None
+        st = cls._streams.get(device)
+        if st is None:
+            st = cls._streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    @classmethod
+    def join(cls, device):
+        """Main stream waits for every weight-gradient launch issued so far (no-op when nothing is pending)."""
+        if device in cls._dirty:
+            torch.cuda.current_stream(device).wait_stream(cls._streams[device])
+            cls._dirty.discard(device)
+
+
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
-    """dw[N, K] += dy[M, N]^T @ x[M, K]  (fp32 atomics, split over M)."""
+    """dw[N, K] += dy[M, N]^T @ x[M, K]  (split over M, slabs folded in a fixed order; on the weight-gradient stream, see ``WgradStream``)."""
     if dy.dtype == torch.bfloat16 and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
         M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
-        ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
+        side = WgradStream.get(dy.device)
+        if side is None:
+            ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
+            return None, None
+        side.wait_stream(torch.cuda.current_stream(dy.device))     # dy (and the zeroed arena) are produced on the main stream
+        with torch.cuda.stream(side):
+            ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))
+        dy.record_stream(side)
+        x.record_stream(side)
+        WgradStream._dirty.add(dy.device)
         return None, None
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt

@@ -40,6 +40,7 @@ class SasrecFn(torch.autograd.Function):
         grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
         d = dout.contiguous().view(-1, in_shape[-1])
         dx = engine.sasrec_backward(p, prep, saved, d, grads, prefix)
+        engine.WgradStream.join(d.device)          # autograd consumers (DDP hooks, the optimizer) read the gradients on this stream
         if dx.dtype != in_dtype:
             dx = ops.cast(dx, in_dtype)
         return (dx.view(in_shape), None, None) + tuple(grads[n] for n in names)
@@ -71,6 +72,7 @@ class BertEncoderFn(torch.autograd.Function):
         skip |= {n for n in names if not engine.bert_needs_grad_buffer(n, grad_from, prefix)}    # never reached by the backward
         grads = _zeros_like_params(names, [p[n] for n in names], skip=skip)
         engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+        engine.WgradStream.join(d_item.device)
         needs = ctx.needs[2:]
         return (None, None) + tuple(grads.get(n) if nd else None for n, nd in zip(names, needs))
 
@@ -97,6 +99,7 @@ class SwinEncoderFn(torch.autograd.Function):
                for b in range(depth) for n in ("q_proj", "k_proj", "v_proj") for k in ("weight", "bias")}
         grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
         swin_engine.swin_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+        engine.WgradStream.join(d_item.device)
         needs = ctx.needs[2:]
         return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
 

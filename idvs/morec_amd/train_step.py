@@ -389,6 +389,7 @@ class TrainStep:
             engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE, on_ready=self._on_ready)
         else:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
+        engine.WgradStream.join(self.device)       # the weight gradients of the side stream are final from here on
         return loss_sum[0] / n_valid
 
     @staticmethod
@@ -417,6 +418,15 @@ class TrainStep:
         """Backward-pass callback of the engines: start reducing the gradients that have just become final."""
         if not self.collectives or not self.overlap_reduce:
             return
+        side = engine.WgradStream.get(self.device) if self.device in engine.WgradStream._dirty else None
+        if side is not None:      # this bucket's weight gradients are being written on the weight-gradient stream: order the collective behind THAT stream
+            side.wait_stream(torch.cuda.current_stream(self.device))    # ... and behind the main stream's share (LayerNorm / bias gradients)
+            with torch.cuda.stream(side):
+                self._issue_ready(key)
+            return
+        self._issue_ready(key)
+
+    def _issue_ready(self, key):
         if key == "head":      # the recommender group (SASRec, fc, id table) is complete once the tower's backward is under way
             gi = len(self.groups) - 1
             self._reduce_slice(gi, 0, self.groups[gi]["arena"].numel)

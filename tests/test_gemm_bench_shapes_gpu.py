@@ -167,12 +167,15 @@ def test_gemm_tn8p_absolute(M, N, K, accumulate):
     x = (torch.randn(M, K, device=DEV, generator=g) * SCALE).to(BF)
     base = torch.randn(N, K, device=DEV, generator=g) if accumulate else torch.full((N, K), 7.0, device=DEV)
     out = base.clone()
-    ops.gemm_tn_(dy, x, out, split_m=_splitk(N, K, M), accumulate=accumulate)       # the split the engines pick for this shape
+    # accumulate (what the engines do: += into the gradient arena) with the split over tokens the engines pick for this shape;
+    # overwrite mode exists for an unsplit launch only (include/morec_hip.h: split_m > 1 requires accumulate != 0)
+    split = _splitk(N, K, M) if accumulate else 1
+    ops.gemm_tn_(dy, x, out, split_m=split, accumulate=accumulate)
     want = dy.double().t() @ x.double() + (base.double() if accumulate else 0.0)
     sigma = SCALE * SCALE * math.sqrt(M)
     _check(out, want, 0.0, 1e-4 * sigma, f"tn {M}x{N}x{K}")
     out2 = base.clone()
-    ops.gemm_tn_(dy, x, out2, split_m=_splitk(N, K, M), accumulate=accumulate)
+    ops.gemm_tn_(dy, x, out2, split_m=split, accumulate=accumulate)
     assert torch.equal(out, out2), "slab fold is not deterministic"
 
 

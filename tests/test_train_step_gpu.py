@@ -305,3 +305,34 @@ def test_short_last_batch_runs_through_the_same_step():
     # two identical runs agree to fp32 rounding, not bit for bit: the first step's parameter gradients are accumulated with
     # float atomics (LayerNorm / bias column sums), whose order differs from launch to launch
     assert np.isfinite(l_short) and abs(l_short - l_ref) < 2e-5
+
+
+@pytest.mark.parametrize("use_modal", [True, False])
+def test_weight_gradient_stream_is_bit_identical(use_modal):
+    """The weight-gradient GEMMs on their own HIP stream (``engine.WgradStream``: dW = dY^T X overlapped with the dX chain) change
+    the ORDER IN TIME of the launches, nothing else: gradient arenas, loss and the parameters after two steps are bit-identical
+    to the single-stream run (bf16: every sum of the step has a fixed order)."""
+    from idvs.morec_amd import engine
+    from idvs.morec_amd.train_step import TrainStep
+    saved = engine.WgradStream.enabled
+    tdev = lambda a: torch.from_numpy(a).to(DEV)      # noqa: E731
+    out = {}
+    try:
+        for on in (False, True):
+            engine.WgradStream.enabled = on
+            model, ids, items, lm, pop, _ = _setup("bf16", use_modal, B=40, S=12, D=256)
+            ts = TrainStep(model, lr=1e-3, fine_tune_lr=5e-4, l2_weight=0.01, fine_tune_l2_weight=0.02)
+            loss0 = ts.forward_backward(tdev(ids).view(-1), tdev(items), tdev(lm))
+            torch.cuda.synchronize()
+            grads = [g["arena"].grad.clone() for g in ts.groups]
+            ts.reduce_gradients()
+            ts.optimizer_step()
+            loss1 = ts.step(tdev(ids).view(-1), tdev(items), tdev(lm))
+            torch.cuda.synchronize()
+            out[on] = (float(loss0), float(loss1), grads, [g["arena"].data.clone() for g in ts.groups])
+    finally:
+        engine.WgradStream.enabled = saved
+    assert out[False][0] == out[True][0] and out[False][1] == out[True][1]
+    for a, b in zip(out[False][2] + out[False][3], out[True][2] + out[True][3]):
+        assert torch.equal(a, b)
+    assert all(float(g.abs().sum()) > 0 for g in out[True][2])

@@ -73,8 +73,14 @@ def test_one_rank_rccl_collectives_are_the_identity(tower, dtype, comm, overlap)
     # a one-rank SUM is the identity: the only difference is the fp32 hand-over of dE (pooled path) instead of the compute dtype
     tol = 1e-6 if dtype == "fp32" else 2e-2
     assert all(abs(a - b) <= tol * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
-    worst = max(float(np.abs(sd0[k] - sd1[k]).max()) for k in sd0 if "pooler" not in k)
-    assert worst <= (1e-6 if dtype == "fp32" else 2.5e-3), worst
+    # bf16: every sum of the step has a fixed order -> the two runs agree to the last bit or two.  fp32 parity mode: its weight
+    # gradients are split-K fp32 ATOMIC sums (order varies from launch to launch), and two Adam steps turn a last-bit difference of an
+    # eps-dominated gradient element into a fraction of 2 lr -- the bound of tests/test_train_step_ddp_gpu.py (key biases excluded
+    # there too: their true gradient is zero, softmax shift invariance)
+    lr = 1e-3
+    worst = max(float(np.abs(sd0[k] - sd1[k]).max()) for k in sd0
+                if "pooler" not in k and not k.endswith(("key.bias", "k_proj.bias", "w_K.bias")))
+    assert worst <= (0.2 * lr if dtype == "fp32" else 1e-6), worst
     print(f"{tower} {dtype} comm={comm or 'torch.distributed(nccl)'} overlap={overlap}: losses {l0} vs {l1}; worst parameter difference {worst:.2e}; "
           f"{n1} reduced slices, buckets {buckets}")
 
