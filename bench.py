@@ -467,11 +467,20 @@ def main():
     # the record.
     ce_fl = sum((2.0 if kind == "fwd" else 6.0) * nr * nc * dd for kind, nr, nc, dd in ce_shapes)
     ce_tf = ce_fl / (ce_ms * 1e-3) / 1e12 if ce_ms > 0 else 0.0
-    roof["scoring"] = {"bound": "mfma", "kernel": "ce_fwd_kernel + ce_combine / ce_bwd_dl_kernel + gemm_tn (dE) + gemm_nt (dP) (fused in-batch debiased CE; logits never stored)",
+    roof["scoring"] = {"bound": "mfma", "kernel": "ce8p_kernel<fwd> + ce_combine / ce8p_kernel<bwd> + gemm8p (dE = dl^T P) + gemm_tn8p (dP = dl E) (fused in-batch debiased CE on 256 x 256 "
+                                                   "eight-phase tiles; logits never stored)",
                        "achieved": round(ce_tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ce_tf / peak, 4),
                        "algorithmic_GBps": round(ce_gbs, 1), "ms_per_step": round(ce_ms / max(1, n_inst), 4),
-                       "note": "launch-latency class at the one-GPU size (0.13 ms per step); 192 / 216 TFLOP/s fwd / bwd in isolation, 359 / 292 at the 8-rank "
-                               "pooled column count (profiles/r02_scoring_pooled.txt)"}
+                       "note": "launch-latency class at the one-GPU size (2560 x 2688 logits: 110 tiles for 256 CUs); the size the multi-GPU step runs is "
+                               "`pooled_8_ranks`"}
+
+    # the scoring kernels at the 8-rank POOLED size (this rank's B S rows against eight ranks' worth of item vectors, emulated on one
+    # GPU): the size north_star's multi-GPU step runs them at; never part of `value`
+    if not a.no_secondary and not vision and world == 1 and a.dtype == "bf16":
+        try:
+            roof["scoring"]["pooled_8_ranks"] = scoring_pooled(ops, a.batch, S, D, dev, peak)
+        except Exception as e:  # noqa: BLE001
+            roof["scoring"]["pooled_8_ranks"] = {"error": f"{type(e).__name__}: {e}"}
 
     out = {"metric": "user-sequences/sec end-to-end train step, SASRec+BERT-base", "value": round(world * a.batch * a.steps / dt, 2),
            "unit": "user-seq/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1), "steps": a.steps, "warmup": a.warmup,
@@ -552,6 +561,44 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scoring_pooled(ops, B, S, D, dev, peak, ranks=8, rank=3, iters=20):
+    """Fused in-batch CE forward + backward at the pooled-negative size of an `ranks`-GPU step, bf16: call-level times (every launch of
+    the C-ABI call: table prep, positive logits, tile kernel, combine / dl^T GEMMs) and the executed FLOP rate."""
+    dt = torch.bfloat16
+    Nr, Nc = B * S, ranks * B * (S + 1)
+    g = torch.Generator(device=dev).manual_seed(ranks)
+    P = (torch.randn(Nr, D, device=dev, generator=g) * 0.3).to(dt)
+    E = (torch.randn(Nc, D, device=dev, generator=g) * 0.3).to(dt)
+    ids = torch.randint(1, 80000, (Nc,), device=dev, generator=g, dtype=torch.int32)
+    row_ids = ids[rank * B * (S + 1):(rank + 1) * B * (S + 1)].contiguous()
+    logpop = torch.randn(Nc, device=dev, generator=g) - 9.0
+    col_valid = torch.ones(Nc, device=dev, dtype=torch.uint8)
+    row_valid = torch.ones(Nr, device=dev, dtype=torch.uint8)
+    desc = ops.ce_desc(B, S, D, Nc, rank * B * (S + 1), dt, dE_fp32=True)
+    ws = ops.ce_workspace(desc, dev)
+    fwd = lambda: ops.inbatch_ce_fwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, ws)      # noqa: E731
+    _, lse, _ = fwd()
+    bwd = lambda: ops.inbatch_ce_bwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, lse, None, 1.0 / Nr, ws)   # noqa: E731
+    bwd()
+    torch.cuda.synchronize()
+    res = {}
+    for name, fn in (("fwd", fwd), ("bwd", bwd)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e3
+    fl = 2.0 * Nr * Nc * D
+    alg_f = (Nr + Nc) * D * 2 + 13 * Nc + 8 * Nr
+    return {"Nr": Nr, "Nc": Nc, "D": D, "fwd_us": round(res["fwd"], 1), "bwd_us": round(res["bwd"], 1),
+            "fwd_tflops": round(fl / res["fwd"] / 1e6, 1), "bwd_tflops": round(3 * fl / res["bwd"] / 1e6, 1),
+            "fwd_frac_of_mfma_peak": round(fl / res["fwd"] / 1e6 / peak, 4), "fwd_algorithmic_GBps": round(alg_f / res["fwd"] / 1e3, 1),
+            "note": "call-level: ce8p prep + positive-logit + 256 x 256 tile kernel + combine (fwd); + dl^T, dE = dl^T P (one NT GEMM, fp32), "
+                    "dP = dl E (transposing GEMM) (bwd); kernel-level numbers in profiles/"}
 
 
 def cpu_baseline(a):

@@ -26,246 +26,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
-#include "gemm_core.hpp"
+#include "gemm8p_core.hpp"
 #include "gemm_args.hpp"
+#include "ce_args.hpp"
 
 namespace {
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
-
-constexpr int TM = 256, TN = 256, KE = 64;      // tile; K elements per K-tile
-constexpr int KB = 128;                          // bytes of K per row per K-tile
-constexpr int OP_BYTES = 256 * KB;               // one operand of one K-tile: 32 KiB
-constexpr int BUF_BYTES = 2 * OP_BYTES;          // 64 KiB
-constexpr int LDS_BYTES = 2 * BUF_BYTES;         // 128 KiB
-constexpr int THREADS = 512;
-
-template <int N>
-__device__ __forceinline__ void vm_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
-__device__ __forceinline__ void bar() {
-    pin();
-    __builtin_amdgcn_s_barrier();
-    pin();
-}
-
-typedef __attribute__((address_space(8))) void* rsrc_t;   // 128-bit buffer descriptor (4 SGPRs)
-
-// The two 1-KiB pieces (8 rows each) this wave contributes to a half-tile.  buffer_load ... offen lds: descriptor (SGPRs) +
-// per-lane 32-bit byte offset (loop-invariant VGPR) + wave-uniform K offset (SGPR): no per-lane 64-bit pointers to keep alive
-// or to advance, which is what made the flat global_load_lds form of this loop spill.
-__device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, int kbyte, char* dst) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, o0, kbyte, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, o1, kbyte, 0, 0);
-}
-struct Ctx;
-// The same for a K-tile that may be the LAST one of a K that is not a multiple of 64: `m` = all ones when it is (wave-uniform),
-// and the lanes whose 16-byte slot lies past K carry 0x80000000 in c.pz[]: the offset leaves the descriptor's range and the DMA
-// writes zeros.  One v_and_or_b32 per instruction; with K % 64 == 0 pz is 0 and nothing changes.
-__device__ __forceinline__ void dma2z(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, const uint32_t (&pz)[2], uint32_t m, int kbyte, char* dst) {
-    dma2(rs, o0 | (pz[0] & m), o1 | (pz[1] & m), kbyte, dst);
-}
-
-struct Ctx {
-    __amdgpu_buffer_rsrc_t ra, rb;               // descriptors of A / B, based at the tile's first row
-    uint32_t a1[2], a2[2], b1[2], b2[2];         // per-lane byte offsets of the wave's two pieces of each half-tile
-    int dA1, dA2, dB1, dB2;                      // wave-uniform LDS offsets (within a buffer) of those pieces
-    int aoff, boff;                              // LDS offsets (within a buffer) of the wave's first A row / first B row
-    int loff[4];                                 // per-lane fragment offset of MFMA k-step ks: row (lane & 31), swizzled slot
-    uint32_t pz[2];                              // 0x80000000 where this lane's slot of piece j lies past K in the LAST K-tile, else 0
-};
-
-__device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
-
-// ZERO: the first K-tile of an output tile starts its accumulators from the MFMA's inline-constant 0 operand instead of 128
-// v_mov per lane ahead of the loop.
-template <int M0, int NQ, bool ZERO>
-__device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4 (&fa)[2][4], const uint4 (&fb)[4]) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {  // operand-swapped: the lane ends up owning ONE m and runs of 4 consecutive n
-            f32x16_t cin = acc[M0 + mi][NQ];
-            if constexpr (ZERO) {
-                if (ks == 0) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) cin[v] = 0.f;
-                }
-            }
-            acc[M0 + mi][NQ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[mi][ks]), cin, 0, 0, 0);
-        }
-    __builtin_amdgcn_s_setprio(0);
-}
-
-// vmcnt left in flight after a phase's issue: 8 in the steady state (the refills of the last four phases); the last two
-// K-tiles issue fewer, so fewer may be left.  REM = K-tiles after this one, capped at 2 (compile time: no branches in the loop).
-// SLACK: VMEM operations YOUNGER than the tile's prologue and OLDER than its in-loop refills that may also stay in flight -- the
-// global stores of the previous tile's epilogue.  Vector memory operations complete in execution order, so "at most 8 + SLACK
-// outstanding" still means "everything up to the 8 newest refills has landed" as long as SLACK does not exceed their number.
-template <int REM, int W1, int W0, int SLACK = 0>
-__device__ __forceinline__ void vm_wait_tail() {
-    vm_wait<(REM >= 2 ? 8 + SLACK : (REM == 1 ? W1 : W0))>();
-}
-
-// One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
-// last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
-template <int REM, int SLACK = 0, bool ZERO = false>
-__device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
-    const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
-    const uint32_t m2 = last2 ? 0xffffffffu : 0u;
-    static_assert(SLACK == 0 || REM == 2, "slack only on a steady K-tile");
-    char* cur = smem + cb;
-    char* oth = smem + (cb ^ BUF_BYTES);
-    uint4 fa[2][4], fb0[4], fb1[4];
-    int ada[4], adb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        ada[ks] = cb + c.aoff + c.loff[ks];
-        adb[ks] = cb + OP_BYTES + c.boff + c.loff[ks];
-    }
-    // ---- phase 0: B-first + A-first fragments; refill B-second of t+1
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = lds16(smem + adb[ks]);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
-    if constexpr (REM >= 1) dma2z(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
-    pin();
-    vm_wait_tail<REM, 8, 2, SLACK>();
-    bar();
-    mfma_quadrant<0, 0, ZERO>(acc, fa, fb0);
-    bar();
-    // ---- phase 1: B-second fragments; refill A-second of t+1
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = lds16(smem + adb[ks] + 32 * KB);
-    if constexpr (REM >= 1) dma2z(c.ra, c.a2[0], c.a2[1], c.pz, m1, kb + KB, oth + c.dA2);
-    pin();
-    vm_wait_tail<REM, 8, 0, SLACK>();
-    bar();
-    mfma_quadrant<0, 1, ZERO>(acc, fa, fb1);
-    bar();
-    // ---- phase 2: A-second fragments; refill A-first of t+2 (this buffer)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + (64 + mi * 32) * KB);
-    if constexpr (REM >= 2) dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m2, kb + 2 * KB, cur + c.dA1);
-    pin();
-    vm_wait_tail<REM, 6, 0, SLACK>();
-    bar();
-    mfma_quadrant<2, 1, ZERO>(acc, fa, fb1);
-    bar();
-    // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
-    if constexpr (REM >= 2) dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
-    pin();
-    vm_wait_tail<REM, 4, 0, SLACK>();
-    bar();
-    mfma_quadrant<2, 0, ZERO>(acc, fa, fb0);
-    bar();
-}
-
-// ---- DMA / fragment context of one tile.  At, Bt = first row of the tile's A / B panel; rows_a, rows_b = rows that exist from
-// there on (M - m0, N - n0; rows past them are clamped to the last valid one).  `tid` is an opaque copy of threadIdx.x: the
-// context is recomputed per tile (a few dozen integer ops) instead of being kept alive across the epilogue.
-__device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const bf16* Bt, int rows_a, int rows_b, int lda, int ldb, int krem) {
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    // DMA geometry: piece j of a half-tile = 8 rows; lane -> row (lane >> 3) of the piece, physical slot lane & 7
-    const int ra = wr * 128 + wc * 16;                       // this wave's 16 rows of A-first (A-second: + 64)
-    const int rb = (wave >> 1) * 64 + (wave & 1) * 16;       // this wave's 16 rows of B-first (B-second: + 32)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rl = j * 8 + (lane >> 3);
-        const int slot = (lane & 7) ^ ((rl >> 1) & 7);       // (row >> 1) & 7 with row = 16-aligned base + rl
-        c.a1[j] = (uint32_t)min(ra + rl, rows_a - 1) * (uint32_t)(lda * 2) + slot * 16;
-        c.a2[j] = (uint32_t)min(ra + 64 + rl, rows_a - 1) * (uint32_t)(lda * 2) + slot * 16;
-        c.b1[j] = (uint32_t)min(rb + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
-        c.b2[j] = (uint32_t)min(rb + 32 + rl, rows_b - 1) * (uint32_t)(ldb * 2) + slot * 16;
-        c.pz[j] = slot * 8 >= krem ? 0x80000000u : 0u;          // krem = elements of K in the unit's last K-tile (64: all of it)
-    }
-    // descriptors: raw (stride 0), extent = the rows of this tile that exist (every offset above stays inside it)
-    const long abytes = (long)min(256, rows_a) * lda * 2, bbytes = (long)min(256, rows_b) * ldb * 2;
-    c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)At, 0, (int)min(abytes, 0x7fffffffL), 0x00020000);
-    c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, 0, (int)min(bbytes, 0x7fffffffL), 0x00020000);
-    c.dA1 = ra * KB; c.dA2 = (ra + 64) * KB; c.dB1 = rb * KB; c.dB2 = (rb + 32) * KB;
-    c.aoff = wr * 128 * KB;
-    c.boff = wc * 64 * KB;
-    const int r5 = lane & 31, fr = (r5 >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) c.loff[ks] = r5 * KB + (((2 * ks + (lane >> 5)) ^ fr) << 4);
-}
-
-// Prologue of a tile: K-tile 0 entirely, the first halves of K-tile 1 (12 LDS-DMA instructions per lane).  LDS must be free
-// of readers: called before the first tile and, for the NEXT tile, right after a main loop (every wave is past its last barrier)
-// -- i.e. ahead of the finished tile's epilogue, whose slices live outside the two K-tile buffers.
-__device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk) {
-    const uint32_t m = nk == 2 ? 0xffffffffu : 0u;
-    dma2(c.ra, c.a1[0], c.a1[1], 0, smem + c.dA1);
-    dma2(c.rb, c.b1[0], c.b1[1], 0, smem + OP_BYTES + c.dB1);
-    dma2(c.rb, c.b2[0], c.b2[1], 0, smem + OP_BYTES + c.dB2);
-    dma2(c.ra, c.a2[0], c.a2[1], 0, smem + c.dA2);
-    dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m, KB, smem + BUF_BYTES + c.dA1);
-    dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m, KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
-    pin();
-}
-
-// acc += A-panel . B-panel^T over K (K % 64 == 0, K >= 128), prologue already issued.  On return every DMA of this tile has
-// landed and every wave has passed the last barrier: the K-tile buffers are free.
-// The first wait is `vmcnt(8)` whatever else the wave has in flight: it bounds the number of PENDING loads by 8, and loads
-// retire in order among themselves, so the four oldest prologue pieces have landed even with younger stores outstanding.
-#define G8_MSTAMP(i)                                                                    \
-    do {                                                                                \
-        if (st && threadIdx.x == 0) st[(i)] = __builtin_readcyclecounter();              \
-    } while (0)
-template <int SLACK>
-__device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char* smem, f32x16_t (&acc)[4][2], unsigned long long* st) {
-    G8_MSTAMP(8);
-    vm_wait<8 + SLACK>();    // A-first, B-first of K-tile 0 (this wave's pieces)
-    G8_MSTAMP(9);
-    bar();                   // ... everybody's
-    if (wr == 1) bar();      // waves 4-7 run one barrier behind waves 0-3 from here on
-    G8_MSTAMP(10);
-    int cb = 0;
-    int t = 0;
-    if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<2, SLACK, true>(smem, c, cb, 0, acc, nk == 3);
-        cb ^= BUF_BYTES;
-        t = 1;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    }
-    G8_MSTAMP(11);
-    for (; t < nk - 2; ++t) {
-        ktile<2>(smem, c, cb, t * KB, acc, t + 3 == nk);
-        cb ^= BUF_BYTES;
-        if (t == 1) G8_MSTAMP(12);
-    }
-    G8_MSTAMP(13);
-    ktile<1>(smem, c, cb, t * KB, acc);
-    ktile<0>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
-    G8_MSTAMP(14);
-    if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
-    G8_MSTAMP(15);
-}
-// `younger`: VMEM operations this wave has issued since the tile's prologue (only a LOWER bound matters: see vm_wait_tail)
-__device__ __forceinline__ void mainloop8p(const Ctx& c, int wr, int nk, int younger, char* smem, f32x16_t (&acc)[4][2],
-                                           unsigned long long* st) {
-    if (younger >= 32) mainloop8p_s<32>(c, wr, nk, smem, acc, st);
-    else if (younger >= 16) mainloop8p_s<16>(c, wr, nk, smem, acc, st);
-    else mainloop8p_s<0>(c, wr, nk, smem, acc, st);
-}
-
+using namespace g8;
 // -----------------------------------------------------------------------------------------------------------------------
 // Persistent kernel: workgroup b walks the tiles b, b + gridDim.x, ... (gridDim.x = one workgroup per CU); the prologue DMA of
 // the next tile is issued BEFORE the epilogue of the finished one, so the first fill of the pipeline (7.4 k cycles when it
@@ -792,6 +558,7 @@ extern "C" int morec_tuning_set(const char* key, int value) {
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_split")) { g_tail_split = value != 0; return MOREC_OK; }
+    if (!strcmp(key, "ce8p")) { g_ce8p_mode = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_ngroup")) { g_ngroup = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_reserve_cus")) { g_reserve_cus = value < 0 ? 0 : value > 128 ? 128 : value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_bias")) { g_tail_bias = value < 0 ? 0 : value > 16 ? 16 : value; return MOREC_OK; }
@@ -808,6 +575,7 @@ int gemm8p_mode() {
         if (const char* d = getenv("MOREC_GEMM8P_DEBUG")) g_debug8p = atoi(d);     // ablation bits for whole-step A/B runs
         if (const char* t = getenv("MOREC_GEMM8P_TAIL_SPLIT")) g_tail_split = atoi(t) != 0;
         if (const char* n = getenv("MOREC_GEMM8P_NGROUP")) g_ngroup = atoi(n);
+        if (const char* c = getenv("MOREC_CE8P")) g_ce8p_mode = atoi(c);
         if (const char* r = getenv("MOREC_GEMM8P_RESERVE_CUS")) { const int v = atoi(r); g_reserve_cus = v < 0 ? 0 : v > 128 ? 128 : v; }
     }
     return g_mode8p;
@@ -822,7 +590,8 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (a.colsum && d->M < 128) return G8_NOT_TAKEN;      // partial-row workspace is sized per 64 rows
     // automatic: enough tiles to fill the 256 CUs, and at most a quarter of the tile columns past N (N = 192, 384, 576 of the Swin
     // stages: faster here than in the two-buffer kernel; N = 96 is not -- profiles/r02_swin_gemm_shapes_modes.txt)
-    if (g_mode8p != 2 && (tiles < 192 || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 134L)) return G8_NOT_TAKEN;
+    // (long-K problems already from 160 tiles: the scoring backward's dE = dl^T P, 168 tiles of 40 K-tiles each)
+    if (g_mode8p != 2 && (tiles < (d->K >= 2048 ? 160 : 192) || ((d->N + TN - 1) / TN) * TN * 100L > d->N * 134L)) return G8_NOT_TAKEN;
     if (d->dact != MOREC_ACT_NONE && a.bias) return G8_NOT_TAKEN;      // no bias register set in the derivative epilogues
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
                      : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;

@@ -13,6 +13,7 @@
 //   label(r = u*S + j) = col_offset + u*(S+1) + j + 1                         (model.py:45-48)
 // Masked cells keep the VALUE -1e4 inside the softmax (exactly as the reference) and get zero gradient.
 #include "gemm_core.hpp"
+#include "ce_args.hpp"
 
 namespace {
 constexpr float MASKED_LOGIT = -1e4f;
@@ -149,34 +150,40 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(CeArgs p) {
     }
 }
 
-// one wave per row: merge the K2 partials -> lse, loss; block-sum the valid rows' losses into loss_sum
+// one wave per FOUR rows: merge the K2 partials -> lse, loss; block-sum the valid rows' losses into loss_sum (one atomic per 16 rows:
+// with one per 4 rows the 640 same-address atomics of the B = 128 step were most of this kernel's 12 us)
+constexpr int CE_ROWS_PER_WAVE = 4;
 __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                          const float* __restrict__ pos,
                                                          const uint8_t* __restrict__ row_valid,
                                                          float* __restrict__ row_lse, float* __restrict__ row_loss,
-                                                         float* __restrict__ loss_sum, int Nr, int K2) {
+                                                         float* __restrict__ loss_sum, int Nr, int K2, int log2_domain) {
     __shared__ float s_part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    float loss = 0.f;
-    if (row < Nr) {
+    float loss_w = 0.f;
+#pragma unroll
+    for (int i = 0; i < CE_ROWS_PER_WAVE; ++i) {
+        const int row = (blockIdx.x * 4 + wave) * CE_ROWS_PER_WAVE + i;
+        if (row >= Nr) break;
         float mx = -INFINITY;
         for (int k = lane; k < K2; k += 64) mx = fmaxf(mx, pmax[(size_t)row * K2 + k]);
         mx = wave_max(mx);
         float sm = 0.f;
         for (int k = lane; k < K2; k += 64) {
             const float pm = pmax[(size_t)row * K2 + k];
-            if (pm > -INFINITY) sm += psum[(size_t)row * K2 + k] * expf(pm - mx);
+            if (pm > -INFINITY) sm += psum[(size_t)row * K2 + k] * (log2_domain ? exp2f(pm - mx) : expf(pm - mx));
         }
         sm = wave_sum(sm);
-        const float lse = mx + logf(sm);
-        loss = row_valid[row] ? (lse - pos[row]) : 0.f;
+        // log2_domain (the eight-phase scoring kernels): maxima and sums of 2^(x log2 e) -> lse = ln 2 (max2 + log2 sum)
+        const float lse = log2_domain ? 0.6931471805599453f * (mx + log2f(sm)) : mx + logf(sm);
+        const float loss = row_valid[row] ? (lse - pos[row]) : 0.f;
         if (lane == 0) {
             row_lse[row] = lse;
             row_loss[row] = loss;
         }
+        loss_w += loss;
     }
-    if (lane == 0) s_part[wave] = loss;
+    if (lane == 0) s_part[wave] = loss_w;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
@@ -251,7 +258,14 @@ extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
         const size_t tn = (Nr * ldc + D * ldc) * es + Nc * D * sizeof(float) + (size_t)ce_tn_split((int)Nr, (int)Nc, (int)D) * Nc * D * sizeof(float) + 1024;
         bwd = tn > bwd ? tn : bwd;
     }
-    return (fwd > bwd ? fwd : bwd) + 256;
+    size_t need = (fwd > bwd ? fwd : bwd) + 256;
+    if (ce8p_eligible(d)) {      // the eight-phase scoring kernels (inbatch_ce8p.hip) lay the workspace out differently
+        Ce8Layout L;
+        ce8p_layout(d, L);
+        if (L.fwd_bytes + 256 > need) need = L.fwd_bytes + 256;
+        if (L.bwd_bytes + 256 > need) need = L.bwd_bytes + 256;
+    }
+    return need;
 }
 
 static int ce_fill(const morec_ce_desc* d, CeArgs& a) {
@@ -282,7 +296,13 @@ extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const
     a.pmax = ws; a.psum = ws + (size_t)a.Nr * a.K2; a.pos = ws + 2 * (size_t)a.Nr * a.K2;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.tiles_m * a.tiles_n);
-    if (d->dtype == MOREC_F32) {
+    int log2_domain = 0;
+    if (ce8p_eligible(d)) {      // 256 x 256 tiles on the eight-phase main loop; same partial format (one entry per 64-column slice)
+        if (!aligned16(col_ids) || !aligned16(col_logpop) || (reinterpret_cast<uintptr_t>(col_valid) & 3u)) return MOREC_E_ALIGN;
+        rc = ce8p_fwd(d, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, workspace, &a.pmax, &a.psum, &a.pos, &a.K2, s);
+        if (rc) return rc;
+        log2_domain = 1;
+    } else if (d->dtype == MOREC_F32) {
         using G = GemmTile<float, 2>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<float>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -294,8 +314,8 @@ extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const
         hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
     }
     MOREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_combine_kernel, dim3((a.Nr + 3) / 4), dim3(256), 0, s, a.pmax, a.psum, a.pos, row_valid,
-                       row_lse, row_loss, loss_sum, a.Nr, a.K2);
+    hipLaunchKernelGGL(ce_combine_kernel, dim3((a.Nr + 4 * CE_ROWS_PER_WAVE - 1) / (4 * CE_ROWS_PER_WAVE)), dim3(256), 0, s, a.pmax, a.psum, a.pos, row_valid,
+                       row_lse, row_loss, loss_sum, a.Nr, a.K2, log2_domain);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -314,6 +334,11 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
         return MOREC_E_ALIGN;
     a.P = P; a.E = E; a.row_ids = row_ids; a.col_ids = col_ids; a.col_logpop = col_logpop; a.col_valid = col_valid;
     a.row_valid = row_valid; a.row_lse = row_lse; a.gscale_dev = gscale_dev; a.gscale = gscale;
+    if (ce8p_eligible(d)) {
+        if (!aligned16(col_ids) || !aligned16(col_logpop) || (reinterpret_cast<uintptr_t>(col_valid) & 3u)) return MOREC_E_ALIGN;
+        return ce8p_bwd(d, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, row_lse, gscale_dev, gscale, dP, dE, workspace,
+                        reinterpret_cast<hipStream_t>(stream));
+    }
     const int es = elt_size(d->dtype);
     const int ldc = pad8(a.Nc), ldr = pad8(a.Nr);
     char* ws = reinterpret_cast<char*>(workspace);

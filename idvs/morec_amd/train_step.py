@@ -186,6 +186,14 @@ class TrainStep:
         # the C-ABI's own RCCL communicator ON THE COMPUTE STREAM (morec_comm_*: no cross-stream events around three small
         # collectives whose results the next kernel needs at once), and the gradient buckets through a second communicator on a
         # side stream (they overlap the rest of the backward pass).  Default: torch.distributed's collectives.
+        # Data parallel: the persistent GEMM grid (one 160-KiB-LDS workgroup per CU) is sized to ALL CUs; an RCCL ring kernel that
+        # holds a few CUs for the length of a 28-MB bucket would push the last workgroups of every GEMM launch into a second
+        # round (2x the launch).  Leave CUs out of the grid while collectives overlap the backward pass (scripts/rccl_cu_probe.py;
+        # MOREC_GEMM8P_RESERVE_CUS overrides, 0 = none).
+        self.overlap_reduce = os.environ.get("MOREC_OVERLAP_REDUCE", "1") != "0"
+        if self.collectives and self.overlap_reduce and self.device.type == "cuda" and "MOREC_GEMM8P_RESERVE_CUS" not in os.environ:
+            from . import _lib
+            _lib.lib().morec_tuning_set(b"gemm8p_reserve_cus", 16)
         comm = comm if comm is not None else os.environ.get("MOREC_COMM", "")
         self.comm = self.comm_grad = self._grad_stream = None
         if comm == "rccl" and self.collectives and self.device.type == "cuda":
@@ -193,7 +201,6 @@ class TrainStep:
             self.comm, self.comm_grad = MorecComm(), MorecComm()
             self._grad_stream = torch.cuda.Stream(device=self.device)
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
-        self.overlap_reduce = os.environ.get("MOREC_OVERLAP_REDUCE", "1") != "0"
         self.buckets = self._bucket_plan()
         self._pending, self._reduced = [], []
 

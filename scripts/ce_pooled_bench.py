@@ -5,11 +5,14 @@ pooled size (Nc = 21 504, emulated on one GPU: this rank's 2 560 rows against ei
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from idvs.morec_amd import ops
+from idvs.morec_amd import ops, _lib
 dev, dt = "cuda", torch.bfloat16
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-B, S, D = 128, 20, 512
-for ranks, rank in ((1, 0), (8, 3)):
+MODE = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # tuning key "ce8p": 0 automatic, 1 the 128 x 128 kernels, 2 the 256 x 256 eight-phase kernels
+_lib.lib().morec_tuning_set(b"ce8p", MODE)
+B, S, D = 128, 20, int(sys.argv[3]) if len(sys.argv) > 3 else 512
+print(f"# ce8p mode {MODE}, D = {D}")
+for ranks, rank in ((1, 0), (2, 1), (4, 1), (8, 3)):
     Nr, Nc = B * S, ranks * B * (S + 1)
     g = torch.Generator(device=dev).manual_seed(ranks)
     P = (torch.randn(Nr, D, device=dev, generator=g) * 0.3).to(dt); E = (torch.randn(Nc, D, device=dev, generator=g) * 0.3).to(dt)

@@ -32,7 +32,7 @@ def _train_step(tower):
                                          ("swin", "backward")])
 def test_every_gradient_element_reduced_once(tower, order):
     ts = _train_step(tower)
-    ts.world = 2                                   # pretend: the slices are recorded instead of sent
+    ts.world, ts.collectives = 2, True             # pretend: the slices are recorded instead of sent
     calls = []
     ts._reduce_slice = lambda gi, lo, hi: (calls.append((gi, lo, hi)), ts._reduced.append((gi, lo, hi)))
     ts._pending, ts._reduced = [], []
