@@ -202,7 +202,8 @@ class TrainStep:
             self._grad_stream = torch.cuda.Stream(device=self.device)
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
         self.buckets = self._bucket_plan()
-        self._pending, self._reduced = [], []
+        self._pending, self._reduced, self._stepped = [], [], []
+        self._fused_update = False
 
     def _bucket_plan(self):
         """Contiguous slices of the tower arena whose gradients become final together: ``("layer", l)`` for the text
@@ -335,11 +336,18 @@ class TrainStep:
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
-        if self._wt_batch is not None:
-            self._wt_batch.run()          # W^T of every Linear weight from the shadows AdamW (or sync_shadow) last wrote
-        for grp in self.groups:
-            grp["arena"].grad.zero_()
-        self._pending, self._reduced = [], []
+        # Nothing in the FORWARD pass reads the gradient arenas or the W^T copies (dX = dY W): zero / refresh them on the side stream,
+        # under the forward GEMMs (HBM-bound fills next to MFMA-bound kernels), and let the main stream wait for them right before
+        # the backward pass starts.
+        side = engine.WgradStream.get(self.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.device))     # the previous step's AdamW wrote the shadows the transposes read
+            with torch.cuda.stream(side):
+                self._prepare_step_buffers()
+            engine.WgradStream._dirty.add(self.device)
+        else:
+            self._prepare_step_buffers()
+        self._pending, self._reduced, self._stepped = [], [], []
         # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
         grads = dict(g)
         for n, t in self.frozen.items():      # frozen tensors the backward still passes through get scratch buffers
@@ -382,6 +390,8 @@ class TrainStep:
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank, self.comm)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.collectives and self.pool))
         gscale = (1.0 / n_valid).reshape(1)
+        if side is not None:       # gradient arenas zeroed, W^T copies in place
+            torch.cuda.current_stream(self.device).wait_stream(side)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
         dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype, self.comm) if (self.collectives and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
@@ -398,6 +408,12 @@ class TrainStep:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
         engine.WgradStream.join(self.device)       # the weight gradients of the side stream are final from here on
         return loss_sum[0] / n_valid
+
+    def _prepare_step_buffers(self):
+        if self._wt_batch is not None:
+            self._wt_batch.run()          # W^T of every Linear weight from the shadows AdamW (or sync_shadow) last wrote
+        for grp in self.groups:
+            grp["arena"].grad.zero_()
 
     @staticmethod
     def _all_reduce(t):
@@ -423,7 +439,10 @@ class TrainStep:
 
     def _on_ready(self, key):
         """Backward-pass callback of the engines: start reducing the gradients that have just become final."""
-        if not self.collectives or not self.overlap_reduce:
+        if not self.collectives:
+            self._early_adamw(key)
+            return
+        if not self.overlap_reduce:
             return
         side = engine.WgradStream.get(self.device) if self.device in engine.WgradStream._dirty else None
         if side is not None:      # this bucket's weight gradients are being written on the weight-gradient stream: order the collective behind THAT stream
@@ -432,6 +451,36 @@ class TrainStep:
                 self._issue_ready(key)
             return
         self._issue_ready(key)
+
+    def _early_adamw(self, key):
+        """Single process, inside ``step()``: the AdamW update of a bucket whose gradients are final (the recommender group once the
+        tower's backward is under way, an encoder layer / Swin stage when its backward is done) runs on the side stream behind that
+        bucket's weight-gradient GEMMs, UNDER the rest of the backward pass (28 B / parameter of HBM traffic next to MFMA-bound
+        GEMMs) instead of after it.  Safe: nothing later in this step reads these weights again -- the backward walks the layers
+        downwards -- and the bf16 shadow / W^T copies are only read by the next step."""
+        if not self._fused_update:
+            return
+        side = engine.WgradStream.get(self.device)
+        if side is None:
+            return
+        if key == "head":
+            gi = len(self.groups) - 1
+            lo, hi = 0, self.groups[gi]["arena"].numel
+        elif key in self.buckets:
+            gi, (lo, hi) = 0, self.buckets[key]
+        else:
+            return
+        side.wait_stream(torch.cuda.current_stream(self.device))      # LayerNorm / bias gradients of the bucket are written on the main stream
+        with torch.cuda.stream(side):
+            self._adamw_slice(gi, lo, hi, self.step_count + 1)
+        engine.WgradStream._dirty.add(self.device)
+        self._stepped.append((gi, lo, hi))
+
+    def _adamw_slice(self, gi, lo, hi, step):
+        grp = self.groups[gi]
+        a = grp["arena"]
+        ops.adamw_(a.data[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], None if a.shadow is None else a.shadow[lo:hi],
+                   grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], step)
 
     def _issue_ready(self, key):
         if key == "head":      # the recommender group (SASRec, fc, id table) is complete once the tower's backward is under way
@@ -547,16 +596,26 @@ class TrainStep:
         return loss
 
     def optimizer_step(self):
+        """AdamW over everything ``_early_adamw`` has not already stepped during this step's backward pass (all of it outside ``step()``)."""
         self.step_count += 1
-        for grp in self.groups:
-            a = grp["arena"]
-            ops.adamw_(a.data, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, grp["lr"], self.betas[0], self.betas[1],
-                       self.eps, grp["wd"], self.step_count)
+        for gi, grp in enumerate(self.groups):
+            done = sorted((lo, hi) for g_, lo, hi in self._stepped if g_ == gi)
+            pos, n = 0, grp["arena"].numel
+            for lo, hi in done + [(n, n)]:
+                assert lo >= pos, "overlapping early-AdamW slices"
+                if lo > pos:
+                    self._adamw_slice(gi, pos, lo, self.step_count)
+                pos = hi
+        self._stepped = []
 
     def step(self, sample_items_id, sample_items, log_mask):
         """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling).  Returns the loss
         of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``."""
-        loss = self.forward_backward(sample_items_id, sample_items, log_mask)
+        self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
+        try:
+            loss = self.forward_backward(sample_items_id, sample_items, log_mask)
+        finally:
+            self._fused_update = False
         self.reduce_gradients()
         self.optimizer_step()
         return loss

@@ -308,10 +308,11 @@ def test_short_last_batch_runs_through_the_same_step():
 
 
 @pytest.mark.parametrize("use_modal", [True, False])
-def test_weight_gradient_stream_is_bit_identical(use_modal):
+def test_weight_gradient_stream_changes_nothing(use_modal):
     """The weight-gradient GEMMs on their own HIP stream (``engine.WgradStream``: dW = dY^T X overlapped with the dX chain) change
-    the ORDER IN TIME of the launches, nothing else: gradient arenas, loss and the parameters after two steps are bit-identical
-    to the single-stream run (bf16: every sum of the step has a fixed order)."""
+    the ORDER IN TIME of the launches, nothing else; the same for the step buffers zeroed / refreshed on that stream under the forward
+    pass and for the AdamW updates issued from the backward pass (``TrainStep._early_adamw``, second step of this test): gradient
+    arenas, loss and the parameters after two steps equal the single-stream run up to the order of the fp32 atomic sums."""
     from idvs.morec_amd import engine
     from idvs.morec_amd.train_step import TrainStep
     saved = engine.WgradStream.enabled
@@ -332,7 +333,14 @@ def test_weight_gradient_stream_is_bit_identical(use_modal):
             out[on] = (float(loss0), float(loss1), grads, [g["arena"].data.clone() for g in ts.groups])
     finally:
         engine.WgradStream.enabled = saved
-    assert out[False][0] == out[True][0] and out[False][1] == out[True][1]
-    for a, b in zip(out[False][2] + out[False][3], out[True][2] + out[True][3]):
-        assert torch.equal(a, b)
+    # (the reported loss is an fp32 atomic sum of per-block partials -- ce_combine -- and may differ in the last bit from run to run;
+    # nothing downstream depends on it: the gradient scale is 1 / n_valid)
+    assert abs(out[False][0] - out[True][0]) <= 1e-6 * abs(out[True][0]) and abs(out[False][1] - out[True][1]) <= 1e-6 * abs(out[True][1])
+    # Weight gradients are bit-identical (fixed-order slab folds); LayerNorm gamma / beta and bias gradients are fp32 ATOMIC sums whose
+    # order varies from launch to launch even on one stream, so the arenas agree to fp32 rounding, not to the bit; two Adam steps may
+    # turn such a last-bit difference of an eps-dominated element into a fraction of 2 lr (the bound of the data-parallel tests)
+    for a, b in zip(out[False][2], out[True][2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    for a, b in zip(out[False][3], out[True][3]):
+        assert float((a - b).abs().max()) <= 0.2 * 1e-3
     assert all(float(g.abs().sum()) > 0 for g in out[True][2])
