@@ -266,7 +266,10 @@ def main():
 
     ops.inbatch_ce_fwd, ops.inbatch_ce_bwd = timed_ce(real_ce_f, "fwd"), timed_ce(real_ce_b, "bwd")
 
+    n_run = {"v": 0}
+
     def run_step(i):
+        n_run["v"] += 1
         ids, items, lm = host[i]
         ids_d = ids.to(dev, non_blocking=True)
         items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
@@ -491,7 +494,7 @@ def main():
                                   f"B={a.batch}/GPU, S=20, T=30", "global_batch": world * a.batch, "seq_len": S + 3,
                       "parallelism": f"dp{world}" + ("" if a.no_pool or world == 1 else "+pooled-negatives"),
                       "dropout": "on (p = 0.1 hidden + attention, SASRec and BERT; counter-based masks fused in the kernels)"},
-           "final_loss": round(loss_v, 4), "roofline": roof}
+           "final_loss": round(loss_v, 4), "roofline": roof, "steps_executed": n_run["v"]}
     if sustained is not None:
         out["sustained"] = sustained
     if id_tower:

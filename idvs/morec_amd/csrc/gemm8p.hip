@@ -267,7 +267,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         return;
     }
     if (p.stamps) { asm volatile("" :: "v"(bv[0][0].x), "v"(bv[1][3].w)); G8_STAMPW(2, cur.wg); }
-    float csum = 0.f;
+    [[maybe_unused]] float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int Mi = 0; Mi < 4; ++Mi) {
         [[maybe_unused]] const bool row_ok = (mw + Mi * 32 + r5) < p.M;
@@ -400,21 +400,49 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
                 if (ACT != 5 && (q & 1)) pin();
             }
             wfence();
-            if constexpr (CS) {     // column sums of the block as stored (rounded to TO)
+            if constexpr (CS) {
+                // column sums of the block AS STORED (rounded to TO), taken from the very vectors the global stores carry: this lane's
+                // four 16-byte pieces = rows (lane >> 3) + 8 i, columns 8 (lane & 7) .. + 7 of the block -- 8 partial column sums per
+                // lane over 16 rows of the wave's 128, folded over the 8 lanes that share a column group once per tile.  (The first
+                // form read the staged block back column by column: 32 two-byte LDS reads per pass and lane, a third of this
+                // epilogue's time.)
                 static_assert(!CS || ES == 2, "fused column sums: bf16 output only");
+                u32x4_t q[4];
 #pragma unroll
-                for (int r = 0; r < 32; ++r)
-                    csum += io<TO>::load1(reinterpret_cast<const TO*>(ws + r * 128 + (((lane >> 3) ^ (r & 7)) << 4)) + (lane & 7));
+                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const u32x4_t*>(ws + rs_off + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        cs8[2 * w] += bfbits2f(q[i][w] & 0xffffu);
+                        cs8[2 * w + 1] += bfbits2f(q[i][w] >> 16);
+                    }
+                if (!(p.debug & 1)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rC, lo[ps] + row_term(Mi, i), 0, 0);
+                }
+            } else {
+                rows_store(rC, Mi, lo[ps]);
             }
-            rows_store(rC, Mi, lo[ps]);
             wfence();
         }
         G8_STAMPW(3 + Mi, cur.wg);
     }
     G8_STAMPW(7, cur.wg);
     if constexpr (CS) {         // one partial row per 128-row wave block; the launcher folds them
-        const int n = nw + lane;
-        if (n < p.N) p.colsum[(size_t)(cur_tm * 2 + wr) * p.N + n] = csum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {      // fold over the 8 lanes (rows lane >> 3) that hold the same 8 columns
+            cs8[j] += __shfl_xor(cs8[j], 8, 64);
+            cs8[j] += __shfl_xor(cs8[j], 16, 64);
+            cs8[j] += __shfl_xor(cs8[j], 32, 64);
+        }
+        if (rs_row == 0) {
+            const int n = nw + rs_slot * 8;
+            float* dst = p.colsum + (size_t)(cur_tm * 2 + wr) * p.N + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n + j < p.N) dst[j] = cs8[j];
+        }
     }
 }
 

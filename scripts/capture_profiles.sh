@@ -1,13 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): kernel trace + PMC passes of the bench command and of four GEMM shapes; everything lands in
 # gpurun_out/ (copy what is to be judged into profiles/).   bash scripts/capture_profiles.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+# Single-stream runs for the per-kernel numbers (with the weight-gradient stream on, dW launches overlap the dX chain and the traced
+# durations of both stretch over each other); the default (overlapped) step is traced separately below.
+export MOREC_WGRAD_STREAM=0
 BENCH="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary"
 rm -rf /tmp/prof; mkdir -p /tmp/prof
 timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o kt -- $BENCH > $O/${TAG}_prof_bench_line.json 2> /dev/null
-python $R/scripts/prof_summary.py /tmp/prof/kt_results.db 6 "$TAG: rocprofv3 --kernel-trace --stats -- bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary (6 steps traced)" > $O/${TAG}_bench_kernel_stats.csv
+NS=$(python -c "import json,sys; print(json.loads([l for l in open('$O/${TAG}_prof_bench_line.json') if l.startswith('{')][-1])['steps_executed'])")
+python $R/scripts/prof_summary.py /tmp/prof/kt_results.db $NS "$TAG: MOREC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary ($NS steps traced: 2 warm-up + 4 timed + 5 of the instrumented pass; single stream)" > $O/${TAG}_bench_kernel_stats.csv
+rm -f /tmp/prof/ko_results.db
+MOREC_WGRAD_STREAM=1 timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ko -- $BENCH > /dev/null 2>&1
+python $R/scripts/prof_summary.py /tmp/prof/ko_results.db $NS "$TAG: default step (weight-gradient stream ON: kernels of the two streams overlap, their durations add up to more than the step)" > $O/${TAG}_bench_kernel_stats_overlap.csv
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o pf -- $BENCH > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof -o pw -- $BENCH > /dev/null 2>&1
 python $R/scripts/pmc_traffic.py /tmp/prof/pf_results.db /tmp/prof/pw_results.db $O/${TAG}_prof_bench_line.json $O/${TAG}_gemm_pmc.json
@@ -22,7 +29,8 @@ done
 # Swin-T step: kernel trace
 rm -f /tmp/prof/ks_results.db
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ks -- python $R/bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof_swin_line.json 2> /dev/null
-python $R/scripts/prof_summary.py /tmp/prof/ks_results.db 6 "$TAG swin_tiny B=64 (704 images/step): rocprofv3 --kernel-trace --stats -- bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 (6 steps traced)" > $O/${TAG}_swin_tiny_kernel_stats.csv
+NS2=$(python -c "import json,sys; print(json.loads([l for l in open('$O/${TAG}_prof_swin_line.json') if l.startswith('{')][-1])['steps_executed'])")
+python $R/scripts/prof_summary.py /tmp/prof/ks_results.db $NS2 "$TAG swin_tiny B=64 (704 images/step): MOREC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 ($NS2 steps traced)" > $O/${TAG}_swin_tiny_kernel_stats.csv
 # scoring kernels at the one-GPU and the 8-rank pooled column count: HBM bytes per launch
 {
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -5,7 +5,7 @@ FLOPs per step) so that bench.py can refuse the file when it does not describe t
 import json, re, sqlite3, sys
 fetch_db, write_db, bench_json, out = sys.argv[1:5]
 line = json.loads([l for l in open(bench_json).read().splitlines() if l.startswith("{")][-1])
-steps = line["steps"] + line["warmup"]
+steps = line.get("steps_executed") or (line["steps"] + line["warmup"])     # every step the profiled process ran (warm-up, timed, instrumented pass)
 
 def per_kernel(dbp, counter):
     db = sqlite3.connect(dbp)
