@@ -299,6 +299,28 @@ def main():
     dt = float(t.item())
     loss_v = float(loss.item())
     log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step")
+    # ---- N > 1: one traced step -- when each gradient bucket's all-reduce is issued (stream time from the start of the step) and how
+    # long the closing join waits, so that a scaling run explains itself
+    reduce_trace = None
+    if world > 1:
+        try:
+            ts.trace = []
+            e_start = torch.cuda.Event(enable_timing=True)
+            e_start.record()
+            run_step(a.warmup)
+            e_end = torch.cuda.Event(enable_timing=True)
+            e_end.record()
+            torch.cuda.synchronize()
+            ev_list, ts.trace = ts.trace, None
+            reduce_trace = {"step_ms": round(e_start.elapsed_time(e_end), 3), "buckets": []}
+            for rec in ev_list:
+                if rec[0] == "issue":
+                    _, gi, lo, hi, ev = rec
+                    reduce_trace["buckets"].append({"group": gi, "MB": round((hi - lo) * 4 / 1e6, 1), "issued_at_ms": round(e_start.elapsed_time(ev), 3)})
+                else:
+                    reduce_trace[rec[0] + "_ms"] = round(e_start.elapsed_time(rec[1]), 3)
+        except Exception as e:  # noqa: BLE001
+            reduce_trace = {"error": f"{type(e).__name__}: {e}"}
     # ---- instrumented pass over the same batches (after the headline; never part of `value`): HIP events around every GEMM /
     # scoring call on the launch stream -> roofline.achieved
     # The weight-gradient stream is switched OFF for this pass: with it on, dW launches overlap the dX chain and the event-timed
@@ -497,6 +519,10 @@ def main():
            "final_loss": round(loss_v, 4), "roofline": roof, "steps_executed": n_run["v"]}
     if sustained is not None:
         out["sustained"] = sustained
+    if reduce_trace is not None:
+        out["gradient_reduce_trace"] = reduce_trace
+    if world > 1:
+        out["config"]["gemm8p_reserve_cus"] = int(os.environ.get("MOREC_GEMM8P_RESERVE_CUS", "16"))
     if id_tower:
         out["metric"] = "user-sequences/sec end-to-end train step, IDRec SASRec (embedding table)"
         out["config"]["workload"] = (f"SASRec(2 blocks, 2 heads, D=512) + ID embedding table ({a.item_num} items, dense AdamW over the table), "

@@ -539,7 +539,9 @@ static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
 }
 
 int g_reserve_cus = 0;      // tuning key "gemm8p_reserve_cus"
-int g_ngroup = 0;           // tuning key "gemm8p_ngroup": 0 = row-major tile order, -1 = automatic column groups, n = groups of n N-tiles
+// tuning key "gemm8p_ngroup": 0 = row-major tile order, -1 = automatic column groups (default: FETCH_SIZE per launch -20 % on the QKV
+// projection, -24 % on FFN-up + GELU, -23 % on its backward at equal launch times; profiles/r03_gemm8p_tile_order_pmc.txt), n = groups of n N-tiles
+int g_ngroup = -1;
 
 template <typename TO, int ACT, bool CS>
 int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {

@@ -204,6 +204,7 @@ class TrainStep:
         self.buckets = self._bucket_plan()
         self._pending, self._reduced, self._stepped = [], [], []
         self._fused_update = False
+        self.trace = None           # list -> _reduce_slice / reduce_gradients record stream-time events of the gradient collectives
 
     def _bucket_plan(self):
         """Contiguous slices of the tower arena whose gradients become final together: ``("layer", l)`` for the text
@@ -426,6 +427,10 @@ class TrainStep:
 
     def _reduce_slice(self, gi, lo, hi):
         t = self.groups[gi]["arena"].grad[lo:hi]
+        if self.trace is not None:      # diagnostics (bench.py, N > 1): when, in stream time, each bucket's collective is issued
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self.trace.append(("issue", gi, lo, hi, ev))
         if self.comm_grad is not None:     # own RCCL communicator on a side stream, behind the kernels already queued on this one
             self._grad_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._grad_stream):
@@ -501,12 +506,20 @@ class TrainStep:
                     if lo > pos:
                         self._reduce_slice(gi, pos, lo)
                     pos = hi
+            if self.trace is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                self.trace.append(("join_begin", ev))
             for w in self._pending:
                 if w is not None:
                     w.wait()
             if self._grad_stream is not None:
                 torch.cuda.current_stream().wait_stream(self._grad_stream)
             self._pending = []
+            if self.trace is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                self.trace.append(("join_end", ev))
             if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
                 for grp in self.groups:
                     grp["arena"].grad.mul_(1.0 / self.world)

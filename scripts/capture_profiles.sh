@@ -31,12 +31,19 @@ rm -f /tmp/prof/ks_results.db
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ks -- python $R/bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof_swin_line.json 2> /dev/null
 NS2=$(python -c "import json,sys; print(json.loads([l for l in open('$O/${TAG}_prof_swin_line.json') if l.startswith('{')][-1])['steps_executed'])")
 python $R/scripts/prof_summary.py /tmp/prof/ks_results.db $NS2 "$TAG swin_tiny B=64 (704 images/step): MOREC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 ($NS2 steps traced)" > $O/${TAG}_swin_tiny_kernel_stats.csv
-# scoring kernels at the one-GPU and the 8-rank pooled column count: HBM bytes per launch
+# scoring kernels at the 8-rank pooled column count (Nr = 2560 rows x Nc = 21 504 columns, D = 512): HBM-side bytes per launch, then
+# the kernel trace of the same command
 {
 for c in FETCH_SIZE WRITE_SIZE; do
-  echo "# rocprofv3 --kernel-trace --pmc $c -- python scripts/ce_pooled_bench.py   (per-dispatch sums; FETCH_SIZE / WRITE_SIZE in KiB units as the guide's HBM section prescribes)"
+  echo "# rocprofv3 --kernel-trace --pmc $c -- python scripts/ce_pooled_bench.py 20 0 512 8   (per-dispatch averages, KiB; FETCH_SIZE to be doubled on gfx950: MI355X_MICROARCH.md, HBM section)"
   rm -f /tmp/prof/ce_results.db
-  timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof -o ce -- python $R/scripts/ce_pooled_bench.py > $O/${TAG}_ce_pooled_bench.txt 2>&1
-  python $R/scripts/pmc_summary.py /tmp/prof/ce_results.db "%ce_%"
+  timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/prof -o ce -- python $R/scripts/ce_pooled_bench.py 20 0 512 8 > /dev/null 2>&1
+  python $R/scripts/pmc_summary.py /tmp/prof/ce_results.db "%"  | grep -v "at::native"
 done
+echo "# algorithmic bytes at this size: forward (Nr + Nc) D 2 + 13 Nc + 8 Nr = 24.9 MB; backward 2 (Nr + Nc) D 2 + 4 Nr + Nr D 2 + Nc D 4 = 95.9 MB (dE handed out in fp32)"
+rm -f /tmp/prof/cek_results.db
+timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof -o cek -- python $R/scripts/ce_pooled_bench.py 20 0 512 8 > $O/${TAG}_ce_pooled_bench.txt 2>&1
+python $R/scripts/prof_summary.py /tmp/prof/cek_results.db 1 "$TAG scoring at the 8-rank pooled size: rocprofv3 --kernel-trace --stats -- python scripts/ce_pooled_bench.py 20 0 512 8 (2 + 21 forward calls, 1 + 20 backward calls)"
+python $R/scripts/ce_pooled_bench.py 20 0 512
+python $R/scripts/ce_pooled_bench.py 20 1 512 8
 } > $O/${TAG}_scoring_pmc.txt 2>&1

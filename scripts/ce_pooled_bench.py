@@ -11,8 +11,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 MODE = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # tuning key "ce8p": 0 automatic, 1 the 128 x 128 kernels, 2 the 256 x 256 eight-phase kernels
 _lib.lib().morec_tuning_set(b"ce8p", MODE)
 B, S, D = 128, 20, int(sys.argv[3]) if len(sys.argv) > 3 else 512
+RANKS = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 2, 4, 8]      # pooled sizes to run (a counter pass wants ONE)
 print(f"# ce8p mode {MODE}, D = {D}")
-for ranks, rank in ((1, 0), (2, 1), (4, 1), (8, 3)):
+for ranks, rank in [(r, min(3, r - 1)) for r in RANKS]:
     Nr, Nc = B * S, ranks * B * (S + 1)
     g = torch.Generator(device=dev).manual_seed(ranks)
     P = (torch.randn(Nr, D, device=dev, generator=g) * 0.3).to(dt); E = (torch.randn(Nc, D, device=dev, generator=g) * 0.3).to(dt)
