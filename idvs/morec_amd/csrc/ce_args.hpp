@@ -21,7 +21,7 @@ struct Ce8Args {
 };
 
 struct Ce8Layout {           // byte offsets into the caller's workspace
-    size_t off_tab, off_lpp, off_pmax, off_psum, off_pos, fwd_bytes;
+    size_t off_tab, off_lpp, off_pmax, off_psum, off_pos, off_part, fwd_bytes;
     size_t off_dlt, off_pt, off_dp32, off_de32, off_slabs, bwd_bytes;
     int tiles_m, tiles_n, Ncp, K2, ldr, tn_split;
 };
@@ -31,7 +31,7 @@ extern int g_ce8p_mode;
 bool ce8p_eligible(const morec_ce_desc* d);
 void ce8p_layout(const morec_ce_desc* d, Ce8Layout& L);
 int ce8p_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
-             const uint8_t* col_valid, const uint8_t* row_valid, void* workspace, float** pmax, float** psum, float** pos, int* K2, hipStream_t s);
+             const uint8_t* col_valid, const uint8_t* row_valid, void* workspace, float** pmax, float** psum, float** pos, float** part, int* K2, hipStream_t s);
 int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
              const uint8_t* col_valid, const uint8_t* row_valid, const float* row_lse, const float* gscale_dev, float gscale, void* dP, void* dE,
              void* workspace, hipStream_t s);

@@ -150,21 +150,19 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(CeArgs p) {
     }
 }
 
-// one wave per FOUR rows: merge the K2 partials -> lse, loss; block-sum the valid rows' losses into loss_sum (one atomic per 16 rows:
-// with one per 4 rows the 640 same-address atomics of the B = 128 step were most of this kernel's 12 us)
-constexpr int CE_ROWS_PER_WAVE = 4;
+// one wave per row: merge the K2 partials -> lse, loss; the valid rows' losses of a block (4 rows) go to block_part[block], and
+// ce_loss_total adds them up IN A FIXED ORDER (the first version did one fp32 atomicAdd per block into loss_sum: 640 same-address
+// atomics at B = 128 -- most of the kernel's time -- and a total that changed in the last bit from run to run)
 __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                          const float* __restrict__ pos,
                                                          const uint8_t* __restrict__ row_valid,
                                                          float* __restrict__ row_lse, float* __restrict__ row_loss,
-                                                         float* __restrict__ loss_sum, int Nr, int K2, int log2_domain) {
+                                                         float* __restrict__ block_part, int Nr, int K2, int log2_domain) {
     __shared__ float s_part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float loss_w = 0.f;
-#pragma unroll
-    for (int i = 0; i < CE_ROWS_PER_WAVE; ++i) {
-        const int row = (blockIdx.x * 4 + wave) * CE_ROWS_PER_WAVE + i;
-        if (row >= Nr) break;
+    const int row = blockIdx.x * 4 + wave;
+    float loss = 0.f;
+    if (row < Nr) {
         float mx = -INFINITY;
         for (int k = lane; k < K2; k += 64) mx = fmaxf(mx, pmax[(size_t)row * K2 + k]);
         mx = wave_max(mx);
@@ -176,16 +174,28 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict
         sm = wave_sum(sm);
         // log2_domain (the eight-phase scoring kernels): maxima and sums of 2^(x log2 e) -> lse = ln 2 (max2 + log2 sum)
         const float lse = log2_domain ? 0.6931471805599453f * (mx + log2f(sm)) : mx + logf(sm);
-        const float loss = row_valid[row] ? (lse - pos[row]) : 0.f;
+        loss = row_valid[row] ? (lse - pos[row]) : 0.f;
         if (lane == 0) {
             row_lse[row] = lse;
             row_loss[row] = loss;
         }
-        loss_w += loss;
     }
-    if (lane == 0) s_part[wave] = loss_w;
+    if (lane == 0) s_part[wave] = loss;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_sum, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    if (threadIdx.x == 0) block_part[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+// loss_sum += sum of the block partials: one block, fixed summation tree -> bit-identical totals from run to run
+__global__ __launch_bounds__(256) void ce_loss_total_kernel(const float* __restrict__ block_part, int n, float* __restrict__ loss_sum) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += block_part[i];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_sum += s[0];
 }
 
 // backward, stage 1: recompute the logit tile and emit dlogits = g * (softmax - onehot) for the unmasked
@@ -250,7 +260,7 @@ extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
     if (!d) return 0;
     const size_t Nr = (size_t)d->B * d->S, Nc = d->Nc, D = d->D;
     const size_t K2 = 2 * ((Nc + 127) / 128);
-    const size_t fwd = (2 * Nr * K2 + Nr) * sizeof(float);
+    const size_t fwd = (2 * Nr * K2 + Nr + (Nr + 3) / 4 + 4) * sizeof(float);       // pmax | psum | pos | per-block loss partials
     const size_t es = elt_size(d->dtype);
     const size_t ldc = pad8((int)Nc), ldr = pad8((int)Nr);
     size_t bwd = (Nr * ldc + Nc * ldr + D * ldr + D * ldc) * es + 256;
@@ -297,9 +307,10 @@ extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.tiles_m * a.tiles_n);
     int log2_domain = 0;
+    float* part8 = nullptr;
     if (ce8p_eligible(d)) {      // 256 x 256 tiles on the eight-phase main loop; same partial format (one entry per 64-column slice)
         if (!aligned16(col_ids) || !aligned16(col_logpop) || (reinterpret_cast<uintptr_t>(col_valid) & 3u)) return MOREC_E_ALIGN;
-        rc = ce8p_fwd(d, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, workspace, &a.pmax, &a.psum, &a.pos, &a.K2, s);
+        rc = ce8p_fwd(d, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, workspace, &a.pmax, &a.psum, &a.pos, &part8, &a.K2, s);
         if (rc) return rc;
         log2_domain = 1;
     } else if (d->dtype == MOREC_F32) {
@@ -314,8 +325,12 @@ extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const
         hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
     }
     MOREC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_combine_kernel, dim3((a.Nr + 4 * CE_ROWS_PER_WAVE - 1) / (4 * CE_ROWS_PER_WAVE)), dim3(256), 0, s, a.pmax, a.psum, a.pos, row_valid,
-                       row_lse, row_loss, loss_sum, a.Nr, a.K2, log2_domain);
+    const int n_blocks = (a.Nr + 3) / 4;
+    float* block_part = part8 ? part8 : a.pos + a.Nr;
+    hipLaunchKernelGGL(ce_combine_kernel, dim3(n_blocks), dim3(256), 0, s, a.pmax, a.psum, a.pos, row_valid, row_lse, row_loss, block_part,
+                       a.Nr, a.K2, log2_domain);
+    MOREC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_loss_total_kernel, dim3(1), dim3(256), 0, s, block_part, n_blocks, loss_sum);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

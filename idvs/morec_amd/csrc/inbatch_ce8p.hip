@@ -316,6 +316,7 @@ void ce8p_layout(const morec_ce_desc* d, Ce8Layout& L) {
     L.off_pos = o; o += up(Nr * 4);
     L.off_pmax = o; o += up(Nr * L.K2 * 4);
     L.off_psum = o; o += up(Nr * L.K2 * 4);
+    L.off_part = o; o += up(((Nr + 3) / 4) * 4);
     L.fwd_bytes = o;
     o = L.off_pmax;                                            // backward reuses the space behind the tables
     L.off_dlt = o; o += up(Nc * L.ldr * 2);
@@ -369,7 +370,7 @@ static int ce8p_launch(const Ce8Args& a, hipStream_t s) {
 // forward: per-(row, 64-column) softmax partials (BASE-2 domain) + the positive logit (natural) into the workspace; the caller runs
 // ce_combine over the K2 partials with log2_domain = 1
 int ce8p_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
-             const uint8_t* col_valid, const uint8_t* row_valid, void* workspace, float** pmax, float** psum, float** pos, int* K2, hipStream_t s) {
+             const uint8_t* col_valid, const uint8_t* row_valid, void* workspace, float** pmax, float** psum, float** pos, float** part, int* K2, hipStream_t s) {
     Ce8Layout L;
     ce8p_layout(d, L);
     char* ws = reinterpret_cast<char*>(workspace);
@@ -379,6 +380,7 @@ int ce8p_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t
     ce8p_fill(d, L, ws, P, E, row_valid, a);
     a.pmax = reinterpret_cast<float*>(ws + L.off_pmax); a.psum = reinterpret_cast<float*>(ws + L.off_psum);
     *pmax = a.pmax; *psum = a.psum; *pos = a.pos; *K2 = L.K2;
+    *part = reinterpret_cast<float*>(ws + L.off_part);
     return ce8p_launch<false>(a, s);
 }
 
