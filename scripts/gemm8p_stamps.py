@@ -39,6 +39,11 @@ for name, N, K, kind in [("qkv", 2304, 768, "bias"), ("fc1+gelu", 3072, 768, "ge
     print(f"{name} tiles {tiles}: kernel span {(s[:, 7].max() - t0)} ticks; per-tile total mean {(s[:, 7] - s[:, 0]).mean():.0f}")
     print("   mean  : " + "  ".join(f"{n} {v:8.0f}" for n, v in zip(names, d.mean(0))))
     print("   median: " + "  ".join(f"{n} {v:8.0f}" for n, v in zip(names, np.median(d, 0))))
+    # inside the main loop (stamps 8..15 of wave 0): wait for the prologue's first pieces | barriers (+ the wave rows' offset) | first
+    # K-tile | second | steady K-tiles | last two | trailing barrier; and from the tile's first stamp to the loop's first
+    dm = np.diff(s[:, 8:16], axis=1).astype(np.float64)
+    mn = ["wait_prologue", "barrier", "ktile0", "ktile1", "steady", "last2", "trail"]
+    print("   mainloop mean: " + "  ".join(f"{n} {v:7.0f}" for n, v in zip(mn, dm.mean(0))) + f"  | tile start -> loop start {np.mean(s[:, 8] - s[:, 0]):7.0f}  loop end -> epilogue stamp {np.mean(s[:, 1] - s[:, 15]):7.0f}")
     # start-time distribution: how synchronised are the rounds
     starts = np.sort(s[:, 0] - t0)
     print("   start ticks at tile index 0,255,256,511,512,767: " + ", ".join(str(int(starts[i])) for i in (0, 255, 256, 511, 512, 767) if i < tiles))
