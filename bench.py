@@ -609,7 +609,8 @@ def scoring_pooled(ops, B, S, D, dev, peak, ranks=8, rank=3, iters=20):
     ws = ops.ce_workspace(desc, dev)
     fwd = lambda: ops.inbatch_ce_fwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, ws)      # noqa: E731
     _, lse, _ = fwd()
-    bwd = lambda: ops.inbatch_ce_bwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, lse, None, 1.0 / Nr, ws)   # noqa: E731
+    bdesc = ops.ce_desc(B, S, D, Nc, rank * B * (S + 1), dt, dE_fp32=True, ws_from_fwd=True)      # as engine.ce_backward calls it: the forward's tables reused
+    bwd = lambda: ops.inbatch_ce_bwd(bdesc, P, E, row_ids, ids, logpop, col_valid, row_valid, lse, None, 1.0 / Nr, ws)   # noqa: E731
     bwd()
     torch.cuda.synchronize()
     res = {}

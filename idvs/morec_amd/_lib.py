@@ -45,7 +45,7 @@ class TransposeItem(C.Structure):      # morec_transpose_item
 
 class CeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("D", C.c_int), ("Nc", C.c_int), ("col_offset", C.c_int),
-                ("dtype", C.c_int), ("dE_fp32", C.c_int)]
+                ("dtype", C.c_int), ("dE_fp32", C.c_int), ("ws_from_fwd", C.c_int)]
 
 
 class SwinAttnDesc(C.Structure):

@@ -9,7 +9,7 @@ struct Ce8Args {
     const uint8_t* tab;      // [B][Ncp] cell flags in lane order (inbatch_ce8p.hip: ce8p_prep_kernel)
     const float* lpp;        // [Ncp] log-popularity in lane order
     const uint8_t* row_valid;
-    float* pmax;             // fwd: [Nr][K2] partial maxima over 64-column slices
+    float* pmax;             // fwd: [Nr][K2] partial maxima (base-2 domain), one per 256-column tile
     float* psum;             // fwd: [Nr][K2] partial sum-exp
     float* pos;              // fwd: [Nr] positive logit
     const float* row_lse;    // bwd

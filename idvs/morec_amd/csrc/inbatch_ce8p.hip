@@ -182,7 +182,9 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
         issue_prologue(cn, smem, nk);
     }
     if constexpr (!BWD) {
-        const int kcol = (cur.n0 >> 6) + wc;                   // which 64-column slice of the pool
+        // per (row, 64-column chunk of this wave) maximum and sum; the four chunks of a row (the four wave columns) are merged through
+        // LDS so that ONE partial per (row, 256-column tile) leaves the workgroup: K2 = tiles_n entries per row for ce_combine
+        float2* red = reinterpret_cast<float2*>(smem + LDS_BYTES);        // [4 wave columns][256 rows] (the epilogue slices' space)
 #pragma unroll
         for (int Mi = 0; Mi < 4; ++Mi) {
             float x[32];
@@ -196,13 +198,24 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
 #pragma unroll
             for (int k = 0; k < 32; ++k) sm += __builtin_amdgcn_exp2f(x[k] - base);
             sm += __shfl_xor(sm, 32, 64);
-            const int m = mrow[Mi];
-            if (m < p.Nr && h == 0) {
+            if (h == 0) red[wc * 256 + wr * 128 + Mi * 32 + r5] = make_float2(mx, sm);
+            pin();
+        }
+        bar();      // all eight waves (they are aligned here: mainloop8p ends with the wave rows re-joined)
+        if (tid_e < 256) {
+            const int m = cur.m0 + tid_e;
+            const float2 p0 = red[tid_e], p1 = red[256 + tid_e], p2 = red[512 + tid_e], p3 = red[768 + tid_e];
+            const float mx = fmaxf(fmaxf(p0.x, p1.x), fmaxf(p2.x, p3.x));
+            const float base = mx > -INFINITY ? mx : 0.f;
+            const float sm = p0.y * __builtin_amdgcn_exp2f(p0.x - base) + p1.y * __builtin_amdgcn_exp2f(p1.x - base) +
+                             p2.y * __builtin_amdgcn_exp2f(p2.x - base) + p3.y * __builtin_amdgcn_exp2f(p3.x - base);
+            if (m < p.Nr) {
+                const int kcol = cur.n0 >> 8;
                 p.pmax[(size_t)m * p.K2 + kcol] = mx;
                 p.psum[(size_t)m * p.K2 + kcol] = sm;
             }
-            pin();
         }
+        // (the next write to `red` is a whole main loop -- dozens of barriers -- away: no second barrier)
     } else {
         // dlogit = g (softmax - onehot) on the cells of valid rows that were not overwritten, 0 elsewhere (model.py:65-67 backward;
         // an overwritten cell receives no gradient: index_put semantics), written TRANSPOSED: dlt[c][m].  Each 32-row block goes
@@ -307,7 +320,7 @@ void ce8p_layout(const morec_ce_desc* d, Ce8Layout& L) {
     L.tiles_m = (int)((Nr + 255) / 256);
     L.tiles_n = (int)((Nc + 255) / 256);
     L.Ncp = L.tiles_n * 256;
-    L.K2 = L.tiles_n * 4;
+    L.K2 = L.tiles_n;
     L.ldr = (int)((Nr + 63) & ~(size_t)63);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
@@ -391,7 +404,7 @@ int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t
     ce8p_layout(d, L);
     char* ws = reinterpret_cast<char*>(workspace);
     const int Nr = d->B * d->S, Nc = d->Nc, D = d->D;
-    int rc = ce8p_prep(d, L, ws, P, E, row_ids, col_ids, col_logpop, col_valid, s);
+    int rc = d->ws_from_fwd ? MOREC_OK : ce8p_prep(d, L, ws, P, E, row_ids, col_ids, col_logpop, col_valid, s);   // tables + positive logits: the forward's, or rebuilt
     if (rc) return rc;
     Ce8Args a{};
     ce8p_fill(d, L, ws, P, E, row_valid, a);

@@ -553,5 +553,7 @@ def ce_forward(ci: CeInputs, P: torch.Tensor, E: torch.Tensor, dE_fp32: bool = F
 
 def ce_backward(ci: CeInputs, P, E, saved, gscale_dev, gscale: float):
     desc, ws, lse = saved
-    return ops.inbatch_ce_bwd(desc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, lse,
+    # `ws` is the forward call's workspace, kept alive and untouched inside `saved`: the backward reuses the tables it holds
+    bdesc = ops.CeDesc(desc.B, desc.S, desc.D, desc.Nc, desc.col_offset, desc.dtype, desc.dE_fp32, 1)
+    return ops.inbatch_ce_bwd(bdesc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, lse,
                               gscale_dev, gscale, ws)

@@ -271,8 +271,9 @@ def strided_rows_copy(src, out, R, D, in_stride, out_stride):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def ce_desc(B, S, D, Nc, col_offset, dtype, dE_fp32=False):
-    return CeDesc(B, S, D, Nc, col_offset, code(dtype), int(bool(dE_fp32)))
+def ce_desc(B, S, D, Nc, col_offset, dtype, dE_fp32=False, ws_from_fwd=False):
+    """``ws_from_fwd`` (backward): the workspace is the untouched one of the matching forward call -- its tables are reused."""
+    return CeDesc(B, S, D, Nc, col_offset, code(dtype), int(bool(dE_fp32)), int(bool(ws_from_fwd)))
 
 
 def ce_workspace(desc, device):

@@ -289,7 +289,7 @@ int morec_strided_rows_copy(const void* in, void* out, int R, int D, int in_row_
  *   row_valid uint8 [Nr]       log_mask != 0
  *   col_offset                 column of this rank's slot 0 in the pool
  * fwd: per-(row, 64-column slice) partial (max, sumexp) + positive logit -> row_lse[Nr], row_loss[Nr]
- *      and loss_sum (fp32 scalar accumulated atomically; caller zeroes it).
+ *      and loss_sum (fp32 scalar, += the sum of the valid rows' losses, added in a fixed order: bit-reproducible; caller zeroes it).
  * bwd: dP[Nr, D] and dE[Nc, D] (dtype, overwritten):
  *      dlogit = gscale * (*gscale_dev if given) * (softmax - onehot) on unmasked cells of valid rows,
  *      0 elsewhere; dP = dlogit . E, dE = dlogit^T . P.
@@ -302,6 +302,10 @@ typedef struct {
     int dtype;
     int dE_fp32;   /* backward only: dE is written as fp32 [Nc, D] whatever the compute dtype (the pooled-negative step reduce-scatters it
                     * over ranks in fp32); bf16 compute with Nc % 8 == 0 only, MOREC_E_UNSUPPORTED otherwise */
+    int ws_from_fwd; /* backward only: 1 = `workspace` is the buffer the matching morec_inbatch_ce_fwd call (same descriptor fields, same
+                      * P / E / ids / log-pop / validity) was given and nothing has written to it since: the backward then reuses the
+                      * (user, column) flag table and the positive logits the forward left there instead of rebuilding them (the
+                      * 256 x 256 kernels; ignored by the 128 x 128 ones).  0 = the workspace is plain scratch. */
 } morec_ce_desc;
 
 size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d);

@@ -25,7 +25,8 @@ for ranks, rank in [(r, min(3, r - 1)) for r in RANKS]:
     ws = ops.ce_workspace(desc, dev)
     def fwd(): return ops.inbatch_ce_fwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, ws)
     loss_sum, lse, _ = fwd()
-    def bwd(): return ops.inbatch_ce_bwd(desc, P, E, row_ids, ids, logpop, col_valid, row_valid, lse, None, 1.0 / Nr, ws)
+    bdesc = ops.ce_desc(B, S, D, Nc, rank * B * (S + 1), dt, dE_fp32=(ranks > 1), ws_from_fwd=True)     # as engine.ce_backward: the forward's tables reused
+    def bwd(): return ops.inbatch_ce_bwd(bdesc, P, E, row_ids, ids, logpop, col_valid, row_valid, lse, None, 1.0 / Nr, ws)
     bwd(); torch.cuda.synchronize()
     res = {}
     for name, fn in (("fwd", fwd), ("bwd", bwd)):

@@ -33,7 +33,13 @@ def _inputs(B, S, D, item_num, n_ranks, rank, seed=None):
 def _run(desc, P, E, args, n_valid, dE_fp32=False):
     ws = ops.ce_workspace(desc, DEV)
     loss_sum, lse, row_loss = ops.inbatch_ce_fwd(desc, P, E, *args, ws)
+    # backward on the forward's untouched workspace (ws_from_fwd: the flag table / positive logits are reused) ...
+    reuse = ops.CeDesc(desc.B, desc.S, desc.D, desc.Nc, desc.col_offset, desc.dtype, desc.dE_fp32, 1)
+    dP_r, dE_r = ops.inbatch_ce_bwd(reuse, P, E, *args, lse, None, 1.0 / n_valid, ws)
+    # ... and on a workspace that is plain scratch (everything rebuilt): the same numbers, bit for bit
+    ws.fill_(0xA5)
     dP, dE = ops.inbatch_ce_bwd(desc, P, E, *args, lse, None, 1.0 / n_valid, ws)
+    assert torch.equal(dP, dP_r) and torch.equal(dE, dE_r)
     return loss_sum.item() / n_valid, lse, row_loss, dP, dE
 
 
