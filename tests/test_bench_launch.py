@@ -29,3 +29,26 @@ def test_world_size_mismatch_fails_loudly():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
+    """The N > 1 code path of bench.py end to end on one MI355X: two gloo ranks sharing cuda:0 (RCCL refuses two ranks on one device),
+    pooled negatives, bucketed gradient reduction from the backward callbacks.  The line must say what ran (2 ranks, weak scaling,
+    whole-job throughput) and carry the per-bucket issue / join trace a scaling run is read with."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-device", "--backend", "gloo", "--bert", "tiny", "--batch", "16", "--steps", "3",
+                        "--warmup", "2", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=500, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and "pooled-negatives" in out["config"]["parallelism"]
+    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
+    tr = out["gradient_reduce_trace"]
+    assert "error" not in tr and len(tr["buckets"]) >= 3            # recommender group, encoder layers, closing sweep
+    issued = [b["issued_at_ms"] for b in tr["buckets"]]
+    assert issued == sorted(issued) and tr["join_begin_ms"] >= issued[-1] and tr["join_end_ms"] >= tr["join_begin_ms"]
+    assert out["config"]["gemm8p_reserve_cus"] == 16
