@@ -369,6 +369,31 @@ def token_packing(mask: torch.Tensor):
     return cu, tok_idx
 
 
+def token_packing_host(mask):
+    """The same bookkeeping on the HOST (numpy / CPU tensor ``mask`` int [Nc, T], what the data loader's collate holds before the H2D
+    copy, ``T/run.py:232-239``): returns pinned int32 CPU tensors ``(cu_seqlens [Nc + 1], tok_idx [n_tokens])`` or ``None`` when the
+    rows are not a run of ones followed by zeros (the padded layout is kept then).  Uploading the two vectors with the batch spares
+    the step its only two host synchronisations (the ``all()`` / ``nonzero()`` of the device-side version), i.e. ~0.25 ms of idle GPU
+    at every step boundary."""
+    import numpy as np
+    m = mask.numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+    m = (m != 0)
+    Nc, T = m.shape
+    if T > 1 and bool((m[:, :-1] < m[:, 1:]).any()):
+        return None
+    lens = np.maximum(m.sum(1), 1).astype(np.int64)
+    cu = np.zeros(Nc + 1, dtype=np.int32)
+    cu[1:] = np.cumsum(lens)
+    n = int(cu[-1])
+    # packed row r of sequence s, position t -> padded row s * T + t
+    seq = np.repeat(np.arange(Nc, dtype=np.int64), lens)
+    pos = np.arange(n, dtype=np.int64) - np.repeat(cu[:-1].astype(np.int64), lens)
+    tok = (seq * T + pos).astype(np.int32)
+    pin = torch.cuda.is_available()
+    cu_t, tok_t = torch.from_numpy(cu), torch.from_numpy(tok)
+    return (cu_t.pin_memory(), tok_t.pin_memory()) if pin else (cu_t, tok_t)
+
+
 def bert_grad_from(trainable_names, n_layers: int, prefix: str = TE) -> int:
     """Lowest point of the text tower that has a trainable parameter (the reference freezes ``bert_model`` parameters by
     index, ``T/run.py:73-75``; its default ``--freeze_paras_before 165`` = embeddings + layers 0-9, and autograd then never
@@ -401,7 +426,7 @@ def bert_needs_grad_buffer(name: str, grad_from: int, prefix: str = TE) -> bool:
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
                  mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None,
-                 grad_from: int = -1):
+                 grad_from: int = -1, packing=None):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
 
     ``unpad``: run the encoder layers on the REAL tokens only (packed rows + ``cu_seqlens``) instead of all T positions of
@@ -424,7 +449,16 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
                                                 eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
-    if (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
+    if packing is not None and (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
+        # ``packing``: (cu_seqlens, tok_idx) int32 DEVICE tensors prepared on the host with the batch (``token_packing_host``): no
+        # device-side bookkeeping, no host synchronisation in the step
+        cu, tok_idx = packing
+        if tok_idx.numel() == Nc * T:
+            cu, tok_idx = None, None
+        else:
+            x = ops.indexed_rows_copy(x, torch.empty((tok_idx.numel(), H), device=x.device, dtype=dtype), in_idx=tok_idx)
+            keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
+    elif (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
         mask = text[:, T:]
         run_of_ones = bool((mask[:, :-1] >= mask[:, 1:]).all()) if T > 1 else True   # ones, then zeros (joins the sync below)
         cu, tok_idx = token_packing(mask) if run_of_ones else (None, torch.empty(Nc * T, dtype=torch.int32))

@@ -29,6 +29,7 @@ from .model import BceModel, BertShape, HipBertModel, Model
 from .model.swin import HipSwinForImageClassification
 from .swin_engine import SwinShape
 from .parameters import parse_args
+from . import engine
 from .train_step import TrainStep
 
 Log = logging.getLogger("morec")
@@ -263,13 +264,17 @@ def train(args, use_modal, local_rank):
                     break
                 continue
             ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
+            pack = None
+            if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
+                hp = engine.token_packing_host(items.view(-1, items.size(-1))[:, T:])
+                pack = None if hp is None else (hp[0].to(local_rank, non_blocking=True), hp[1].to(local_rank, non_blocking=True))
             ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
             if vision:
                 items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)
             else:
                 items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
             if args.fused_step:
-                loss = stepper.global_loss(stepper.step(ids.view(-1), items, log_mask))    # pooled negatives: a rank's step returns its SHARE
+                loss = stepper.global_loss(stepper.step(ids.view(-1), items, log_mask, token_packing=pack))    # pooled negatives: a rank's step returns its SHARE
             else:
                 optimizer.zero_grad()
                 loss = wrapped(ids.view(-1), items, log_mask, local_rank)

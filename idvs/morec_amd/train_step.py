@@ -331,7 +331,7 @@ class TrainStep:
             self._wt_batch = ops.TransposeBatch(pairs)
 
     # -----------------------------------------------------------------------------------------------
-    def forward_backward(self, sample_items_id, sample_items, log_mask):
+    def forward_backward(self, sample_items_id, sample_items, log_mask, token_packing=None):
         """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync).  Under data
         parallelism the bucketed gradient reduction is STARTED here (async collectives issued from the backward pass);
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
@@ -373,7 +373,8 @@ class TrainStep:
                                  f"2 x {m.args.num_words_title}")
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
             E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
-                                             self.bert_mask_value, engine.TE, d_item, grad_from=self.bert_grad_from)
+                                             self.bert_mask_value, engine.TE, d_item, grad_from=self.bert_grad_from,
+                                             packing=None if dedup else token_packing)
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
             E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
@@ -621,12 +622,14 @@ class TrainStep:
                 pos = hi
         self._stepped = []
 
-    def step(self, sample_items_id, sample_items, log_mask):
+    def step(self, sample_items_id, sample_items, log_mask, token_packing=None):
         """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling).  Returns the loss
-        of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``."""
+        of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``.
+        ``token_packing`` (text tower, optional): the device copies of ``engine.token_packing_host(attention mask)`` uploaded with
+        the batch; without it the same index vectors are derived on the device, which costs the step two host synchronisations."""
         self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
         try:
-            loss = self.forward_backward(sample_items_id, sample_items, log_mask)
+            loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
         finally:
             self._fused_update = False
         self.reduce_gradients()

@@ -83,3 +83,26 @@ def test_pretrained_bert_key_normalisation_and_checkpoint_dir():
     assert run.model_dir_of(a, 8) == "./checkpoint_modal_bert_base_uncased_freeze_165/cpt_bert_base_uncased_ed_512_bs_1024_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
     a.item_tower = "id"
     assert run.model_dir_of(a, 1) == "./checkpoint_id/cpt_id_ed_512_bs_128_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
+
+
+def test_token_packing_host_equals_device_bookkeeping():
+    """The collate-side (numpy) unpadded-layout bookkeeping = the device-side one (`engine.token_packing`): same row offsets and packed-row
+    indices for ragged titles, the all-[PAD] padding item (keeps its first position) and full-length rows; a mask with holes is refused."""
+    import numpy as np
+    import torch
+
+    from idvs.morec_amd import engine
+    rng = np.random.default_rng(3)
+    Nc, T = 57, 30
+    lens = rng.integers(0, T + 1, Nc)
+    lens[0], lens[5], lens[9] = 0, T, 1
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    cu_h, tok_h = engine.token_packing_host(mask)
+    cu_d, tok_d = engine.token_packing(torch.from_numpy(mask))
+    assert cu_h.dtype == torch.int32 and tok_h.dtype == torch.int32
+    assert torch.equal(cu_h, cu_d) and torch.equal(tok_h, tok_d)
+    assert int(cu_h[-1]) == int(np.maximum(lens, 1).sum())
+    holes = mask.copy()
+    holes[3, 1] = 0
+    holes[3, 4] = 1
+    assert engine.token_packing_host(holes) is None

@@ -344,3 +344,27 @@ def test_weight_gradient_stream_changes_nothing(use_modal):
     for a, b in zip(out[False][3], out[True][3]):
         assert float((a - b).abs().max()) <= 0.2 * 1e-3
     assert all(float(g.abs().sum()) > 0 for g in out[True][2])
+
+
+def test_host_token_packing_gives_the_same_step():
+    """``TrainStep.step(..., token_packing=...)`` (row offsets / packed-row indices prepared by the collate on the host and uploaded with the
+    batch: no host synchronisation in the step) against the default (the same vectors derived on the device): identical losses and parameters."""
+    from idvs.morec_amd import engine
+    from idvs.morec_amd.train_step import TrainStep
+    tdev = lambda a: torch.from_numpy(a).to(DEV)      # noqa: E731
+    out = {}
+    for mode in ("device", "host"):
+        model, ids, items, lm, pop, _ = _setup("bf16", True, B=24, S=10, D=128)
+        ts = TrainStep(model, lr=1e-3, fine_tune_lr=5e-4, l2_weight=0.01, fine_tune_l2_weight=0.02)
+        T = items.shape[1] // 2
+        pack = None
+        if mode == "host":
+            cu, tok = engine.token_packing_host(items[:, T:])
+            assert int(cu[-1]) < items.shape[0] * T           # the case under test is ragged
+            pack = (cu.to(DEV), tok.to(DEV))
+        losses = [float(ts.step(tdev(ids).view(-1), tdev(items), tdev(lm), token_packing=pack)) for _ in range(2)]
+        torch.cuda.synchronize()
+        out[mode] = (losses, [g["arena"].data.clone() for g in ts.groups])
+    assert out["device"][0] == out["host"][0]
+    for a, b in zip(out["device"][1], out["host"][1]):
+        assert float((a - b).abs().max()) <= 0.2 * 1e-3        # fp32 atomic sums of the LayerNorm / bias gradients: see the stream test above
