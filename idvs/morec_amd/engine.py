@@ -92,12 +92,17 @@ class WgradStream:
     the end of the step), while the persistent 256 x 256 GEMMs of the dX chain leave the last, partly filled round of tiles with idle
     CUs (600 tiles on 256 CUs = 2.34 rounds) and the slab folds / small kernels between them leave more: launched on their own stream
     the dW workgroups start on every CU the dX chain does not use at that moment, and vice versa -- the hardware dispatcher fills
-    both kernels' tails with the other's tiles.  Ordering: the side stream waits for the producing kernels (event), inputs are
-    pinned to it (``record_stream``), ``join()`` (end of the backward pass, before anything reads the gradient arenas) makes the
-    main stream wait for it.  ``MOREC_WGRAD_STREAM=0`` keeps everything on one stream."""
+    both kernels' tails with the other's tiles.  Ordering: the side stream waits for the producing kernels (event); the operands of
+    its launches are kept ALIVE (a reference list) until ``join()`` -- end of the backward pass, before anything reads the gradient
+    arenas -- has made the main stream wait for the side stream: whatever is freed after that point is reused by main-stream
+    allocations that are ordered behind the wait.  (Not ``Tensor.record_stream``: it defers the reuse of ~20 GB of activations per
+    step until the side stream's events have COMPLETED on the device, and a host that issues steps faster than the GPU runs them
+    -- there is no synchronisation inside a step -- then allocates fresh memory for every step in flight until the caching allocator
+    has to stall and flush: 34 -> 140 ms/step, intermittently.)  ``MOREC_WGRAD_STREAM=0`` keeps everything on one stream."""
     enabled = os.environ.get("MOREC_WGRAD_STREAM", "1") != "0"
     _streams: dict = {}
     _dirty: set = set()
+    _keep: dict = {}
 
     @classmethod
     def get(cls, device):
@@ -114,6 +119,7 @@ class WgradStream:
         if device in cls._dirty:
             torch.cuda.current_stream(device).wait_stream(cls._streams[device])
             cls._dirty.discard(device)
+        cls._keep.pop(device, None)      # the operands of the side stream's launches may be freed (and reused behind the wait) now
 
 
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
@@ -127,8 +133,7 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
         side.wait_stream(torch.cuda.current_stream(dy.device))     # dy (and the zeroed arena) are produced on the main stream
         with torch.cuda.stream(side):
             ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))
-        dy.record_stream(side)
-        x.record_stream(side)
+        WgradStream._keep.setdefault(dy.device, []).extend((dy, x))
         WgradStream._dirty.add(dy.device)
         return None, None
     dyt = ops.transpose(dy) if dyt is None else dyt

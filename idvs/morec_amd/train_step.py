@@ -205,6 +205,7 @@ class TrainStep:
         self._pending, self._reduced, self._stepped = [], [], []
         self._fused_update = False
         self.trace = None           # list -> _reduce_slice / reduce_gradients record stream-time events of the gradient collectives
+        self._inflight = []         # end-of-step events of the steps the host has issued and not yet waited for (at most two)
 
     def _bucket_plan(self):
         """Contiguous slices of the tower arena whose gradients become final together: ``("layer", l)`` for the text
@@ -627,6 +628,14 @@ class TrainStep:
         of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``.
         ``token_packing`` (text tower, optional): the device copies of ``engine.token_packing_host(attention mask)`` uploaded with
         the batch; without it the same index vectors are derived on the device, which costs the step two host synchronisations."""
+        # No synchronisation happens inside a step, so the host could issue steps far ahead of the device; every step in flight holds its
+        # host batch, its events and (until its kernels are queued) its share of the allocator's attention.  Two steps in flight keep the
+        # device queue full; the host waits for the step before the previous one.
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            self._inflight.append(ev)
+            if len(self._inflight) > 2:
+                self._inflight.pop(0).synchronize()
         self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
         try:
             loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
@@ -634,4 +643,6 @@ class TrainStep:
             self._fused_update = False
         self.reduce_gradients()
         self.optimizer_step()
+        if self.device.type == "cuda":
+            self._inflight[-1].record(torch.cuda.current_stream(self.device))
         return loss
