@@ -305,7 +305,8 @@ typedef struct {
     int ws_from_fwd; /* backward only: 1 = `workspace` is the buffer the matching morec_inbatch_ce_fwd call (same descriptor fields, same
                       * P / E / ids / log-pop / validity) was given and nothing has written to it since: the backward then reuses the
                       * (user, column) flag table and the positive logits the forward left there instead of rebuilding them (the
-                      * 256 x 256 kernels; ignored by the 128 x 128 ones).  0 = the workspace is plain scratch. */
+                      * 256 x 256 kernels; ignored by the 128 x 128 ones; the "ce8p" knob must not change between the two calls).
+                      * 0 = the workspace is plain scratch. */
 } morec_ce_desc;
 
 size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d);
