@@ -31,16 +31,19 @@ typedef __attribute__((address_space(8))) void* rsrc_t;   // 128-bit buffer desc
 // The two 1-KiB pieces (8 rows each) this wave contributes to a half-tile.  buffer_load ... offen lds: descriptor (SGPRs) +
 // per-lane 32-bit byte offset (loop-invariant VGPR) + wave-uniform K offset (SGPR): no per-lane 64-bit pointers to keep alive
 // or to advance, which is what made the flat global_load_lds form of this loop spill.
+// AUX: cache policy of the loads (0 = default; 2 = nt: a panel that is streamed through once should not push the re-used one out of L2)
+template <int AUX = 0>
 __device__ __forceinline__ void dma2(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, int kbyte, char* dst) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, o0, kbyte, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, o1, kbyte, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, o0, kbyte, 0, AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, o1, kbyte, 0, AUX);
 }
 struct Ctx;
 // The same for a K-tile that may be the LAST one of a K that is not a multiple of 64: `m` = all ones when it is (wave-uniform),
 // and the lanes whose 16-byte slot lies past K carry 0x80000000 in c.pz[]: the offset leaves the descriptor's range and the DMA
 // writes zeros.  One v_and_or_b32 per instruction; with K % 64 == 0 pz is 0 and nothing changes.
+template <int AUX = 0>
 __device__ __forceinline__ void dma2z(__amdgpu_buffer_rsrc_t rs, uint32_t o0, uint32_t o1, const uint32_t (&pz)[2], uint32_t m, int kbyte, char* dst) {
-    dma2(rs, o0 | (pz[0] & m), o1 | (pz[1] & m), kbyte, dst);
+    dma2<AUX>(rs, o0 | (pz[0] & m), o1 | (pz[1] & m), kbyte, dst);
 }
 
 struct Ctx {
@@ -88,7 +91,8 @@ __device__ __forceinline__ void vm_wait_tail() {
 
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
 // last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
-template <int REM, int SLACK = 0, bool ZERO = false>
+// BAUX: cache policy of the B-panel loads (see dma2)
+template <int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0>
 __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
     const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
     const uint32_t m2 = last2 ? 0xffffffffu : 0u;
@@ -109,7 +113,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
-    if constexpr (REM >= 1) dma2z(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
+    if constexpr (REM >= 1) dma2z<BAUX>(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
@@ -136,7 +140,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     mfma_quadrant<2, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
-    if constexpr (REM >= 2) dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
+    if constexpr (REM >= 2) dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
@@ -179,14 +183,15 @@ __device__ __forceinline__ void make_ctx(Ctx& c, int tid, const bf16* At, const 
 // Prologue of a tile: K-tile 0 entirely, the first halves of K-tile 1 (12 LDS-DMA instructions per lane).  LDS must be free
 // of readers: called before the first tile and, for the NEXT tile, right after a main loop (every wave is past its last barrier)
 // -- i.e. ahead of the finished tile's epilogue, whose slices live outside the two K-tile buffers.
+template <int BAUX = 0>
 __device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk) {
     const uint32_t m = nk == 2 ? 0xffffffffu : 0u;
     dma2(c.ra, c.a1[0], c.a1[1], 0, smem + c.dA1);
-    dma2(c.rb, c.b1[0], c.b1[1], 0, smem + OP_BYTES + c.dB1);
-    dma2(c.rb, c.b2[0], c.b2[1], 0, smem + OP_BYTES + c.dB2);
+    dma2<BAUX>(c.rb, c.b1[0], c.b1[1], 0, smem + OP_BYTES + c.dB1);
+    dma2<BAUX>(c.rb, c.b2[0], c.b2[1], 0, smem + OP_BYTES + c.dB2);
     dma2(c.ra, c.a2[0], c.a2[1], 0, smem + c.dA2);
     dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m, KB, smem + BUF_BYTES + c.dA1);
-    dma2z(c.rb, c.b1[0], c.b1[1], c.pz, m, KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
+    dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m, KB, smem + BUF_BYTES + OP_BYTES + c.dB1);
     pin();
 }
 
@@ -198,7 +203,7 @@ __device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk)
     do {                                                                                \
         if (st && threadIdx.x == 0) st[(i)] = __builtin_readcyclecounter();              \
     } while (0)
-template <int SLACK>
+template <int SLACK, int BAUX = 0>
 __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char* smem, f32x16_t (&acc)[4][2], unsigned long long* st) {
     G8_MSTAMP(8);
     vm_wait<8 + SLACK>();    // A-first, B-first of K-tile 0 (this wave's pieces)
@@ -209,7 +214,7 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     int cb = 0;
     int t = 0;
     if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<2, SLACK, true>(smem, c, cb, 0, acc, nk == 3);
+        ktile<2, SLACK, true, BAUX>(smem, c, cb, 0, acc, nk == 3);
         cb ^= BUF_BYTES;
         t = 1;
     } else {
@@ -222,22 +227,23 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
-        ktile<2>(smem, c, cb, t * KB, acc, t + 3 == nk);
+        ktile<2, 0, false, BAUX>(smem, c, cb, t * KB, acc, t + 3 == nk);
         cb ^= BUF_BYTES;
         if (t == 1) G8_MSTAMP(12);
     }
     G8_MSTAMP(13);
-    ktile<1>(smem, c, cb, t * KB, acc);
-    ktile<0>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
+    ktile<1, 0, false, BAUX>(smem, c, cb, t * KB, acc);
+    ktile<0, 0, false, BAUX>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
     G8_MSTAMP(14);
     if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
     G8_MSTAMP(15);
 }
 // `younger`: VMEM operations this wave has issued since the tile's prologue (only a LOWER bound matters: see vm_wait_tail)
+template <int BAUX = 0>
 __device__ __forceinline__ void mainloop8p(const Ctx& c, int wr, int nk, int younger, char* smem, f32x16_t (&acc)[4][2],
                                            unsigned long long* st) {
-    if (younger >= 32) mainloop8p_s<32>(c, wr, nk, smem, acc, st);
-    else if (younger >= 16) mainloop8p_s<16>(c, wr, nk, smem, acc, st);
-    else mainloop8p_s<0>(c, wr, nk, smem, acc, st);
+    if (younger >= 32) mainloop8p_s<32, BAUX>(c, wr, nk, smem, acc, st);
+    else if (younger >= 16) mainloop8p_s<16, BAUX>(c, wr, nk, smem, acc, st);
+    else mainloop8p_s<0, BAUX>(c, wr, nk, smem, acc, st);
 }
 }  // namespace g8

@@ -20,6 +20,12 @@ using namespace g8;
 constexpr float MASKED_LOGIT = -1e4f;
 constexpr int SLICE = 4096;
 constexpr int LDS_TOTAL = LDS_BYTES + 8 * SLICE;
+// The E panels stream through an XCD once (column-panel-major order); P (2.6 MB at B = 128, D = 512) is re-read from L2 by every tile.
+// Non-temporal loads for E keep them from pushing P out of the 4-MiB L2: forward FETCH_SIZE 43.5 -> 26.9 MiB raw per launch at the pooled
+// size (2.2x the operand bytes instead of 3.6x).  The backward streams 110 MB of dl^T through the same L2 and fetched slightly MORE with
+// them (56.8 -> 63.0 MiB): default policy there.
+template <bool BWD>
+constexpr int E_AUX = BWD ? 0 : 2;
 
 // The tile works in the BASE-2 domain: x2 = (acc - log pop) * log2(e) is one fma per cell (the table holds log2(e) * log pop) and
 // 2^x is the native v_exp_f32; partial maxima / sums leave the kernel in that domain and ce_combine converts (lse = ln 2 * (max2 +
@@ -135,8 +141,8 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
         asm volatile("" : "+v"(tid_m));
         Ctx c;
         make_ctx(c, tid_m, Pc, Ec, p.Nr - cur.m0, p.Nc - cur.n0, p.D, p.D, krem);
-        if (first) issue_prologue(c, smem, nk);
-        mainloop8p(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, 0, smem, acc, nullptr);
+        if (first) issue_prologue<E_AUX<BWD>>(c, smem, nk);
+        mainloop8p<E_AUX<BWD>>(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, 0, smem, acc, nullptr);
     }
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
@@ -179,7 +185,7 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
         asm volatile("" : "+v"(tid_n));
         Ctx cn;
         make_ctx(cn, tid_n, Pn, En, p.Nr - nxt.m0, p.Nc - nxt.n0, p.D, p.D, krem);
-        issue_prologue(cn, smem, nk);
+        issue_prologue<E_AUX<BWD>>(cn, smem, nk);
     }
     if constexpr (!BWD) {
         // per (row, 64-column chunk of this wave) maximum and sum; the four chunks of a row (the four wave columns) are merged through
