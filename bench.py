@@ -198,9 +198,10 @@ def main():
         items = None if vision else (torch.from_numpy(ids_all[i].reshape(-1).copy()).pin_memory() if id_tower
                                      else torch.from_numpy(content[ids_all[i].reshape(-1)]).pin_memory())
         lm = torch.ones(a.batch, S).pin_memory()
-        # the collate's share of the unpadded token layout: row offsets / packed-row indices from the attention masks, on the host,
+        # the collate's share of the unpadded token layout: row offsets / packed-row indices from the attention masks (+ the rows in
+        # token-id order for the word-embedding gradient), on the host,
         # uploaded with the batch (no device-side bookkeeping, no host synchronisation inside the step)
-        pack = None if (vision or id_tower or a.padded) else _engine.token_packing_host(content[ids_all[i].reshape(-1), T:])
+        pack = None if (vision or id_tower or a.padded) else _engine.token_packing_host(content[ids_all[i].reshape(-1), T:], content[ids_all[i].reshape(-1), :T])
         host.append((ids, items, lm, pack))
     if vision:
         gen = torch.Generator(device=dev).manual_seed(4321)
@@ -277,7 +278,7 @@ def main():
         ids_d = ids.to(dev, non_blocking=True)
         items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
         lm_d = lm.to(dev, non_blocking=True)
-        pack_d = None if pack is None else (pack[0].to(dev, non_blocking=True), pack[1].to(dev, non_blocking=True))
+        pack_d = None if pack is None else tuple(t.to(dev, non_blocking=True) for t in pack)
         return ts.step(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
 
     log("warm-up")

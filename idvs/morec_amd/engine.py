@@ -374,12 +374,14 @@ def token_packing(mask: torch.Tensor):
     return cu, tok_idx
 
 
-def token_packing_host(mask):
+def token_packing_host(mask, token_ids=None):
     """The same bookkeeping on the HOST (numpy / CPU tensor ``mask`` int [Nc, T], what the data loader's collate holds before the H2D
     copy, ``T/run.py:232-239``): returns pinned int32 CPU tensors ``(cu_seqlens [Nc + 1], tok_idx [n_tokens])`` or ``None`` when the
     rows are not a run of ones followed by zeros (the padded layout is kept then).  Uploading the two vectors with the batch spares
     the step its only two host synchronisations (the ``all()`` / ``nonzero()`` of the device-side version), i.e. ~0.25 ms of idle GPU
-    at every step boundary."""
+    at every step boundary.  With ``token_ids`` (int [Nc, T], the token half of the same rows) a third vector is returned: the rows
+    of the padded layout in token-id order (stable), which the word-embedding gradient's run-length scatter walks -- otherwise a
+    device-side ``argsort`` (ten small kernels) at the very end of the backward pass, with nothing left to overlap it."""
     import numpy as np
     m = mask.numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
     m = (m != 0)
@@ -395,8 +397,11 @@ def token_packing_host(mask):
     pos = np.arange(n, dtype=np.int64) - np.repeat(cu[:-1].astype(np.int64), lens)
     tok = (seq * T + pos).astype(np.int32)
     pin = torch.cuda.is_available()
-    cu_t, tok_t = torch.from_numpy(cu), torch.from_numpy(tok)
-    return (cu_t.pin_memory(), tok_t.pin_memory()) if pin else (cu_t, tok_t)
+    out = [torch.from_numpy(cu), torch.from_numpy(tok)]
+    if token_ids is not None:
+        ids = token_ids.numpy() if isinstance(token_ids, torch.Tensor) else np.asarray(token_ids)
+        out.append(torch.from_numpy(np.argsort(ids.reshape(-1), kind="stable").astype(np.int32)))
+    return tuple(t.pin_memory() for t in out) if pin else tuple(out)
 
 
 def bert_grad_from(trainable_names, n_layers: int, prefix: str = TE) -> int:
@@ -454,10 +459,11 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
                                                 eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
+    order = packing[2] if packing is not None and len(packing) > 2 else None     # rows in token-id order, for the backward's word scatter
     if packing is not None and (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
-        # ``packing``: (cu_seqlens, tok_idx) int32 DEVICE tensors prepared on the host with the batch (``token_packing_host``): no
-        # device-side bookkeeping, no host synchronisation in the step
-        cu, tok_idx = packing
+        # ``packing``: (cu_seqlens, tok_idx[, order]) int32 DEVICE tensors prepared on the host with the batch (``token_packing_host``):
+        # no device-side bookkeeping, no host synchronisation in the step
+        cu, tok_idx = packing[0], packing[1]
         if tok_idx.numel() == Nc * T:
             cu, tok_idx = None, None
         else:
@@ -485,7 +491,7 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
-    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from) if need_grad else None
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order) if need_grad else None
     return item, saved
 
 
@@ -494,7 +500,7 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     ``bert_model`` is, ``("layer", l)`` after layer ``l`` -- so a data-parallel driver can start reducing them while the
     rest of the backward pass still runs."""
     bm = prefix + "bert_model."
-    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from = saved
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order = saved
     n_layers = len(prep["layers"])
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
@@ -546,7 +552,8 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
                                 p_out=drop.p_hidden, seed_out=drop.site(0))
-    order = torch.argsort(ids32).to(torch.int32)      # integer bookkeeping: rows in token-id order for the run-length scatter
+    if order is None:      # integer bookkeeping: rows in token-id order for the run-length scatter (the collate can supply it: token_packing_host)
+        order = torch.argsort(ids32).to(torch.int32)
     ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],
                         grads[bm + "embeddings.position_embeddings.weight"],
                         grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T, order)

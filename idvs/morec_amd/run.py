@@ -266,8 +266,9 @@ def train(args, use_modal, local_rank):
             ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
             pack = None
             if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
-                hp = engine.token_packing_host(items.view(-1, items.size(-1))[:, T:])
-                pack = None if hp is None else (hp[0].to(local_rank, non_blocking=True), hp[1].to(local_rank, non_blocking=True))
+                rows = items.view(-1, items.size(-1))
+                hp = engine.token_packing_host(rows[:, T:], rows[:, :T])
+                pack = None if hp is None else tuple(t.to(local_rank, non_blocking=True) for t in hp)
             ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
             if vision:
                 items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)

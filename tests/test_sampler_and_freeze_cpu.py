@@ -102,6 +102,11 @@ def test_token_packing_host_equals_device_bookkeeping():
     assert cu_h.dtype == torch.int32 and tok_h.dtype == torch.int32
     assert torch.equal(cu_h, cu_d) and torch.equal(tok_h, tok_d)
     assert int(cu_h[-1]) == int(np.maximum(lens, 1).sum())
+    ids = rng.integers(0, 40, (Nc, T))
+    cu_o, tok_o, order = engine.token_packing_host(mask, ids)
+    assert torch.equal(cu_o, cu_h) and torch.equal(tok_o, tok_h) and order.dtype == torch.int32
+    flat = ids.reshape(-1)
+    assert sorted(order.tolist()) == list(range(Nc * T)) and (np.diff(flat[order.numpy()]) >= 0).all()      # a permutation that groups equal ids
     holes = mask.copy()
     holes[3, 1] = 0
     holes[3, 4] = 1
