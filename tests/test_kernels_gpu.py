@@ -318,6 +318,29 @@ def test_bert_embed(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("n_seq,T,H", [(150, 30, 768), (131, 7, 128), (70, 5, 516), (3, 30, 1024)])
+def test_bert_embed_bwd_shapes(dt, n_seq, T, H):
+    """Word / position / type gradients at more shapes: several sequence chunks per position (n_seq > 64), a last wave with fewer
+    than 32 sorted rows, rows wider / narrower than one 256-lane pass, and a bf16 row width that is not a multiple of the 16-byte
+    vector (516: the scalar position kernel); sorted (run-length) and plain scatter against an fp64 index_add."""
+    V = 300
+    g = torch.Generator(device=DEV).manual_seed(n_seq * 1000 + H)
+    ids = torch.randint(0, V, (n_seq * T,), device=DEV, dtype=torch.int32, generator=g)
+    ids[::3] = 0
+    ids[1::4] = 17
+    dz = rnd(n_seq * T, H, dt=dt, seed=H)
+    ref = torch.zeros((V, H), device=DEV, dtype=torch.float64)
+    ref.index_add_(0, ids.long(), dz.double())
+    ref[0] = 0
+    for order in (None, torch.argsort(ids, stable=True).to(torch.int32)):
+        dword, dpos, dtyp = torch.zeros((V, H), device=DEV), torch.zeros((T + 3, H), device=DEV), torch.zeros(H, device=DEV)
+        ops.bert_embed_bwd_(ids, dz, dword, dpos, dtyp, 0, T, order)
+        assert rel(dword, ref) < 1e-5
+        assert rel(dpos[:T], dz.double().view(n_seq, T, H).sum(0)) < 1e-5 and (dpos[T:] == 0).all()
+        assert rel(dtyp, dz.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gather_scatter(dt):
     V, D, R = 500, 512, 333
     table = rnd(V, D)
