@@ -4,6 +4,7 @@
 //   ID tower (T/model/model.py:27-28,37): row gather / scatter-add with padding_idx = 0;
 //   strided row copies for hidden[:, 0] (T/model/encoders.py:69).
 #include "common.hpp"
+#include "pos_grad.hpp"
 
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __restrict__ ids,
@@ -224,68 +225,6 @@ __global__ __launch_bounds__(256) void word_scatter_sorted_kernel(const int32_t*
     flush();
 }
 
-// dpos[t] = sum over sequences of dz[seq*T + t]; dtype0 = sum over all rows.  A block owns 4 * groups sequences and walks the T
-// positions: a thread owns one 16-byte column vector of the row and four of the block's sequences, with the rows of the next TWO
-// positions in flight while this position's partials are folded through LDS into ONE coalesced atomic per column (the type-row
-// sum stays in registers over all positions: one atomic per column per block).  The first version read two bytes per lane per
-// dependent trip and sent every block's type-row sums to the same H addresses: 118 us for 124 MB.
-template <typename T>
-__global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
-                                                            float* __restrict__ dtype0, int nseq, int Tlen, int H) {
-    constexpr int EV = vio<T>::EV, R = 4;
-    extern __shared__ __attribute__((aligned(16))) float sm_pt[];      // [groups][H]
-    const int nv = H / EV;                                   // <= 256, H % EV == 0 (launcher)
-    const int groups = 256 / nv;
-    const int grp = (int)threadIdx.x / nv, cv = (int)threadIdx.x - grp * nv;
-    const bool active = grp < groups;
-    const int s0 = blockIdx.x * (R * groups);
-    // this thread's sequences: s0 + grp + u * groups, u < n_ok
-    const int n_ok = active ? max(0, min(R, (nseq - s0 - grp + groups - 1) / groups)) : 0;
-    const T* base = dz + ((size_t)(n_ok ? s0 + grp : 0) * Tlen) * H + cv * EV;
-    const size_t ustride = (size_t)groups * Tlen * H;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 ra[R], rb[R];
-#define PT_FETCH(r, t)                                                                                              \
-    _Pragma("unroll") for (int u = 0; u < R; ++u)                                                                    \
-        r[u] = (u < n_ok && (t) < Tlen) ? vio<T>::load_raw(base + u * ustride + (size_t)(t) * H) : zero4
-    float ty[EV];
-#pragma unroll
-    for (int k = 0; k < EV; ++k) ty[k] = 0.f;
-    auto fold = [&](const float (&acc)[EV], float* dst) {      // the groups' partials -> ONE coalesced atomic per column
-        if (active) store_f32v<EV>(sm_pt + (size_t)grp * H + cv * EV, acc);
-        __syncthreads();
-        for (int c = threadIdx.x; c < H; c += 256) {
-            float v = 0.f;
-            for (int g = 0; g < groups; ++g) v += sm_pt[(size_t)g * H + c];
-            atomicAdd(dst + c, v);
-        }
-        __syncthreads();
-    };
-    // consume position t from r, refill r with position t + 2, fold and emit
-#define PT_POSITION(r, t)                                                                     \
-    {                                                                                         \
-        float acc[EV];                                                                        \
-        _Pragma("unroll") for (int k = 0; k < EV; ++k) acc[k] = 0.f;                          \
-        _Pragma("unroll") for (int u = 0; u < R; ++u) {                                       \
-            float e[EV];                                                                      \
-            vio<T>::unpack(r[u], e);                                                          \
-            _Pragma("unroll") for (int k = 0; k < EV; ++k) acc[k] += e[k];                    \
-        }                                                                                     \
-        PT_FETCH(r, (t) + 2);                                                                 \
-        _Pragma("unroll") for (int k = 0; k < EV; ++k) ty[k] += acc[k];                       \
-        fold(acc, dpos + (size_t)(t) * H);                                                    \
-    }
-    PT_FETCH(ra, 0);
-    PT_FETCH(rb, 1);
-    for (int t = 0; t < Tlen; t += 2) {
-        PT_POSITION(ra, t);
-        if (t + 1 < Tlen) PT_POSITION(rb, t + 1);
-    }
-    if (dtype0) fold(ty, dtype0);
-#undef PT_FETCH
-#undef PT_POSITION
-}
-
 template <typename T>      // row width not a multiple of the 16-byte vector: one element per lane per trip
 __global__ __launch_bounds__(256) void pos_type_grad_scalar_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
                                                                    float* __restrict__ dtype0, int nseq, int Tlen, int H,
@@ -309,21 +248,18 @@ extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* d
     dim3 g1((M + 3) / 4), g2(T, (M / T + spb - 1) / spb);
     const int ev = dtype == MOREC_BF16 ? 8 : 4;
     const bool vec = H % ev == 0 && H / ev <= 256;          // one 16-byte column vector per thread
-    const int grp = vec ? 256 / (H / ev) : 1;
-    dim3 gv((M / T + 4 * grp - 1) / (4 * grp));
-    const size_t lds_v = (size_t)grp * H * sizeof(float);
     const int rpw = 32;                                   // sorted rows per wave
     dim3 g3((((M + rpw - 1) / rpw) + 3) / 4);
     const bool sorted = order != nullptr && H <= 1024;
     if (dtype == MOREC_F32) {
         if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<float, 4>), g3, dim3(256), 0, s, ids, order, (const float*)dz, dword, pad_id, M, H, rpw);
         else hipLaunchKernelGGL((word_scatter_kernel<float>), g1, dim3(256), 0, s, ids, (const float*)dz, dword, pad_id, M, H);
-        if (vec) hipLaunchKernelGGL((pos_type_grad_kernel<float>), gv, dim3(256), lds_v, s, (const float*)dz, dpos, dtype0, M / T, T, H);
+        if (vec) pos_type_grad_launch<float>((const float*)dz, dpos, dtype0, M / T, T, H, s);
         else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<float>), g2, dim3(256), 0, s, (const float*)dz, dpos, dtype0, M / T, T, H, spb);
     } else if (dtype == MOREC_BF16) {
         if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<bf16, 4>), g3, dim3(256), 0, s, ids, order, (const bf16*)dz, dword, pad_id, M, H, rpw);
         else hipLaunchKernelGGL((word_scatter_kernel<bf16>), g1, dim3(256), 0, s, ids, (const bf16*)dz, dword, pad_id, M, H);
-        if (vec) hipLaunchKernelGGL((pos_type_grad_kernel<bf16>), gv, dim3(256), lds_v, s, (const bf16*)dz, dpos, dtype0, M / T, T, H);
+        if (vec) pos_type_grad_launch<bf16>((const bf16*)dz, dpos, dtype0, M / T, T, H, s);
         else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<bf16>), g2, dim3(256), 0, s, (const bf16*)dz, dpos, dtype0, M / T, T, H, spb);
     } else {
         return MOREC_E_DTYPE;

@@ -4,6 +4,7 @@
 // BertEmbeddings LayerNorm (eps 1e-12); HBM-bound (one read of each input, one write of each output).
 #include <algorithm>
 #include "common.hpp"
+#include "pos_grad.hpp"
 
 // Every lane moves 16 bytes per access (EV = 4 fp32 / 8 bf16 elements); VPL = such vectors per lane, a row of N
 // elements needs ceil(N / (64 EV)) of them.  (With 8-byte bf16 accesses the kernels were memory-INSTRUCTION bound:
@@ -455,12 +456,16 @@ extern "C" int morec_pos_grad(const void* dz, float* dpos, int M, int N, int per
     const int spb = 64;
     dim3 grid(period, (M / period + spb - 1) / spb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == MOREC_F32)
-        hipLaunchKernelGGL((pos_grad_kernel<float>), grid, dim3(256), 0, s, (const float*)dz, dpos, M, N, period, spb);
-    else if (dtype == MOREC_BF16)
-        hipLaunchKernelGGL((pos_grad_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)dz, dpos, M, N, period, spb);
-    else
+    // 16-byte column vectors, several rows in flight (pos_grad.hpp); the scalar kernel keeps the row widths that do not fit
+    if (dtype == MOREC_F32) {
+        if (!pos_type_grad_launch<float>((const float*)dz, dpos, nullptr, M / period, period, N, s))
+            hipLaunchKernelGGL((pos_grad_kernel<float>), grid, dim3(256), 0, s, (const float*)dz, dpos, M, N, period, spb);
+    } else if (dtype == MOREC_BF16) {
+        if (!pos_type_grad_launch<bf16>((const bf16*)dz, dpos, nullptr, M / period, period, N, s))
+            hipLaunchKernelGGL((pos_grad_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)dz, dpos, M, N, period, spb);
+    } else {
         return MOREC_E_DTYPE;
+    }
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -235,6 +235,18 @@ def test_layernorm(dt, N):
     assert rel(y2, torch.nn.functional.layer_norm(x.double(), (N,), gamma.double(), beta.double(), 1e-12)) < tol(dt)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nseq,S,N", [(128, 20, 512), (64, 10, 2048), (3, 7, 64), (1, 5, 128), (700, 3, 768), (9, 4, 4104), (33, 6, 516)])
+def test_pos_grad_shapes(dt, nseq, S, N):
+    """dpos[m % S] += dz[m] at the recommender's sizes (text D = 512, vision D = 2048), a single sequence, many sequences with few
+    positions, and row widths outside the one-vector-per-thread layout (4104 > 256 vectors; 516 is not a multiple of 8: scalar kernel);
+    accumulates into what is there."""
+    dz = rnd(nseq * S, N, dt=dt, seed=N + S)
+    dpos = torch.full((S + 2, N), 0.5, device=DEV)
+    ops.pos_grad_(dz, dpos, S)
+    assert rel(dpos[:S] - 0.5, dz.double().view(nseq, S, N).sum(0)) < 1e-5 and (dpos[S:] == 0.5).all()
+
+
 def attn_ref(qkv, keep, n_heads, causal, scale, mask_value):
     M, H3 = qkv.shape
     n_seq, T = keep.shape
