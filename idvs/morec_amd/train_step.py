@@ -341,13 +341,22 @@ class TrainStep:
         # Nothing in the FORWARD pass reads the gradient arenas or the W^T copies (dX = dY W): zero / refresh them on the side stream,
         # under the forward GEMMs (HBM-bound fills next to MFMA-bound kernels), and let the main stream wait for them right before
         # the backward pass starts.
+        # So does the scoring stage's index bookkeeping (validity masks, log-popularity gather, 1 / n_valid: a dozen small kernels that
+        # depend on the batch's ids and mask only) -- between the two towers they would sit on the critical path at ~6 us apiece.
+        ids = sample_items_id.view(-1)
         side = engine.WgradStream.get(self.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(self.device))     # the previous step's AdamW wrote the shadows the transposes read
             with torch.cuda.stream(side):
+                ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
+                n_valid = ci.row_valid.sum(dtype=torch.float32)
+                gscale = (1.0 / n_valid).reshape(1)
                 self._prepare_step_buffers()
             engine.WgradStream._dirty.add(self.device)
         else:
+            ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
+            n_valid = ci.row_valid.sum(dtype=torch.float32)
+            gscale = (1.0 / n_valid).reshape(1)
             self._prepare_step_buffers()
         self._pending, self._reduced, self._stepped = [], [], []
         # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
@@ -355,7 +364,6 @@ class TrainStep:
         for n, t in self.frozen.items():      # frozen tensors the backward still passes through get scratch buffers
             if ".pooler." not in n and (self.vision or not m.use_modal or engine.bert_needs_grad_buffer(n, self.bert_grad_from)):
                 grads[n] = torch.zeros_like(t)
-        ids = sample_items_id.view(-1)
         d_item, d_user = m.dropout_cfgs()
         dedup = self.dedup_items and m.use_modal
         if dedup:   # integer bookkeeping only (sort / unique / first-occurrence index); one host sync for the count
@@ -386,15 +394,13 @@ class TrainStep:
         x_in = E.view(B, S + 1, D)[:, :-1, :].contiguous()
         prep_s = engine.sasrec_prepare(p, m.args.transformer_block, self.dtype, engine.UE, self.sh)
         P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE, d_user)
-        ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
-        n_valid = ci.row_valid.sum(dtype=torch.float32)
+        if side is not None:       # scoring bookkeeping done, gradient arenas zeroed, W^T copies in place
+            torch.cuda.current_stream(self.device).wait_stream(side)
         Epool = E
         if self.collectives and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank, self.comm)
+            gscale = (1.0 / n_valid).reshape(1)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.collectives and self.pool))
-        gscale = (1.0 / n_valid).reshape(1)
-        if side is not None:       # gradient arenas zeroed, W^T copies in place
-            torch.cuda.current_stream(self.device).wait_stream(side)
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
         dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype, self.comm) if (self.collectives and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
