@@ -369,11 +369,12 @@ __global__ __launch_bounds__(256) void indexed_rows_kernel(const T* __restrict__
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
-    const size_t src = in_idx ? (size_t)in_idx[row] : (size_t)row, dst = out_idx ? (size_t)out_idx[row] : (size_t)row;
+    const int si = in_idx ? in_idx[row] : row;         // negative gather index: a zero row (the [PAD] rows of an unpacked layout)
+    const size_t src = (size_t)(si < 0 ? 0 : si), dst = out_idx ? (size_t)out_idx[row] : (size_t)row;
     for (int c = lane * EV; c < D; c += 64 * EV) {
-        float v[EV];
-        vio<T>::load(in + src * D + c, v);
-        vio<T>::store(out + dst * D + c, v);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (si >= 0) v = vio<T>::load_raw(in + src * D + c);
+        *reinterpret_cast<uint4*>(out + dst * D + c) = v;
     }
 }
 

@@ -381,7 +381,9 @@ def token_packing_host(mask, token_ids=None):
     the step its only two host synchronisations (the ``all()`` / ``nonzero()`` of the device-side version), i.e. ~0.25 ms of idle GPU
     at every step boundary.  With ``token_ids`` (int [Nc, T], the token half of the same rows) a third vector is returned: the rows
     of the padded layout in token-id order (stable), which the word-embedding gradient's run-length scatter walks -- otherwise a
-    device-side ``argsort`` (ten small kernels) at the very end of the backward pass, with nothing left to overlap it."""
+    device-side ``argsort`` (ten small kernels) at the very end of the backward pass, with nothing left to overlap it -- and a fourth:
+    padded row -> packed row (-1 for [PAD] rows), with which the backward spreads the packed gradients over the padded layout in one
+    gather per tensor instead of a fill + scatter."""
     import numpy as np
     m = mask.numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
     m = (m != 0)
@@ -401,6 +403,9 @@ def token_packing_host(mask, token_ids=None):
     if token_ids is not None:
         ids = token_ids.numpy() if isinstance(token_ids, torch.Tensor) else np.asarray(token_ids)
         out.append(torch.from_numpy(np.argsort(ids.reshape(-1), kind="stable").astype(np.int32)))
+        inv = np.full(Nc * T, -1, dtype=np.int32)      # padded row -> packed row (-1: a [PAD] row), for the way back in the backward pass
+        inv[tok] = np.arange(n, dtype=np.int32)
+        out.append(torch.from_numpy(inv))
     return tuple(t.pin_memory() for t in out) if pin else tuple(out)
 
 
@@ -460,6 +465,7 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
     order = packing[2] if packing is not None and len(packing) > 2 else None     # rows in token-id order, for the backward's word scatter
+    inv = packing[3] if packing is not None and len(packing) > 3 else None       # padded row -> packed row or -1
     if packing is not None and (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
         # ``packing``: (cu_seqlens, tok_idx[, order]) int32 DEVICE tensors prepared on the host with the batch (``token_packing_host``):
         # no device-side bookkeeping, no host synchronisation in the step
@@ -491,7 +497,7 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
-    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order) if need_grad else None
+    saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order, inv) if need_grad else None
     return item, saved
 
 
@@ -500,7 +506,7 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     ``bert_model`` is, ``("layer", l)`` after layer ``l`` -- so a data-parallel driver can start reducing them while the
     rest of the backward pass still runs."""
     bm = prefix + "bert_model."
-    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order = saved
+    cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order, inv = saved
     n_layers = len(prep["layers"])
     dv = ops.act_bwd(d_item.contiguous(), pre, ACT_GELU)
     ops.colsum_(dv, grads[prefix + "fc.bias"])
@@ -542,13 +548,18 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     if grad_from >= 0:        # frozen embeddings: no embedding-LayerNorm backward, no word / position / type scatter
         return
     if tok_idx is not None:   # back to the padded layout the embedding stage (and its dropout stream) lives in: [PAD] rows get zero
-        pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
-        ops.indexed_rows_copy(da, pa, out_idx=tok_idx)
-        if db is not None:
-            pb = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
-            ops.indexed_rows_copy(db, pb, out_idx=tok_idx)
-            db = pb
-        da = pa
+        if inv is not None:     # one gather per tensor, [PAD] rows written as zeros (no fill)
+            da = ops.indexed_rows_copy(da, torch.empty((Nc * T, H), device=da.device, dtype=da.dtype), in_idx=inv)
+            if db is not None:
+                db = ops.indexed_rows_copy(db, torch.empty((Nc * T, H), device=da.device, dtype=da.dtype), in_idx=inv)
+        else:
+            pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
+            ops.indexed_rows_copy(da, pa, out_idx=tok_idx)
+            if db is not None:
+                pb = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
+                ops.indexed_rows_copy(db, pb, out_idx=tok_idx)
+                db = pb
+            da = pa
     dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
                                 p_out=drop.p_hidden, seed_out=drop.site(0))

@@ -272,7 +272,8 @@ int morec_scatter_add_rows(const void* d, const int32_t* idx, float* dtable, int
                            void* stream);
 /* strided row copy: out[r, :] = in[r*stride_rows, :]  (hidden[:, 0], T/model/encoders.py:69) and its
  * backward (scatter into a zero-filled [R*stride_rows, D]) */
-/* out[out_idx ? out_idx[r] : r, :] = in[in_idx ? in_idx[r] : r, :] for r < R (row gather / scatter; indices int32, device) */
+/* out[out_idx ? out_idx[r] : r, :] = in[in_idx ? in_idx[r] : r, :] for r < R (row gather / scatter; indices int32, device);
+ * in_idx[r] < 0 writes a zero row (the [PAD] rows when a packed token layout is spread back over the padded one) */
 int morec_indexed_rows_copy(const void* in, void* out, const int32_t* in_idx, const int32_t* out_idx, int R, int D, int dtype,
                             void* stream);
 int morec_strided_rows_copy(const void* in, void* out, int R, int D, int in_row_stride, int out_row_stride,

@@ -353,6 +353,17 @@ def test_bert_embed_bwd_shapes(dt, n_seq, T, H):
 
 
 @pytest.mark.parametrize("dt", DT)
+def test_indexed_rows_negative_gather_index_is_a_zero_row(dt):
+    src = rnd(50, 136, dt=dt)
+    idx = torch.randint(0, 50, (333,), device=DEV, dtype=torch.int32)
+    idx[::3] = -1
+    out = ops.indexed_rows_copy(src, torch.full((333, 136), 7.0, device=DEV, dtype=dt), in_idx=idx)
+    want = src[idx.clamp(min=0).long()]
+    want[idx < 0] = 0
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gather_scatter(dt):
     V, D, R = 500, 512, 333
     table = rnd(V, D)

@@ -103,8 +103,10 @@ def test_token_packing_host_equals_device_bookkeeping():
     assert torch.equal(cu_h, cu_d) and torch.equal(tok_h, tok_d)
     assert int(cu_h[-1]) == int(np.maximum(lens, 1).sum())
     ids = rng.integers(0, 40, (Nc, T))
-    cu_o, tok_o, order = engine.token_packing_host(mask, ids)
-    assert torch.equal(cu_o, cu_h) and torch.equal(tok_o, tok_h) and order.dtype == torch.int32
+    cu_o, tok_o, order, inv = engine.token_packing_host(mask, ids)
+    assert torch.equal(cu_o, cu_h) and torch.equal(tok_o, tok_h) and order.dtype == torch.int32 and inv.dtype == torch.int32
+    assert torch.equal(inv[tok_h.long()], torch.arange(tok_h.numel(), dtype=torch.int32))       # padded row -> packed row ...
+    assert int((inv >= 0).sum()) == tok_h.numel() and int(inv.min()) == -1                     # ... and -1 on every [PAD] row
     flat = ids.reshape(-1)
     assert sorted(order.tolist()) == list(range(Nc * T)) and (np.diff(flat[order.numpy()]) >= 0).all()      # a permutation that groups equal ids
     holes = mask.copy()

@@ -359,9 +359,9 @@ def test_host_token_packing_gives_the_same_step():
         T = items.shape[1] // 2
         pack = None
         if mode == "host":
-            cu, tok, order = engine.token_packing_host(items[:, T:], items[:, :T])
-            assert int(cu[-1]) < items.shape[0] * T           # the case under test is ragged
-            pack = (cu.to(DEV), tok.to(DEV), order.to(DEV))
+            hp = engine.token_packing_host(items[:, T:], items[:, :T])      # (cu_seqlens, packed rows, token-id order, padded -> packed)
+            assert len(hp) == 4 and int(hp[0][-1]) < items.shape[0] * T     # the case under test is ragged
+            pack = tuple(t.to(DEV) for t in hp)
         losses = [float(ts.step(tdev(ids).view(-1), tdev(items), tdev(lm), token_packing=pack)) for _ in range(2)]
         torch.cuda.synchronize()
         out[mode] = (losses, [g["arena"].data.clone() for g in ts.groups])
