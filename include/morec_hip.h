@@ -261,8 +261,10 @@ int morec_bert_embed_fwd(const int32_t* ids, const float* word, const float* pos
                          const float* gamma, const float* beta, float eps, void* z_out, void* y, float* mean,
                          float* rstd, int M, int T, int H, int dtype, float p_out, uint64_t seed_out, void* stream);
 /* scatter dz into dword[ids[m]] (skipping pad_id: nn.Embedding padding_idx), dpos[m % T], dtype0.
- * order (may be NULL): int32[M] permutation visiting the rows in ascending token id (argsort of ids); with it equal ids are
- * summed in registers before the atomic (one atomic per run instead of one per row). */
+ * order (may be NULL): int32[M] permutation of the rows in which EQUAL token ids are adjacent (argsort of ids); a run of equal
+ * ids is summed in registers, and a run that lies inside one wavefront's 32 rows is added to its table row by a plain
+ * read-modify-write (it is that row's only contribution), the others atomically.  An order that is not grouped by id is a
+ * caller error (lost updates); without order every row is added atomically. */
 int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* dword, float* dpos, float* dtype0, int pad_id,
                          int M, int T, int H, int dtype, const int32_t* order, void* stream);
 /* out[r, :] = table[idx[r], :]  (fp32 table -> dtype out).  T/model/model.py:37 nn.Embedding lookup. */
