@@ -32,6 +32,9 @@ bool ce8p_eligible(const morec_ce_desc* d);
 void ce8p_layout(const morec_ce_desc* d, Ce8Layout& L);
 int ce8p_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
              const uint8_t* col_valid, const uint8_t* row_valid, void* workspace, float** pmax, float** psum, float** pos, float** part, int* K2, hipStream_t s);
+// morec_gemm_tn with a choice of output type for the slab fold (gemm_tn.hip)
+int gemm_tn_launch(const void* DY, const void* X, void* C, int c_dtype, int M, int N, int K, int ldy, int ldx, int ldc, int dtype, int split_m,
+                   int accumulate, float* workspace, void* stream);
 int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
              const uint8_t* col_valid, const uint8_t* row_valid, const float* row_lse, const float* gscale_dev, float gscale, void* dP, void* dE,
              void* workspace, hipStream_t s);

@@ -154,8 +154,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
         }
     }
 }
-// C[n, k] (+)= sum_s slabs[s][n][k]   (deterministic split-m reduction; replaces 65k fp32 atomics per workgroup)
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ C, int N, int K,
+// C[n, k] (+)= sum_s slabs[s][n][k]   (deterministic split-m reduction; replaces 65k fp32 atomics per workgroup).  TO = bf16: the sum
+// is rounded once on the way out (overwrite only) -- the scoring backward's dP, which nothing reads in fp32.
+template <typename TO>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, TO* __restrict__ C, int N, int K,
                                                            int ldc, int nslab, int accumulate) {
     const size_t total4 = (size_t)N * K / 4;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
@@ -166,12 +168,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
             const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)t * N * K)[i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        float4* dst = reinterpret_cast<float4*>(C + (size_t)n * ldc + k);
-        if (accumulate) {
-            const float4 c = *dst;
-            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        if constexpr (sizeof(TO) == 4) {
+            float4* dst = reinterpret_cast<float4*>(C + (size_t)n * ldc + k);
+            if (accumulate) {
+                const float4 c = *dst;
+                s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            }
+            *dst = s;
+        } else {
+            const float o[4] = {s.x, s.y, s.z, s.w};
+            io<bf16>::store4(C + (size_t)n * ldc + k, o);
         }
-        *dst = s;
     }
 }
 }  // namespace
@@ -180,14 +187,15 @@ extern "C" size_t morec_gemm_tn_workspace_bytes(int N, int K, int split_m) {
     return split_m > 1 ? (size_t)split_m * N * K * sizeof(float) : 0;
 }
 
-extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc,
-                             int dtype, int split_m, int accumulate, float* workspace, void* stream) {
+// c_dtype = MOREC_BF16: only with slabs (split_m > 1 + workspace) and accumulate == 0 -- the fold writes the rounded sum.
+int gemm_tn_launch(const void* DY, const void* X, void* C, int c_dtype, int M, int N, int K, int ldy, int ldx, int ldc, int dtype, int split_m,
+                   int accumulate, float* workspace, void* stream) {
     if (!DY || !X || !C || M <= 0 || N <= 0 || K <= 0) return MOREC_E_ARG;
     if (dtype != MOREC_BF16) return MOREC_E_UNSUPPORTED;   // the exact-fp32 path uses transposed copies + morec_gemm_nt
     if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldc % 4 || !aligned16(DY) || !aligned16(X) || !aligned16(C)) return MOREC_E_ALIGN;
-    if (split_m > 1 && !accumulate) return MOREC_E_ARG;
+    if (split_m > 1 && !accumulate && !workspace) return MOREC_E_ARG;      // the atomic path needs a caller-zeroed C
     TnArgs a;
-    a.DY = reinterpret_cast<const bf16*>(DY); a.X = reinterpret_cast<const bf16*>(X); a.C = C;
+    a.DY = reinterpret_cast<const bf16*>(DY); a.X = reinterpret_cast<const bf16*>(X); a.C = reinterpret_cast<float*>(C);
     a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.ldc = ldc; a.atomic = accumulate ? 1 : 0;
     const int split = split_m < 1 ? 1 : split_m;
     int mchunk = (M + split - 1) / split;
@@ -197,11 +205,13 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     a.tiles_n = (N + TC - 1) / TC; a.tiles_k = (K + TC - 1) / TC;
     a.slabs = (zs > 1 && workspace) ? workspace : nullptr;
     if (a.slabs && (K % 4 || !aligned16(workspace))) return MOREC_E_ALIGN;
+    if (c_dtype != MOREC_F32 && (!a.slabs || accumulate)) return MOREC_E_UNSUPPORTED;
+    if (zs > 1 && !a.slabs && !accumulate) return MOREC_E_ARG;
     int r8 = G8_NOT_TAKEN;
     if (a.slabs)                    // split-m partials -> slabs: the eight-phase kernel (gemm_tn8p.hip) when the launch is large enough
         r8 = gemm_tn8p_try_launch(a.DY, a.X, a.slabs, (size_t)N * K, M, N, K, ldy, ldx, K, mchunk, zs, reinterpret_cast<hipStream_t>(stream));
     else if (zs == 1 && !accumulate)
-        r8 = gemm_tn8p_try_launch(a.DY, a.X, C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, reinterpret_cast<hipStream_t>(stream));
+        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, reinterpret_cast<hipStream_t>(stream));
     if (r8 != G8_NOT_TAKEN && r8 != MOREC_OK) return r8;
     if (r8 == G8_NOT_TAKEN) {
         static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);   // thread-safe one-time set-up
@@ -213,9 +223,18 @@ extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int
     if (a.slabs) {
         const size_t total4 = (size_t)N * K / 4;
         const unsigned blocks = (unsigned)((total4 + 255) / 256 > 2048 ? 2048 : (total4 + 255) / 256);
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs, C, N,
-                           K, ldc, zs, accumulate ? 1 : 0);
+        if (c_dtype == MOREC_F32)
+            hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs, a.C, N,
+                               K, ldc, zs, accumulate ? 1 : 0);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel<bf16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs,
+                               reinterpret_cast<bf16*>(C), N, K, ldc, zs, 0);
         MOREC_CHECK_LAUNCH();
     }
     return MOREC_OK;
+}
+
+extern "C" int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc,
+                             int dtype, int split_m, int accumulate, float* workspace, void* stream) {
+    return gemm_tn_launch(DY, X, C, MOREC_F32, M, N, K, ldy, ldx, ldc, dtype, split_m, accumulate, workspace, stream);
 }

@@ -43,16 +43,28 @@ __host__ __device__ inline int lane_order(int c64) {
 }
 
 // ---- prep: tab[u][Ncp] flags and lpp[Ncp] = log2(e) * log-popularity, both in lane order per 64-column chunk (Ncp = tiles_n * 256)
+__device__ __forceinline__ void ce8p_pos_rows(const bf16* __restrict__ P, const bf16* __restrict__ E, const float* __restrict__ col_logpop,
+                                              const uint8_t* __restrict__ col_valid, float* __restrict__ pos, int u, int j, int S, int D, int col_offset);
+
+// blockIdx.y = user.  Blocks x < prep_blocks build the flag table / log-pop row; the blocks behind them compute the user's positive
+// logits (four rows each): one launch for the two independent pieces of bookkeeping.
 __global__ __launch_bounds__(256) void ce8p_prep_kernel(const int32_t* __restrict__ row_ids, const int32_t* __restrict__ col_ids,
                                                         const float* __restrict__ col_logpop, const uint8_t* __restrict__ col_valid,
-                                                        uint8_t* __restrict__ tab, float* __restrict__ lpp, int B, int S1, int Nc, int Ncp) {
+                                                        uint8_t* __restrict__ tab, float* __restrict__ lpp, int B, int S1, int Nc, int Ncp,
+                                                        int prep_blocks, const bf16* __restrict__ P, const bf16* __restrict__ E,
+                                                        float* __restrict__ pos, int D, int col_offset) {
     extern __shared__ int32_t s_uid[];                     // this user's S + 1 slot ids
     const int u = blockIdx.y;
+    if ((int)blockIdx.x >= prep_blocks) {
+        const int j = ((int)blockIdx.x - prep_blocks) * 4 + (int)(threadIdx.x >> 6);
+        if (j < S1 - 1) ce8p_pos_rows(P, E, col_logpop, col_valid, pos, u, j, S1 - 1, D, col_offset);
+        return;
+    }
     for (int i = threadIdx.x; i < S1; i += blockDim.x) s_uid[i] = row_ids[u * S1 + i];
     __syncthreads();
     // one thread per group of 4 consecutive columns (= 4 consecutive cells in lane order; Nc % 4 == 0: a group is all inside the pool
     // or all past it): 16-byte loads of the ids / log-pop, one 4-byte table store
-    for (int c = 4 * (blockIdx.x * blockDim.x + threadIdx.x); c < Ncp; c += 4 * gridDim.x * blockDim.x) {
+    for (int c = 4 * (blockIdx.x * blockDim.x + threadIdx.x); c < Ncp; c += 4 * prep_blocks * blockDim.x) {
         uint32_t f4 = 0;
         float4 lp = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);   // past the pool: x2 = fma(acc, log2 e, -inf) = -inf (weight 0, never the maximum)
         if (c < Nc) {
@@ -80,13 +92,11 @@ __global__ __launch_bounds__(256) void ce8p_prep_kernel(const int32_t* __restric
 // The positive logit of every row, pos[m] = P[m] . E[label(m)] - log pop (model.py:45-50; -1e4 when the label's column is a padding
 // slot, :51-52 -- only on rows that are dropped anyway): one wavefront per row.  Separate from the tile kernel so that its inner loop
 // carries no "is this my label" select per cell; the forward needs it for loss = lse - pos, the backward for the one cell per row
-// whose gradient is softmax - 1.
-__global__ __launch_bounds__(256) void ce8p_pos_kernel(const bf16* __restrict__ P, const bf16* __restrict__ E, const float* __restrict__ col_logpop,
-                                                       const uint8_t* __restrict__ col_valid, float* __restrict__ pos, int Nr, int S, int D, int col_offset) {
+// whose gradient is softmax - 1.  Runs in the tail blocks of ce8p_prep_kernel.
+__device__ __forceinline__ void ce8p_pos_rows(const bf16* __restrict__ P, const bf16* __restrict__ E, const float* __restrict__ col_logpop,
+                                              const uint8_t* __restrict__ col_valid, float* __restrict__ pos, int u, int j, int S, int D, int col_offset) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Nr) return;
-    const int u = row / S, j = row - u * S;
+    const int row = u * S + j;
     const int lab = col_offset + u * (S + 1) + j + 1;
     const bf16* p = P + (size_t)row * D;
     const bf16* e = E + (size_t)lab * D;
@@ -356,13 +366,13 @@ void ce8p_layout(const morec_ce_desc* d, Ce8Layout& L) {
 
 static int ce8p_prep(const morec_ce_desc* d, const Ce8Layout& L, char* ws, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids,
                      const float* col_logpop, const uint8_t* col_valid, hipStream_t s) {
-    const int S1 = d->S + 1, Nr = d->B * d->S;
-    hipLaunchKernelGGL(ce8p_pos_kernel, dim3((Nr + 3) / 4), dim3(256), 0, s, reinterpret_cast<const bf16*>(P), reinterpret_cast<const bf16*>(E),
-                       col_logpop, col_valid, reinterpret_cast<float*>(ws + L.off_pos), Nr, d->S, d->D, d->col_offset);
-    MOREC_CHECK_LAUNCH();
-    dim3 grid((L.Ncp / 4 + 255) / 256, d->B);
+    const int S1 = d->S + 1;
+    const int prep_blocks = (L.Ncp / 4 + 255) / 256;
+    dim3 grid(prep_blocks + (d->S + 3) / 4, d->B);
     hipLaunchKernelGGL(ce8p_prep_kernel, grid, dim3(256), S1 * sizeof(int32_t), s, row_ids, col_ids, col_logpop, col_valid,
-                       reinterpret_cast<uint8_t*>(ws + L.off_tab), reinterpret_cast<float*>(ws + L.off_lpp), d->B, S1, d->Nc, L.Ncp);
+                       reinterpret_cast<uint8_t*>(ws + L.off_tab), reinterpret_cast<float*>(ws + L.off_lpp), d->B, S1, d->Nc, L.Ncp, prep_blocks,
+                       reinterpret_cast<const bf16*>(P), reinterpret_cast<const bf16*>(E), reinterpret_cast<float*>(ws + L.off_pos), d->D,
+                       d->col_offset);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -432,10 +442,11 @@ int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t
     rc = morec_gemm_nt(&g, a.dlt, Pt, dE, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     // dP[Nr, D] = sum_c dlt[c, r] E[c, d]: the transposing GEMM, contraction over the Nc columns cut into tn_split chunks
+    if (L.tn_split > 1)      // the slab fold rounds the sum straight into dP: no zero-fill, no fp32 copy, no conversion pass
+        return gemm_tn_launch(a.dlt, E, dP, MOREC_BF16, Nc, Nr, D, L.ldr, D, D, MOREC_BF16, L.tn_split, 0, reinterpret_cast<float*>(ws + L.off_slabs),
+                              stream);
     float* dP32 = reinterpret_cast<float*>(ws + L.off_dp32);
-    if (L.tn_split > 1) (void)hipMemsetAsync(dP32, 0, (size_t)Nr * D * sizeof(float), s);
-    rc = morec_gemm_tn(a.dlt, E, dP32, Nc, Nr, D, L.ldr, D, D, MOREC_BF16, L.tn_split, L.tn_split > 1 ? 1 : 0,
-                       L.tn_split > 1 ? reinterpret_cast<float*>(ws + L.off_slabs) : nullptr, stream);
+    rc = morec_gemm_tn(a.dlt, E, dP32, Nc, Nr, D, L.ldr, D, D, MOREC_BF16, 1, 0, nullptr, stream);
     if (rc) return rc;
     return morec_cast(dP32, dP, (size_t)Nr * D, MOREC_F32, MOREC_BF16, stream);
 }

@@ -105,8 +105,9 @@ int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, const void* B,
                          void* aux_out, const void* dact_in, float* colsum_out, float* workspace, void* stream);
 
 /* Weight-gradient GEMM without transposed copies (bf16 only; MOREC_E_UNSUPPORTED otherwise):
- * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z and requires
- * accumulate != 0 (fp32 atomicAdd into a caller-zeroed C).  Autograd backward of nn.Linear: dW = dY^T X. */
+ * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z; without a workspace that
+ * requires accumulate != 0 (fp32 atomicAdd into a caller-zeroed C), with one the partial tiles are folded by a second kernel and
+ * accumulate == 0 overwrites C.  Autograd backward of nn.Linear: dW = dY^T X. */
 int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc, int dtype,
                   int split_m, int accumulate, float* workspace, void* stream);
 /* workspace (optional, fp32): morec_gemm_tn_workspace_bytes(N, K, split_m).  With it the split-m partial tiles are written

@@ -167,9 +167,9 @@ def test_gemm_tn8p_absolute(M, N, K, accumulate):
     x = (torch.randn(M, K, device=DEV, generator=g) * SCALE).to(BF)
     base = torch.randn(N, K, device=DEV, generator=g) if accumulate else torch.full((N, K), 7.0, device=DEV)
     out = base.clone()
-    # accumulate (what the engines do: += into the gradient arena) with the split over tokens the engines pick for this shape;
-    # overwrite mode exists for an unsplit launch only (include/morec_hip.h: split_m > 1 requires accumulate != 0)
-    split = _splitk(N, K, M) if accumulate else 1
+    # accumulate (what the engines do: += into the gradient arena) and overwrite, both with the split over tokens the engines pick for
+    # this shape (the slab fold overwrites or adds; only the workspace-less atomic path needs accumulate != 0: include/morec_hip.h)
+    split = _splitk(N, K, M)
     ops.gemm_tn_(dy, x, out, split_m=split, accumulate=accumulate)
     want = dy.double().t() @ x.double() + (base.double() if accumulate else 0.0)
     sigma = SCALE * SCALE * math.sqrt(M)
@@ -177,6 +177,9 @@ def test_gemm_tn8p_absolute(M, N, K, accumulate):
     out2 = base.clone()
     ops.gemm_tn_(dy, x, out2, split_m=split, accumulate=accumulate)
     assert torch.equal(out, out2), "slab fold is not deterministic"
+    if not accumulate and split > 1:      # overwrite without a workspace would race between the token chunks: refused
+        with pytest.raises(RuntimeError):
+            ops.gemm_tn_(dy, x, out2, split_m=split, accumulate=False, slabs=False)
 
 
 def test_gemm8p_tail_split_absolute():
