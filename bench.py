@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--bert", default="base")
     ap.add_argument("--tower", default="text", help="text (BASELINE.json metric: BERT item encoder) | swin_tiny | swin_base | swin_micro "
                     "(vision configs of BASELINE.json: Swin item encoder, S=10, D=2048, 224x224 images; default --batch 64)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -203,6 +203,13 @@ def main():
         # uploaded with the batch (no device-side bookkeeping, no host synchronisation inside the step)
         pack = None if (vision or id_tower or a.padded) else _engine.token_packing_host(content[ids_all[i].reshape(-1), T:], content[ids_all[i].reshape(-1), :T])
         host.append((ids, items, lm, pack))
+    # Warm-up batch 0 = a copy of the TIMED batch with the most real tokens (the timed set itself is untouched): activation buffers
+    # are sized by the batch's token count and the caching allocator cannot reuse a smaller block for a larger request, so the first
+    # batch that is larger than everything before it costs fresh hipMallocs (and, near the reservation limit, a cache flush: one
+    # 300-ms step in a short timed region).  With the largest one seen during warm-up every later request is a cache hit.
+    if a.warmup >= 1 and host and host[0][3] is not None and os.environ.get("MOREC_BENCH_PRIME", "1") != "0":
+        j = max(range(a.warmup, n_batches), key=lambda i: int(host[i][3][1].numel()))
+        host[0] = host[j]
     if vision:
         gen = torch.Generator(device=dev).manual_seed(4321)
         catalog = torch.randn((a.item_num + 1, 3, vshape.image_size, vshape.image_size), device=dev, generator=gen)
@@ -409,44 +416,57 @@ def main():
 
     # secondary line (never `value`): the same step in the PARITY mode (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32 -- the mode the
     # reference goldens pin at 1e-4 on the loss), so that the price of reference-level numerics is a measured number
-    fp32_info = None
+    fp32_info = fp32x3_info = None
     main_gemm_log = list(gemm_log)
     main_ce_log, main_ce_shapes = list(ce_log), list(ce_shapes)
     if not vision and not id_tower and a.dtype == "bf16" and not a.no_secondary and world == 1:
-        try:
-            args32 = types.SimpleNamespace(**dict(vars(args), compute_dtype="fp32"))
-            torch.manual_seed(12345)
-            model32 = Model(args32, a.item_num, True, HipBertModel(shape), pop).to(dev)
-            model32.train()
+        def fp32_mode_line(mode):
+            nonlocal ts
+            info = None
             saved = (ts, )
-            ts32 = TrainStep(model32, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False)
-            ts = ts32                      # run_step closes over `ts`
-            n32 = max(2, min(4, a.steps))
-            run_step(0)
-            torch.cuda.synchronize()
-            del gemm_log[:]
-            timing_on["v"] = True
-            t1 = time.perf_counter()
-            for i in range(n32):
-                run_step(a.warmup + i % a.steps)
-            torch.cuda.synchronize()
-            dt32 = time.perf_counter() - t1
-            timing_on["v"] = False
-            fl32 = sum(g_[0] for g_ in gemm_log)
-            ms32 = sum(g_[1].elapsed_time(g_[2]) for g_ in gemm_log)
-            tf32 = fl32 / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
-            fp32_info = {"ms_per_step": round(dt32 / n32 * 1e3, 2), "user_seq_per_s": round(a.batch * n32 / dt32, 2), "steps": n32,
-                         "gemm_tflops": round(tf32, 1), "mfma_f32_peak": MFMA_PEAK_TFLOPS["f32"],
-                         "frac_of_f32_mfma_peak": round(tf32 / MFMA_PEAK_TFLOPS["f32"], 4),
-                         "note": "compute_dtype=fp32: every GEMM on exact-fp32 MFMA; the mode whose loss matches the reference goldens "
-                                 "to < 1e-4 (tests/test_model_gpu.py g6). tests/test_bench_mode_parity_gpu.py bounds the bf16 mode "
-                                 "against it at this configuration: step-0 loss 3e-2 (measured 1.3e-3 ... 1.5e-2: rounding-pattern dependent), gradient norms 5e-2 (measured 0.6e-2 ... 2.3e-2), 20-step loss curve 2 % (measured 0.9 %)"}
+            try:
+                args32 = types.SimpleNamespace(**dict(vars(args), compute_dtype=mode))
+                torch.manual_seed(12345)
+                model32 = Model(args32, a.item_num, True, HipBertModel(shape), pop).to(dev)
+                model32.train()
+                ts32 = TrainStep(model32, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False)
+                ts = ts32                      # run_step closes over `ts`
+                n32 = max(2, min(4, a.steps))
+                for _ in range(3 if mode == "fp32x3" else 1):      # fp32x3 holds ~90 GB of splits per step: let the caching allocator reach its size first
+                    run_step(0)
+                torch.cuda.synchronize()
+                del gemm_log[:]
+                timing_on["v"] = True
+                t1 = time.perf_counter()
+                for i in range(n32):
+                    run_step(a.warmup + i % a.steps)
+                torch.cuda.synchronize()
+                dt32 = time.perf_counter() - t1
+                timing_on["v"] = False
+                fl32 = sum(g_[0] for g_ in gemm_log)
+                ms32 = sum(g_[1].elapsed_time(g_[2]) for g_ in gemm_log)
+                info = {"ms_per_step": round(dt32 / n32 * 1e3, 2), "user_seq_per_s": round(a.batch * n32 / dt32, 2), "steps": n32}
+                if mode == "fp32":
+                    tf32 = fl32 / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+                    info.update({"gemm_tflops": round(tf32, 1), "mfma_f32_peak": MFMA_PEAK_TFLOPS["f32"],
+                                 "frac_of_f32_mfma_peak": round(tf32 / MFMA_PEAK_TFLOPS["f32"], 4),
+                                 "note": "compute_dtype=fp32: every GEMM on exact-fp32 MFMA; the mode whose loss matches the reference goldens "
+                                         "to < 1e-4 (tests/test_model_gpu.py g6). tests/test_bench_mode_parity_gpu.py bounds the bf16 mode "
+                                         "against it at this configuration: step-0 loss 3e-2 (measured 1.3e-3 ... 1.5e-2: rounding-pattern dependent), gradient norms 5e-2 (measured 0.6e-2 ... 2.3e-2), 20-step loss curve 2 % (measured 0.9 %)"}) 
+                else:
+                    info["note"] = ("compute_dtype=fp32x3: fp32 tensors, every GEMM as ONE bf16 MFMA product over hi / lo splits of both operands "
+                                    "(morec_split_bf16x3, K' = 3 K, fp32 accumulation; the lo.lo term, 2^-16 relative, dropped): against the exact-fp32 "
+                                    "mode step-0 loss 5e-7 relative, gradient norms 4e-5, loss curve 1e-5 (tests/test_fp32x3_gpu.py asserts 2e-4 / 1e-3 / "
+                                    "1e-3) -- inside north_star's 1e-3, which the bf16 mode is not")
+                del ts32, model32
+            except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
+                info = {"error": f"{type(e).__name__}: {e}"}
+                timing_on["v"] = False
             (ts, ) = saved
-            del ts32, model32
             torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
-            fp32_info = {"error": f"{type(e).__name__}: {e}"}
-            timing_on["v"] = False
+            return info
+        fp32_info = fp32_mode_line("fp32")
+        fp32x3_info = fp32_mode_line("fp32x3")
         gemm_log[:] = main_gemm_log
         ce_log[:] = main_ce_log
         ce_shapes[:] = main_ce_shapes
@@ -564,6 +584,7 @@ def main():
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
     if fp32_info is not None:
         out["fp32_parity_mode"] = fp32_info
+        out["fp32x3_mode"] = fp32x3_info
         out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 3e-2, gradient norms 5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 ... 1.5e-2 depending on the GEMM summation order / 0.6e-2 ... 2.3e-2 / 0.9 %)"
     if a.dedup:
         out["config"]["item_dedup"] = True

@@ -66,6 +66,7 @@ _SIGS = {
     "morec_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_transpose_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "morec_split_bf16x3": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,

@@ -299,10 +299,7 @@ template <typename G, typename TI, typename TO>
 static int launch_gemm_cfg(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     const int mode = d->dact == MOREC_ACT_GELU ? 3 : d->dact == MOREC_ACT_RELU ? 4 : d->dact == MOREC_DACT_MUL ? 5
                      : d->act == MOREC_ACT_GELU ? 1 : d->act == MOREC_ACT_RELU ? 2 : 0;
-    if constexpr (sizeof(TI) != sizeof(TO)) {     // bf16 operands -> fp32 output: only the linear epilogue is used
-        if (mode != 0 || a.colsum) return MOREC_E_UNSUPPORTED;
-        return launch_gemm_act<G, TI, TO, 0>(d, a, s);
-    } else {
+    {   // (bf16 operands -> fp32 output carries every epilogue as well: the fp32x3 mode's GEMMs, include/morec_hip.h morec_split_bf16x3)
         if (a.colsum) {     // fused bias gradient: only behind the activation-derivative epilogues
             if (mode == 3) return launch_gemm_act<G, TI, TO, 3, true>(d, a, s);
             if (mode == 4) return launch_gemm_act<G, TI, TO, 4, true>(d, a, s);
@@ -520,6 +517,42 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, siz
         io<TI>::load4(in + i * 4, v);
         io<TO>::store4(out + i * 4, v);
     }
+}
+
+// out[r] = [ hi(in[r]) | s1 | s2 ] (bf16, 3 C columns): hi = bf16(x), lo = bf16(x - hi); slot lo_slot (1 or 2) holds lo, the other one
+// hi again.  An NT product of an A-side row block (lo_slot 2: hi | hi | lo) with a B-side one (lo_slot 1: hi | lo | hi) over 3 C is
+// hi.hi + hi.lo + lo.hi in the MFMA's fp32 accumulators: the fp32 product up to the lo.lo term (2^-16 relative) -- three bf16 MFMA
+// passes instead of the 1/16-rate exact-fp32 MFMA.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ in, bf16* __restrict__ out, int R, int Cc, int ld_in,
+                                                           int ld_out, int lo_slot) {
+    const int c4 = Cc / 4;
+    const size_t total = (size_t)R * c4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4), c = (int)(i - (size_t)r * c4) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(in + (size_t)r * ld_in + c);
+        const float v[4] = {x.x, x.y, x.z, x.w};
+        float hi[4], lo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hi[k] = bf2f(f2bf(v[k]));
+            lo[k] = v[k] - hi[k];
+        }
+        bf16* o = out + (size_t)r * ld_out + c;
+        io<bf16>::store4(o, hi);
+        io<bf16>::store4(o + (size_t)(lo_slot == 1 ? 2 : 1) * Cc, hi);
+        io<bf16>::store4(o + (size_t)lo_slot * Cc, lo);
+    }
+}
+
+extern "C" int morec_split_bf16x3(const float* in, void* out, int R, int C, int ld_in, int ld_out, int lo_slot, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0 || (lo_slot != 1 && lo_slot != 2)) return MOREC_E_ARG;
+    if (C % 4 || ld_in % 4 || ld_out % 4 || ld_in < C || ld_out < 3 * C || !aligned16(in) || (reinterpret_cast<uintptr_t>(out) & 7u)) return MOREC_E_ALIGN;
+    const size_t total = (size_t)R * (C / 4);
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, reinterpret_cast<bf16*>(out), R, C,
+                       ld_in, ld_out, lo_slot);
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
 }
 
 extern "C" int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream) {

@@ -136,6 +136,22 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
         WgradStream._keep.setdefault(dy.device, []).extend((dy, x))
         WgradStream._dirty.add(dy.device)
         return None, None
+    if (dy.dtype == torch.float32 and ops.FP32_GEMM == "bf16x3" and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+            and dy.is_contiguous() and x.is_contiguous()):
+        # fp32x3 mode: the [hi | hi | lo] splits the dX product / the forward product of the same tensors have already made, three
+        # transposing bf16 GEMMs (no transposed copies), on the weight-gradient stream like the bf16 path
+        M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+        dy3, x3 = ops.split_cached(dy), ops.split_cached(x)
+        side = WgradStream.get(dy.device)
+        if side is None:
+            ops.gemm_tn_x3_(dy3, x3, dw, N, K, split_m=_splitk(N, K, M))
+            return None, None
+        side.wait_stream(torch.cuda.current_stream(dy.device))
+        with torch.cuda.stream(side):
+            ops.gemm_tn_x3_(dy3, x3, dw, N, K, split_m=_splitk(N, K, M))
+        WgradStream._keep.setdefault(dy.device, []).extend((dy3, x3))
+        WgradStream._dirty.add(dy.device)
+        return None, None
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt
     N, K, Mp = dyt.shape[0], xt.shape[0], dyt.shape[1]

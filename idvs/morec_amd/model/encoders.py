@@ -15,9 +15,17 @@ from .modules import TransformerEncoder
 
 
 def resolve_dtype(args=None) -> torch.dtype:
-    """Compute dtype: ``args.compute_dtype`` > env ``MOREC_DTYPE`` > bf16.  'fp32' = exact-fp32 MFMA (parity mode)."""
+    """Compute dtype: ``args.compute_dtype`` > env ``MOREC_DTYPE`` > bf16.  'fp32' = exact-fp32 MFMA (parity mode); 'fp32x3' = fp32
+    tensors everywhere, the GEMMs as three bf16 MFMA passes over hi / lo splits of both operands (``resolve_fp32_gemm``)."""
     name = getattr(args, "compute_dtype", None) or os.environ.get("MOREC_DTYPE", "bf16")
-    return {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[str(name)]
+    return {"fp32": torch.float32, "float32": torch.float32, "fp32x3": torch.float32, "bf16": torch.bfloat16,
+            "bfloat16": torch.bfloat16}[str(name)]
+
+
+def resolve_fp32_gemm(args=None) -> str:
+    """How products of fp32 operands run for this model: ``ops.FP32_GEMM`` value ("exact" | "bf16x3")."""
+    name = getattr(args, "compute_dtype", None) or os.environ.get("MOREC_DTYPE", "bf16")
+    return "bf16x3" if str(name) == "fp32x3" else "exact"
 
 
 class User_Encoder(nn.Module):

@@ -8,9 +8,9 @@ import torch.distributed as dist
 from torch import nn
 from torch.nn.init import xavier_normal_
 
-from .. import engine
+from .. import engine, ops
 from .. import functional as F_
-from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, Vit_Encoder, resolve_dtype
+from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, Vit_Encoder, resolve_dtype, resolve_fp32_gemm
 
 
 class Model(nn.Module):
@@ -20,6 +20,7 @@ class Model(nn.Module):
         self.use_modal = use_modal
         self.max_seq_len = args.max_seq_len
         self.compute_dtype = resolve_dtype(args)
+        self.fp32_gemm = resolve_fp32_gemm(args)                      # "exact" | "bf16x3": how fp32 GEMMs run (ops.FP32_GEMM)
         self.pop_prob_list = torch.FloatTensor(pop_prob_list)        # plain attribute, as in T/model/model.py:14
         self._log_pop = None                                          # log(pop) table, built once per device
         # pooled negatives across ranks; off = the reference's rank-local negatives
@@ -71,6 +72,8 @@ class Model(nn.Module):
         return self._log_pop
 
     def forward(self, sample_items_id, sample_items, log_mask, local_rank=None):
+        ops.FP32_GEMM = self.fp32_gemm
+        ops.x3_cache_clear()
         D = self.args.embedding_dim
         ids = sample_items_id.view(-1)
         d_item, d_user = self.dropout_cfgs()

@@ -43,6 +43,62 @@ def pad8(n: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------------
+# How products of fp32 operands run: "exact" = the exact-fp32 MFMA (the parity mode pinned to the reference goldens), "bf16x3" = both
+# operands split into bf16 hi / lo parts and ONE bf16 GEMM over [hi | hi | lo] x [hi | lo | hi] (fp32 accumulation; the lo.lo term,
+# 2^-16 relative, is dropped).  Set per step / forward by whoever owns the model (``compute_dtype`` "fp32" / "fp32x3").
+FP32_GEMM = "exact"
+
+
+def split_bf16x3(t, lo_slot, rows=None, cols=None, ld=None):
+    """fp32 [R, C] (row pitch ``ld``) -> bf16 [R, 3 C]: hi | hi | lo (``lo_slot`` 2, A side) or hi | lo | hi (``lo_slot`` 1, B side)."""
+    R = t.shape[0] if rows is None else rows
+    Cc = t.shape[1] if cols is None else cols
+    ld = t.stride(0) if ld is None else ld
+    out = torch.empty((R, 3 * Cc), device=t.device, dtype=torch.bfloat16)
+    check(_lib.lib().morec_split_bf16x3(_p(t), _p(out), R, Cc, ld, 3 * Cc, lo_slot, _stream()), "morec_split_bf16x3")
+    return out
+
+
+# hi | hi | lo splits of whole activation tensors, kept for the length of one step: the forward's split of x is what the weight-gradient
+# product of the same x needs again, the dX product's split of dY likewise.  An entry holds a reference to its source (so the address
+# cannot be recycled under it) and the source's version counter (an in-place write invalidates it).
+_X3_CACHE = {}
+
+
+def x3_cache_clear():
+    _X3_CACHE.clear()
+
+
+def split_cached(t):
+    """``split_bf16x3(t, 2)`` ([hi | hi | lo], bf16 [R, 3 C]) of a whole contiguous fp32 tensor, computed once per step."""
+    key = id(t)
+    hit = _X3_CACHE.get(key)
+    if hit is not None and hit[0] is t and hit[1] == t._version:
+        return hit[2]
+    s = split_bf16x3(t, 2)
+    _X3_CACHE[key] = (t, t._version, s)
+    return s
+
+
+def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1):
+    """out[N, K] += dy^T x for fp32 dy [M, N], x [M, K] given as their [hi | hi | lo] splits (bf16 [M, 3 N], [M, 3 K]): the three
+    products hi.hi + hi.lo + lo.hi on the transposing bf16 GEMM, reading the column blocks in place (row pitch 3 N / 3 K)."""
+    _dev(dy3), _dev(x3)
+    M = dy3.shape[0]
+    ws = None
+    if split_m > 1:
+        need = _lib.lib().morec_gemm_tn_workspace_bytes(N, K, split_m) // 4
+        ws = _TN_WS.get(dy3.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 20 * 1024 * 1024), device=dy3.device, dtype=torch.float32)
+            _TN_WS[dy3.device] = ws
+    py, px = dy3.data_ptr(), x3.data_ptr()
+    for sy, sx in ((0, 0), (0, 2), (2, 0)):      # (hi, hi), (hi, lo), (lo, hi)
+        check(_lib.lib().morec_gemm_tn(C.c_void_p(py + 2 * sy * N), C.c_void_p(px + 2 * sx * K), _p(out), M, N, K, 3 * N, 3 * K, out.stride(0),
+                                       BF16, split_m, 1, _p(ws), _stream()), "morec_gemm_tn")
+    return out
+
+
 _CS_WS = {}      # per-device fp32 scratch of the fused column sums (stream-ordered reuse, like _TN_WS)
 
 
@@ -60,6 +116,11 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype or a.dtype)
     ldc = out.stride(0) if ldc is None else ldc
+    if FP32_GEMM == "bf16x3" and a.dtype == torch.float32 and b.dtype == torch.float32 and K % 8 == 0:
+        whole = a.dim() == 2 and a.is_contiguous() and M == a.shape[0] and K == a.shape[1] and lda == K
+        a = split_cached(a) if whole else split_bf16x3(a, 2, M, K, lda)
+        b = split_bf16x3(b, 1, N, K, ldb)
+        K, lda, ldb = 3 * K, 3 * K, 3 * K
     d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
     if colsum_out is not None:
         need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4

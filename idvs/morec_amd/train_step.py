@@ -338,6 +338,8 @@ class TrainStep:
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
+        ops.FP32_GEMM = getattr(m, "fp32_gemm", "exact")
+        ops.x3_cache_clear()
         # Nothing in the FORWARD pass reads the gradient arenas or the W^T copies (dX = dY W): zero / refresh them on the side stream,
         # under the forward GEMMs (HBM-bound fills next to MFMA-bound kernels), and let the main stream wait for them right before
         # the backward pass starts.
@@ -416,6 +418,7 @@ class TrainStep:
         else:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
         engine.WgradStream.join(self.device)       # the weight gradients of the side stream are final from here on
+        ops.x3_cache_clear()
         return loss_sum[0] / n_valid
 
     def _prepare_step_buffers(self):

@@ -136,6 +136,12 @@ typedef struct {
 int morec_transpose_batch(const morec_transpose_item* items, int n_items, int n_tiles, int dtype, void* stream);
 /* elementwise convert n elements */
 int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype, void* stream);
+/* fp32 rows -> bf16 rows of three column blocks for an fp32-accurate product on the bf16 matrix cores ("bf16x3"):
+ * out[r, 0:C] = hi = bf16(in[r, :]); block lo_slot (1 or 2) = lo = bf16(in - hi); the remaining block = hi again.  With
+ * A3 = split(A, lo_slot 2) = [hi | hi | lo] and B3 = split(B, lo_slot 1) = [hi | lo | hi], morec_gemm_nt(A3, B3) over K' = 3 C is
+ * A.B^T up to the lo.lo term (2^-16 relative), accumulated in fp32 -- the numerics of torch's fp32 nn.Linear (T/model/modules.py:14)
+ * to ~1e-5 at three bf16 MFMA passes instead of the 1/16-rate exact-fp32 MFMA.  C % 4 == 0, ld_in >= C, ld_out >= 3 C. */
+int morec_split_bf16x3(const float* in, void* out, int R, int C, int ld_in, int ld_out, int lo_slot, void* stream);
 /* out = dy * act'(pre), elementwise (act = MOREC_ACT_GELU | MOREC_ACT_RELU); T/model/encoders.py:70 backward */
 int morec_act_bwd(const void* dy, const void* pre, void* out, size_t n, int act, int dtype, void* stream);
 /* out[n] = sum_m in[m, n]  (bias gradients), atomically accumulated into fp32 out */

@@ -1,0 +1,116 @@
+"""-m gpu: the ``fp32x3`` mode -- fp32 tensors everywhere, every GEMM as ONE bf16 MFMA product over hi / lo splits of both operands
+(``morec_split_bf16x3`` + ``morec_gemm_nt`` over K' = 3 K, fp32 accumulation; include/morec_hip.h) -- against (a) the exact product,
+next to the exact-fp32 MFMA's own error, (b) the exact-fp32 PARITY mode (the one pinned to the reference goldens) on a BERT-base step
+at B = 16: step-0 loss, gradient norms, a short loss curve.  Stated tolerance of the mode (asserted, measured values printed):
+products 4e-5 of the operand scale product x sqrt(K) (the exact-fp32 MFMA: 0.8 - 1.2e-5); step-0 loss 2e-4 relative, gradient norms 1e-3, 6-step curve 1e-3 relative --
+i.e. inside north_star's 1e-3 on the loss, which the bf16 mode is not."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_split_reconstructs_fp32_to_16_bits():
+    from idvs.morec_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(333, 520, device=DEV, generator=g) * torch.logspace(-6, 6, 520, device=DEV)
+    for lo_slot in (1, 2):
+        s = ops.split_bf16x3(x, lo_slot).float().view(333, 3, 520)
+        hi, lo = s[:, 0], s[:, lo_slot]
+        assert torch.equal(s[:, 3 - lo_slot], hi)
+        assert torch.equal(hi, x.to(torch.bfloat16).float())                      # round-to-nearest-even high part
+        assert float(((hi + lo - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    # a strided source and explicit extents (what gemm_nt passes for views)
+    s = ops.split_bf16x3(x, 2, rows=100, cols=256, ld=x.stride(0))
+    assert s.shape == (100, 768) and torch.equal(s[:, :256].float(), x[:100, :256].to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (2111, 512, 3072), (300, 96, 96)])
+def test_bf16x3_product_against_the_exact_one(M, N, K):
+    from idvs.morec_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a, b = torch.randn(M, K, device=DEV, generator=g), torch.randn(N, K, device=DEV, generator=g) * 0.05
+    bias = torch.randn(N, device=DEV, generator=g)
+    exact = a.double() @ b.double().t() + bias.double()
+    sigma = 0.05 * np.sqrt(K)
+    try:
+        ops.FP32_GEMM = "exact"
+        e_exact = float((ops.gemm_nt(a, b, bias=bias).double() - exact).abs().max()) / sigma
+        ops.FP32_GEMM = "bf16x3"
+        out = ops.gemm_nt(a, b, bias=bias)
+        assert out.dtype == torch.float32
+        e_x3 = float((out.double() - exact).abs().max()) / sigma
+    finally:
+        ops.FP32_GEMM = "exact"
+    print(f"{M}x{N}x{K}: max |error| / (scale sqrt K): exact-fp32 MFMA {e_exact:.2e}, bf16x3 {e_x3:.2e}")
+    assert e_x3 < 4e-5 and e_exact < 2e-5
+
+
+def _build(dtype, shape, item_num, pop, S, T, D, state=None):
+    from idvs.morec_amd.model import HipBertModel, Model
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_base", word_embedding_dim=shape.hidden_size, compute_dtype=dtype)
+    torch.manual_seed(12345)
+    m = Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), pop)
+    if state is not None:
+        m.load_state_dict(state)
+    return m.to(DEV).train()
+
+
+def test_fp32x3_step_tracks_the_exact_fp32_parity_mode():
+    import bench
+    from idvs.morec_amd import ops
+    from idvs.morec_amd.model import BertShape
+    from idvs.morec_amd.train_step import TrainStep
+    B, S, T, D, item_num, steps = 16, 20, 30, 512, 5000, 6
+    shape = BertShape.named("base")
+    content = bench.synth_catalog(item_num, T, np.random.default_rng(12345))
+    ids_all = bench.synth_batches(steps, B, S, item_num, np.random.default_rng(13345))
+    counts = np.bincount(ids_all.reshape(-1), minlength=item_num + 1).astype(np.float64) + 1.0
+    pop = counts / counts[1:].sum()
+    pop[0] = 1.0
+    m32 = _build("fp32", shape, item_num, pop, S, T, D)
+    state = {k: v.detach().cpu().clone() for k, v in m32.state_dict().items()}
+    mx3 = _build("fp32x3", shape, item_num, pop, S, T, D, state)
+    assert m32.fp32_gemm == "exact" and mx3.fp32_gemm == "bf16x3" and mx3.compute_dtype == torch.float32
+    kw = dict(lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False)
+
+    def batch(i):
+        ids = torch.from_numpy(ids_all[i]).cuda()
+        items = torch.from_numpy(content[ids_all[i].reshape(-1)]).cuda()
+        return ids.view(-1), items, torch.ones(B, S, device=DEV)
+
+    curves, gnorms = {}, {}
+    try:
+        for name, model in (("fp32", m32), ("fp32x3", mx3)):
+            ts = TrainStep(model, **kw)
+            curves[name] = []
+            for i in range(steps):
+                loss = ts.forward_backward(*batch(i))
+                if i == 0:
+                    gnorms[name] = [float(g["arena"].grad.double().norm()) for g in ts.groups]
+                ts.reduce_gradients()
+                ts.optimizer_step()
+                curves[name].append(float(loss))
+            del ts
+    finally:
+        ops.FP32_GEMM = "exact"
+    c32, cx3 = np.array(curves["fp32"]), np.array(curves["fp32x3"])
+    d0 = abs(cx3[0] - c32[0]) / c32[0]
+    dc = float((np.abs(cx3 - c32) / c32).max())
+    gn = [abs(a - b) / b for a, b in zip(gnorms["fp32x3"], gnorms["fp32"])]
+    print(f"fp32x3 vs exact fp32 (BERT-base, B = {B}): step-0 loss {cx3[0]:.6f} vs {c32[0]:.6f} (rel. {d0:.1e}); gradient-norm rel. diff "
+          f"{['%.1e' % x for x in gn]}; {steps}-step loss curve max rel. diff {dc:.1e}")
+    assert d0 < 2e-4, d0
+    assert max(gn) < 1e-3, gn
+    assert dc < 1e-3, dc
