@@ -29,6 +29,7 @@ class SasrecFn(torch.autograd.Function):
         prep = engine.sasrec_prepare(p, n_layers, dtype, prefix)
         out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix, drop)
         ctx.stuff = (p, prep, saved, names, prefix, x_in.dtype, tuple(x_in.shape))
+        ctx.fp32_gemm = ops.FP32_GEMM
         return out.view(x_in.shape)
 
     @staticmethod
@@ -39,8 +40,9 @@ class SasrecFn(torch.autograd.Function):
                for w in ("w_Q", "w_K", "w_V")}
         grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
         d = dout.contiguous().view(-1, in_shape[-1])
-        dx = engine.sasrec_backward(p, prep, saved, d, grads, prefix)
-        engine.WgradStream.join(d.device)          # autograd consumers (DDP hooks, the optimizer) read the gradients on this stream
+        with ops.fp32_gemm_mode(ctx.fp32_gemm):
+            dx = engine.sasrec_backward(p, prep, saved, d, grads, prefix)
+            engine.WgradStream.join(d.device)      # autograd consumers (DDP hooks, the optimizer) read the gradients on this stream
         if dx.dtype != in_dtype:
             dx = ops.cast(dx, in_dtype)
         return (dx.view(in_shape), None, None) + tuple(grads[n] for n in names)
@@ -60,6 +62,7 @@ class BertEncoderFn(torch.autograd.Function):
         item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop, grad_from=grad_from)
         ctx.stuff = (p, prep, saved, names, prefix, grad_from)
         ctx.needs = ctx.needs_input_grad
+        ctx.fp32_gemm = ops.FP32_GEMM
         return item
 
     @staticmethod
@@ -71,8 +74,9 @@ class BertEncoderFn(torch.autograd.Function):
                 for n in ("query", "key", "value") for k in ("weight", "bias")}
         skip |= {n for n in names if not engine.bert_needs_grad_buffer(n, grad_from, prefix)}    # never reached by the backward
         grads = _zeros_like_params(names, [p[n] for n in names], skip=skip)
-        engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
-        engine.WgradStream.join(d_item.device)
+        with ops.fp32_gemm_mode(ctx.fp32_gemm):
+            engine.bert_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+            engine.WgradStream.join(d_item.device)
         needs = ctx.needs[2:]
         return (None, None) + tuple(grads.get(n) if nd else None for n, nd in zip(names, needs))
 
@@ -89,6 +93,7 @@ class SwinEncoderFn(torch.autograd.Function):
         item, saved = swin_engine.swin_forward(p, prep, shape, pixels, dtype, need, prefix, drop, training)
         ctx.stuff = (p, prep, saved, names, prefix, shape)
         ctx.needs = ctx.needs_input_grad
+        ctx.fp32_gemm = ops.FP32_GEMM
         return item
 
     @staticmethod
@@ -98,8 +103,9 @@ class SwinEncoderFn(torch.autograd.Function):
         qkv = {swin_engine.swin_layer_names(prefix, s, b) + f"attention.{n}.{k}" for s, depth in enumerate(shape.depths)
                for b in range(depth) for n in ("q_proj", "k_proj", "v_proj") for k in ("weight", "bias")}
         grads = _zeros_like_params(names, [p[n] for n in names], skip=qkv)
-        swin_engine.swin_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
-        engine.WgradStream.join(d_item.device)
+        with ops.fp32_gemm_mode(ctx.fp32_gemm):
+            swin_engine.swin_backward(p, prep, saved, d_item.contiguous(), grads, prefix)
+            engine.WgradStream.join(d_item.device)
         needs = ctx.needs[2:]
         return (None, None) + tuple(grads[n] if nd else None for n, nd in zip(names, needs))
 

@@ -72,8 +72,10 @@ class Model(nn.Module):
         return self._log_pop
 
     def forward(self, sample_items_id, sample_items, log_mask, local_rank=None):
-        ops.FP32_GEMM = self.fp32_gemm
-        ops.x3_cache_clear()
+        with ops.fp32_gemm_mode(self.fp32_gemm):      # "exact" | "bf16x3"; the autograd shells carry it into their backward
+            return self._forward(sample_items_id, sample_items, log_mask, local_rank)
+
+    def _forward(self, sample_items_id, sample_items, log_mask, local_rank=None):
         D = self.args.embedding_dim
         ids = sample_items_id.view(-1)
         d_item, d_user = self.dropout_cfgs()

@@ -49,6 +49,27 @@ def pad8(n: int) -> int:
 FP32_GEMM = "exact"
 
 
+class fp32_gemm_mode:
+    """``with ops.fp32_gemm_mode("bf16x3"): ...`` -- sets ``FP32_GEMM`` for the block and restores it (also drops the per-step split cache
+    on both ends).  ``Model.forward`` / ``TrainStep.forward_backward`` run under their model's mode; the autograd shells remember the
+    mode of their forward for their backward.  Elsewhere (an encoder called on its own, eval) the process default "exact" applies."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global FP32_GEMM
+        self.prev, FP32_GEMM = FP32_GEMM, self.mode
+        _X3_CACHE.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global FP32_GEMM
+        FP32_GEMM = self.prev
+        _X3_CACHE.clear()
+        return False
+
+
 def split_bf16x3(t, lo_slot, rows=None, cols=None, ld=None):
     """fp32 [R, C] (row pitch ``ld``) -> bf16 [R, 3 C]: hi | hi | lo (``lo_slot`` 2, A side) or hi | lo | hi (``lo_slot`` 1, B side)."""
     R = t.shape[0] if rows is None else rows

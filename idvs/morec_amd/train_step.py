@@ -333,13 +333,15 @@ class TrainStep:
 
     # -----------------------------------------------------------------------------------------------
     def forward_backward(self, sample_items_id, sample_items, log_mask, token_packing=None):
+        with ops.fp32_gemm_mode(getattr(self.model, "fp32_gemm", "exact")):      # how fp32 GEMMs run for this model ("exact" | "bf16x3")
+            return self._forward_backward(sample_items_id, sample_items, log_mask, token_packing)
+
+    def _forward_backward(self, sample_items_id, sample_items, log_mask, token_packing=None):
         """One forward + backward into the gradient arenas.  Returns the loss (device scalar, no sync).  Under data
         parallelism the bucketed gradient reduction is STARTED here (async collectives issued from the backward pass);
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
-        ops.FP32_GEMM = getattr(m, "fp32_gemm", "exact")
-        ops.x3_cache_clear()
         # Nothing in the FORWARD pass reads the gradient arenas or the W^T copies (dX = dY W): zero / refresh them on the side stream,
         # under the forward GEMMs (HBM-bound fills next to MFMA-bound kernels), and let the main stream wait for them right before
         # the backward pass starts.
