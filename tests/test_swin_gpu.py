@@ -278,21 +278,21 @@ def _full_size_swin_golden(golden_dir, dt, name, fname, tag):
     with torch.no_grad():
         vec = m.cv_encoder(px)
     e_v = relerr(vec[:, :8].cpu().numpy(), G["item_vec_probe"])
-    assert e_v < (2e-4 if dt == "fp32" else 6e-2), e_v
+    assert e_v < (2e-4 if dt != "bf16" else 6e-2), e_v
     loss = m(torch.from_numpy(ids).view(-1).to(DEV), px, torch.from_numpy(log_mask).to(DEV), DEV)
     e_l = abs(float(loss.detach()) - float(G["loss"]))
-    assert e_l < (1e-3 if dt == "fp32" else 5e-2), (float(loss.detach()), float(G["loss"]))   # north_star: loss within 1e-3 in fp32
+    assert e_l < (1e-3 if dt != "bf16" else 5e-2), (float(loss.detach()), float(G["loss"]))   # north_star: loss within 1e-3 in fp32
     loss.backward()
     worst = 0.0
     for n, p in m.named_parameters():
         ref = float(G[f"grad_norm.{n}"])
         got = float(p.grad.double().norm())
         worst = max(worst, abs(got - ref) / (ref + 1e-9)) if ref > 1e-6 else worst
-        assert abs(got - ref) <= (5e-3 if dt == "fp32" else 1.5e-1) * ref + (1e-6 if dt == "fp32" else 1e-3), (n, got, ref)
+        assert abs(got - ref) <= (5e-3 if dt != "bf16" else 1.5e-1) * ref + (1e-6 if dt != "bf16" else 1e-3), (n, got, ref)
     print(f"{tag} {name} {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp32x3"])      # fp32x3: the fp32 bounds (GEMMs as three bf16 MFMA passes over operand splits)
 def test_g13_swin_tiny_full_size_golden(golden_dir, dt):
     """Full-size Swin-T tower (real config, 224 x 224) in the vision Model against the reference's scalars."""
     _full_size_swin_golden(golden_dir, dt, "swin_tiny", "g13_swin_tiny_scalars.npz", "g13")
