@@ -113,3 +113,29 @@ def test_token_packing_host_equals_device_bookkeeping():
     holes[3, 1] = 0
     holes[3, 4] = 1
     assert engine.token_packing_host(holes) is None
+
+
+def test_fp32_gemm_mode_is_scoped_and_resolved_from_compute_dtype():
+    """``compute_dtype`` "fp32x3" = fp32 tensors + the bf16x3 GEMM mode; the mode is set for a block and restored (nesting included)."""
+    import types
+
+    import torch
+
+    from idvs.morec_amd import ops
+    from idvs.morec_amd.model.encoders import resolve_dtype, resolve_fp32_gemm
+    for name, dt, mode in (("bf16", torch.bfloat16, "exact"), ("fp32", torch.float32, "exact"), ("fp32x3", torch.float32, "bf16x3")):
+        a = types.SimpleNamespace(compute_dtype=name)
+        assert resolve_dtype(a) == dt and resolve_fp32_gemm(a) == mode
+    assert ops.FP32_GEMM == "exact"
+    with ops.fp32_gemm_mode("bf16x3"):
+        assert ops.FP32_GEMM == "bf16x3"
+        with ops.fp32_gemm_mode("exact"):
+            assert ops.FP32_GEMM == "exact"
+        assert ops.FP32_GEMM == "bf16x3"
+    assert ops.FP32_GEMM == "exact"
+    try:
+        with ops.fp32_gemm_mode("bf16x3"):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert ops.FP32_GEMM == "exact"
