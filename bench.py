@@ -475,7 +475,8 @@ def main():
     fl = sum(g_[0] for g_ in gemm_log)
     ms = sum(g_[1].elapsed_time(g_[2]) for g_ in gemm_log)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    peak = MFMA_PEAK_TFLOPS["bf16" if a.dtype == "bf16" else "f32"]
+    # fp32x3: three bf16 MFMA passes per fp32 product -> a third of the bf16 peak in fp32-equivalent FLOPs
+    peak = {"bf16": MFMA_PEAK_TFLOPS["bf16"], "fp32": MFMA_PEAK_TFLOPS["f32"], "fp32x3": round(MFMA_PEAK_TFLOPS["bf16"] / 3.0, 1)}[a.dtype]
     launches_per_step = len(gemm_log) / max(1, n_inst)
     flops_per_step = fl / max(1, n_inst)
     alg_bytes_per_launch = sum(g_[4] for g_ in gemm_log) / max(1, len(gemm_log))
