@@ -26,7 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--bert", default="base")
     ap.add_argument("--tower", default="text", help="text (BASELINE.json metric: BERT item encoder) | swin_tiny | swin_base | swin_micro "
                     "(vision configs of BASELINE.json: Swin item encoder, S=10, D=2048, 224x224 images; default --batch 64)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x3"])
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -476,7 +476,8 @@ def main():
     ms = sum(g_[1].elapsed_time(g_[2]) for g_ in gemm_log)
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # fp32x3: three bf16 MFMA passes per fp32 product -> a third of the bf16 peak in fp32-equivalent FLOPs
-    peak = {"bf16": MFMA_PEAK_TFLOPS["bf16"], "fp32": MFMA_PEAK_TFLOPS["f32"], "fp32x3": round(MFMA_PEAK_TFLOPS["bf16"] / 3.0, 1)}[a.dtype]
+    peak = {"bf16": MFMA_PEAK_TFLOPS["bf16"], "fp16": MFMA_PEAK_TFLOPS["fp16"], "fp32": MFMA_PEAK_TFLOPS["f32"],
+            "fp32x3": round(MFMA_PEAK_TFLOPS["bf16"] / 3.0, 1)}[a.dtype]
     launches_per_step = len(gemm_log) / max(1, n_inst)
     flops_per_step = fl / max(1, n_inst)
     alg_bytes_per_launch = sum(g_[4] for g_ in gemm_log) / max(1, len(gemm_log))

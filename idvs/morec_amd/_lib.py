@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MOREC_HIP_LIB: another build of the same ABI (A/B timing of kernel variants inside one GPU call)
 LIB_PATH = os.environ.get("MOREC_HIP_LIB") or os.path.join(_HERE, "libmorec_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 DACT_MUL = 3      # morec_gemm_desc.dact: multiply by dact_in (which holds act'(pre): aux_deriv outputs)
 
@@ -46,6 +46,12 @@ class TransposeItem(C.Structure):      # morec_transpose_item
 class CeDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("D", C.c_int), ("Nc", C.c_int), ("col_offset", C.c_int),
                 ("dtype", C.c_int), ("dE_fp32", C.c_int), ("ws_from_fwd", C.c_int)]
+
+
+class StepParams(C.Structure):       # morec_step_params (64 bytes, lives on the DEVICE; this mirror is for host-side reads of a copy)
+    _fields_ = [("step", C.c_int32), ("found_inf", C.c_int32), ("growth_tracker", C.c_int32), ("skipped", C.c_int32),
+                ("loss_scale", C.c_float), ("inv_scale", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float), ("apply", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class SwinAttnDesc(C.Structure):
@@ -92,6 +98,10 @@ _SIGS = {
     "morec_bce_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_adamw": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                               C.c_int, C.c_float, _P]),
+    "morec_step_params_init": (C.c_int, [_P, C.c_float, C.c_int, _P]),
+    "morec_grad_check_finite": (C.c_int, [_P, C.c_size_t, _P, _P]),
+    "morec_step_decide": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P]),
+    "morec_adamw_sp": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "morec_eval_rank": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_dropout_keep_mask": (C.c_int, [_P, C.c_size_t, C.c_float, C.c_uint64, _P]),
     "morec_probe": (C.c_int, [_P, _P]),

@@ -11,6 +11,8 @@
 // Reference arithmetic: SASRec T/model/encoders.py:24-27 + T/model/modules.py:27-31 (mask built from
 // log_mask inside the kernel: key kept iff log_mask[b, j] != 0 and j <= i, additive -1e9);
 // BERT: HF BertSelfAttention eager path (additive finfo.min on padded keys).
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -313,6 +315,21 @@ int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const floa
                            void* dqkv, bool backward, hipStream_t s, float* csum = nullptr);
 int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
 
+// A 16-bit problem outside the matrix-core path's shape rules (T <= 32, head width a multiple of 32) runs on the exact-fp32 VALU
+// kernels -- correct, several times slower.  Said ONCE per process on stderr (MOREC_QUIET=1 silences it) so that e.g. a run with
+// num_words_title > 32 does not lose the MFMA attention without a trace.
+static void warn_valu_fallback(const morec_attn_desc* d) {
+    if (!is_h16(d->dtype)) return;
+    static const bool once = [](const morec_attn_desc* q) {
+        const char* e = getenv("MOREC_QUIET");
+        if (!(e && e[0] == '1'))
+            fprintf(stderr, "libmorec_hip: attention with T = %d, head width %d is outside the MFMA path (T <= 32, head width %% 32 == 0): "
+                            "running the VALU kernels for this and every later such call\n", q->T, q->dh);
+        return true;
+    }(d);
+    (void)once;
+}
+
 extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx,
                               void* stream) {
     int rc = check_desc(d);
@@ -324,11 +341,11 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
-    if (d->dtype == MOREC_F32)
-        hipLaunchKernelGGL((attn_fwd_kernel<float, 64>), grid, block, 0, s, a);
-    else if (d->dtype == MOREC_BF16)
-        hipLaunchKernelGGL((attn_fwd_kernel<bf16, 64>), grid, block, 0, s, a);
-    else
+    warn_valu_fallback(d);
+    if (!by_dtype(d->dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((attn_fwd_kernel<T, 64>), grid, block, 0, s, a);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -345,11 +362,11 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
-    if (d->dtype == MOREC_F32)
-        hipLaunchKernelGGL((attn_bwd_kernel<float, 32>), grid, block, 0, s, a);
-    else if (d->dtype == MOREC_BF16)
-        hipLaunchKernelGGL((attn_bwd_kernel<bf16, 32>), grid, block, 0, s, a);
-    else
+    warn_valu_fallback(d);
+    if (!by_dtype(d->dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((attn_bwd_kernel<T, 32>), grid, block, 0, s, a);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;

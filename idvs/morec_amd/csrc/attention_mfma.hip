@@ -35,7 +35,6 @@ struct AttnMArgs {
     const int32_t* cu;  // packed-row offsets (unpadded layout) or nullptr
 };
 
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // No guarded loads in these kernels.  `if (row < T) v = *p;` -- and equally `ok ? *p : 0`, which the compiler turns back into a
 // branch -- makes every load its own basic block that ends in s_waitcnt vmcnt(0): the 12 tile loads, 4 fragment loads and 8
@@ -117,24 +116,25 @@ __device__ __forceinline__ bf16x8_t frag_tr_spread(const char* tile, int pitch_b
 }
 
 // store the 4 * NB consecutive d values of one row held by the lane (NB accumulator blocks, 16-byte pieces)
-template <int NB>
+template <typename T16, int NB>
 __device__ __forceinline__ void store_row_d(bf16* dst, size_t row, int pitch, int col, const f32x4_t (&o)[NB]) {
     static_assert(NB % 2 == 0, "pairs of blocks");
     bf16* p = dst + row * (size_t)pitch + col;
 #pragma unroll
     for (int h = 0; h < NB / 2; ++h) {
         uint4 v;
-        v.x = pack_bf16x2(o[2 * h][0], o[2 * h][1]);
-        v.y = pack_bf16x2(o[2 * h][2], o[2 * h][3]);
-        v.z = pack_bf16x2(o[2 * h + 1][0], o[2 * h + 1][1]);
-        v.w = pack_bf16x2(o[2 * h + 1][2], o[2 * h + 1][3]);
+        v.x = h16<T16>::pack2(o[2 * h][0], o[2 * h][1]);
+        v.y = h16<T16>::pack2(o[2 * h][2], o[2 * h][3]);
+        v.z = h16<T16>::pack2(o[2 * h + 1][0], o[2 * h + 1][1]);
+        v.w = h16<T16>::pack2(o[2 * h + 1][2], o[2 * h + 1][3]);
         *reinterpret_cast<uint4*>(p + 8 * h) = v;
     }
 }
 
 // register fragment of a [query][key] quantity held as x[qb][kb][r]: k-slots (g, e) = keys 4g+e | 16+4g+(e-4)
+template <typename T16>
 __device__ __forceinline__ bf16x8_t frag_regs(const f32x4_t (&x)[2]) {
-    const uint4 v = make_uint4(pack2(x[0][0], x[0][1]), pack2(x[0][2], x[0][3]), pack2(x[1][0], x[1][1]), pack2(x[1][2], x[1][3]));
+    const uint4 v = make_uint4(h16<T16>::pack2(x[0][0], x[0][1]), h16<T16>::pack2(x[0][2], x[0][3]), h16<T16>::pack2(x[1][0], x[1][1]), h16<T16>::pack2(x[1][2], x[1][3]));
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
@@ -206,7 +206,7 @@ __device__ __forceinline__ void drop_mask_regs(const DropRng& d, uint64_t tile, 
 }
 
 // ctx[query][d0 .. d0 + 16 NB) = P_d V for both query blocks; every lane writes 8 NB contiguous bytes of its row
-template <int NB>
+template <typename T16, int NB>
 __device__ __forceinline__ void fwd_pv(const AttnMArgs& a, const char* sV, const bf16x8_t (&pf)[2], size_t row0, int H, int col0) {
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
@@ -217,9 +217,9 @@ __device__ __forceinline__ void fwd_pv(const AttnMArgs& a, const char* sV, const
     for (int qb = 0; qb < 2; ++qb) {
         f32x4_t o[NB];
 #pragma unroll
-        for (int db = 0; db < NB; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[db], pf[qb], zero, 0, 0, 0);
+        for (int db = 0; db < NB; ++db) o[db] = h16<T16>::mma16(vf[db], pf[qb], zero);
         const int q = qb * 16 + c;
-        if (q < a.T) store_row_d<NB>(a.ctx, row0 + q, H, col0 + 4 * NB * g, o);
+        if (q < a.T) store_row_d<T16, NB>(a.ctx, row0 + q, H, col0 + 4 * NB * g, o);
     }
 }
 
@@ -233,7 +233,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // dQ = dS K, dK = dS^T Q, dV = P_d^T dO for one head-width chunk of 16 NB columns (same d-contiguous output layout)
-template <int NB>
+template <typename T16, int NB>
 __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ, const char* sK, const char* sO,
                                              const bf16x8_t (&dsf)[2], const bf16x8_t (&dsT)[2], const bf16x8_t (&pT)[2],
                                              size_t row0, int pitch, int H, int col0, int seq) {
@@ -256,16 +256,16 @@ __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ,
 #pragma unroll
         for (int db = 0; db < NB; ++db) {
             // dQ[query r][d] = sum_key dS[r][key] K[key][d]
-            dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt[db], dsf[b], zero, 0, 0, 0);
+            dq[db] = h16<T16>::mma16(kt[db], dsf[b], zero);
             // dK[key r][d] = sum_query dS[query][r] Q[query][d];  dV[key r][d] = sum_query P_d[query][r] dO[query][d]
-            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[db], dsT[b], zero, 0, 0, 0);
-            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot[db], pT[b], zero, 0, 0, 0);
+            dk[db] = h16<T16>::mma16(qt[db], dsT[b], zero);
+            dv[db] = h16<T16>::mma16(ot[db], pT[b], zero);
         }
         if (r < a.T) {
             const int dcol = col0 + 4 * NB * g;
-            store_row_d<NB>(a.dqkv, row0 + r, pitch, dcol, dq);
-            store_row_d<NB>(a.dqkv, row0 + r, pitch, H + dcol, dk);
-            store_row_d<NB>(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
+            store_row_d<T16, NB>(a.dqkv, row0 + r, pitch, dcol, dq);
+            store_row_d<T16, NB>(a.dqkv, row0 + r, pitch, H + dcol, dk);
+            store_row_d<T16, NB>(a.dqkv, row0 + r, pitch, 2 * H + dcol, dv);
             if (a.csum) {
 #pragma unroll
                 for (int db = 0; db < NB; ++db)
@@ -299,6 +299,7 @@ __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ,
     }
 }
 
+template <typename T16>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
     __shared__ __attribute__((aligned(16))) char sV[TILE];
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks][kb], qf[ks][qb], s[qb][kb], 0, 0, 0);
+                    for (int kb = 0; kb < 2; ++kb) s[qb][kb] = h16<T16>::mma16(kf[ks][kb], qf[ks][qb], s[qb][kb]);
             }
         }
     } else {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
+                for (int kb = 0; kb < 2; ++kb) s[qb][kb] = h16<T16>::mma16(kf[kb], qf[qb], s[qb][kb]);
         }
     }
     __syncthreads();
@@ -361,19 +362,20 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[qb][kb][r] *= m[qb][kb][r];
     }
-    const bf16x8_t pf[2] = {frag_regs(s[0]), frag_regs(s[1])};
+    const bf16x8_t pf[2] = {frag_regs<T16>(s[0]), frag_regs<T16>(s[1])};
     for (int ch = 0; ch < nch; ++ch) {
         const int d0 = ch * DCH, nc = min(DCH, a.dh - d0);
         if (nch > 1) {
             stage_tile(a.qkv, row0, pitch, 2 * H + head * a.dh + d0, nc, a.T, sV);
             __syncthreads();
         }
-        if (nc == 64) fwd_pv<4>(a, sV, pf, row0, H, head * a.dh + d0);
-        else fwd_pv<2>(a, sV, pf, row0, H, head * a.dh + d0);
+        if (nc == 64) fwd_pv<T16, 4>(a, sV, pf, row0, H, head * a.dh + d0);
+        else fwd_pv<T16, 2>(a, sV, pf, row0, H, head * a.dh + d0);
         if (nch > 1) __syncthreads();
     }
 }
 
+template <typename T16>
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
     __shared__ __attribute__((aligned(16))) char sQ[TILE];
     __shared__ __attribute__((aligned(16))) char sK[TILE];
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
-                        s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
-                        dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks][kb], of[qb], dp[qb][kb], 0, 0, 0);
+                        s[qb][kb] = h16<T16>::mma16(kf[kb], qf[qb], s[qb][kb]);
+                        dp[qb][kb] = h16<T16>::mma16(vf[ks][kb], of[qb], dp[qb][kb]);
                     }
             }
         }
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    s[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb], qf[qb], s[qb][kb], 0, 0, 0);
-                    dp[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb], of[qb], dp[qb][kb], 0, 0, 0);
+                    s[qb][kb] = h16<T16>::mma16(kf[kb], qf[qb], s[qb][kb]);
+                    dp[qb][kb] = h16<T16>::mma16(vf[kb], of[qb], dp[qb][kb]);
                 }
         }
         if (nch > 1) __syncthreads();
@@ -476,11 +478,11 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
                 if (a.drop.thresh) s[qb][kb][r] *= msk[qb][kb][r];                  // dV takes the dropped probabilities
             }
             const int q = qb * 16 + c, k0 = kb * 16 + 4 * g;
-            *reinterpret_cast<uint2*>(sP + q * PP + k0 * 2) = make_uint2(pack2(s[qb][kb][0], s[qb][kb][1]), pack2(s[qb][kb][2], s[qb][kb][3]));
-            *reinterpret_cast<uint2*>(sS + q * PP + k0 * 2) = make_uint2(pack2(dp[qb][kb][0], dp[qb][kb][1]), pack2(dp[qb][kb][2], dp[qb][kb][3]));
+            *reinterpret_cast<uint2*>(sP + q * PP + k0 * 2) = make_uint2(h16<T16>::pack2(s[qb][kb][0], s[qb][kb][1]), h16<T16>::pack2(s[qb][kb][2], s[qb][kb][3]));
+            *reinterpret_cast<uint2*>(sS + q * PP + k0 * 2) = make_uint2(h16<T16>::pack2(dp[qb][kb][0], dp[qb][kb][1]), h16<T16>::pack2(dp[qb][kb][2], dp[qb][kb][3]));
         }
     }
-    const bf16x8_t dsf[2] = {frag_regs(dp[0]), frag_regs(dp[1])};
+    const bf16x8_t dsf[2] = {frag_regs<T16>(dp[0]), frag_regs<T16>(dp[1])};
     __syncthreads();
     // transposed [key][query-slot] fragments of dS and P for the two key blocks
     const bf16x8_t dsT[2] = {frag_tr(sS, PP, 0), frag_tr(sS, PP, 16)};
@@ -494,8 +496,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
             stage_tile(dctx, row0, H, head * a.dh + d0, nc, a.T, sO);
             __syncthreads();
         }
-        if (nc == 64) bwd_products<4>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
-        else bwd_products<2>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
+        if (nc == 64) bwd_products<T16, 4>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
+        else bwd_products<T16, 2>(a, sQ, sK, sO, dsf, dsT, pT, row0, pitch, H, head * a.dh + d0, seq);
     }
 }
 
@@ -504,15 +506,18 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
 // returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
                            void* dqkv, bool backward, hipStream_t s, float* csum) {
-    if (d->dtype != MOREC_BF16 || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
+    if (!is_h16(d->dtype) || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
     AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
                 reinterpret_cast<bf16*>(dqkv), csum, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
                 make_drop(d->p_drop, d->seed), d->cu_seqlens};
     dim3 grid(d->n_seq * d->n_heads), block(64);
-    if (backward)
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, block, 0, s, a);
+    by_h16(d->dtype, [&](auto* t) {
+        using T = MOREC_TAG_T(t);
+        if (backward)
+            hipLaunchKernelGGL(attn_bwd_mfma_kernel<T>, grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL(attn_fwd_mfma_kernel<T>, grid, block, 0, s, a);
+    });
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

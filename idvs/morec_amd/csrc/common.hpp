@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "morec_hip.h"
 
 #define MOREC_WAVE 64
@@ -29,6 +30,24 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ bf16 f2bf(float f) { return bf16{f2bf_bits(f)}; }
+
+// ---- fp16 storage (MOREC_F16): IEEE half, 11-bit significand -- the reference's own GPU arithmetic (fp16 autocast + GradScaler,
+// T/run.py:210,242-247).  Same data movement as bf16 (2-byte elements); only the conversions and the MFMA opcode differ.
+struct f16 {
+    unsigned short v;
+};
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ float hbits2f(uint32_t lo16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)lo16); }
+__device__ __forceinline__ float h2f(f16 x) { return hbits2f(x.v); }
+// round-to-nearest-even (v_cvt_f16_f32); values past 65504 become +-inf, which is what the loss scaler's overflow check looks for
+__device__ __forceinline__ unsigned short f2h_bits(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ f16 f2h(float f) { return f16{f2h_bits(f)}; }
 
 // ---- typed 4-element vector IO (16 B for f32, 8 B for bf16) --------------------------------------
 template <typename T>
@@ -64,6 +83,22 @@ struct io<bf16> {
     __device__ __forceinline__ static void store1(bf16* p, float v) { *p = f2bf(v); }
     __device__ __forceinline__ static float round(float v) { return bf2f(f2bf(v)); }
 };
+template <>
+struct io<f16> {
+    static constexpr int dtype = MOREC_F16;
+    __device__ __forceinline__ static void load4(const f16* p, float (&o)[4]) {
+        const f16x4_t h = __builtin_bit_cast(f16x4_t, *reinterpret_cast<const uint2*>(p));
+        const f32x4_t f = __builtin_convertvector(h, f32x4_t);
+        o[0] = f[0]; o[1] = f[1]; o[2] = f[2]; o[3] = f[3];
+    }
+    __device__ __forceinline__ static void store4(f16* p, const float (&o)[4]) {
+        const f32x4_t f = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, __builtin_convertvector(f, f16x4_t));
+    }
+    __device__ __forceinline__ static float load1(const f16* p) { return h2f(*p); }
+    __device__ __forceinline__ static void store1(f16* p, float v) { *p = f2h(v); }
+    __device__ __forceinline__ static float round(float v) { return h2f(f2h(v)); }
+};
 
 // ---- 16-byte vector IO: EV = 4 (f32) or 8 (bf16) elements per lane and access ------------------------------
 template <typename T>
@@ -92,6 +127,49 @@ struct vio<bf16> {
         uint4 v;
         v.x = pack_bf16x2(o[0], o[1]); v.y = pack_bf16x2(o[2], o[3]); v.z = pack_bf16x2(o[4], o[5]); v.w = pack_bf16x2(o[6], o[7]);
         *reinterpret_cast<uint4*>(p) = v;
+    }
+};
+template <>
+struct vio<f16> {
+    static constexpr int EV = 8;
+    __device__ __forceinline__ static uint4 load_raw(const f16* p) { return *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ static void unpack(const uint4& v, float (&o)[8]) {
+        const f16x8_t h = __builtin_bit_cast(f16x8_t, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (float)h[k];
+    }
+    __device__ __forceinline__ static void load(const f16* p, float (&o)[8]) { unpack(load_raw(p), o); }
+    __device__ __forceinline__ static void store(f16* p, const float (&o)[8]) {
+        uint4 v;
+        v.x = pack_f16x2(o[0], o[1]); v.y = pack_f16x2(o[2], o[3]); v.z = pack_f16x2(o[4], o[5]); v.w = pack_f16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+};
+// ---- arithmetic selection for the kernels whose data movement only sees 2-byte elements (MFMA main loops, attention, scoring):
+// T16 = bf16 | f16 picks the conversions and the MFMA opcode; fragments travel as raw 16-byte vectors (bf16x8_t = "8 x 16 bits").
+typedef __attribute__((ext_vector_type(16))) float f32x16c_t;
+template <typename T16>
+struct h16;
+template <>
+struct h16<bf16> {
+    static constexpr int dtype = MOREC_BF16;
+    __device__ __forceinline__ static float bits2f(uint32_t lo16) { return bfbits2f(lo16); }
+    __device__ __forceinline__ static uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    __device__ __forceinline__ static unsigned short bits(float f) { return f2bf_bits(f); }
+    __device__ __forceinline__ static f32x4_t mma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    __device__ __forceinline__ static f32x16c_t mma32(bf16x8_t a, bf16x8_t b, f32x16c_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct h16<f16> {
+    static constexpr int dtype = MOREC_F16;
+    __device__ __forceinline__ static float bits2f(uint32_t lo16) { return hbits2f(lo16); }
+    __device__ __forceinline__ static uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    __device__ __forceinline__ static unsigned short bits(float f) { return f2h_bits(f); }
+    __device__ __forceinline__ static f32x4_t mma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    __device__ __forceinline__ static f32x16c_t mma32(bf16x8_t a, bf16x8_t b, f32x16c_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
     }
 };
 // EV consecutive fp32 values (parameters: gamma / beta / bias / position rows)
@@ -254,7 +332,28 @@ __device__ __forceinline__ void drop_keep_vec(const DropRng& d, uint64_t idx0, b
 
 // ---- host-side argument checks -------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static inline int elt_size(int dtype) { return dtype == MOREC_BF16 ? 2 : 4; }
+static inline int elt_size(int dtype) { return dtype == MOREC_F32 ? 4 : 2; }
+static inline bool is_h16(int dtype) { return dtype == MOREC_BF16 || dtype == MOREC_F16; }
+// host-side dtype dispatch: f(tag) with tag a null T* of the storage type; false = unknown dtype code
+template <typename F>
+static inline bool by_dtype(int dtype, F&& f) {
+    switch (dtype) {
+        case MOREC_F32: f((float*)nullptr); return true;
+        case MOREC_BF16: f((bf16*)nullptr); return true;
+        case MOREC_F16: f((f16*)nullptr); return true;
+        default: return false;
+    }
+}
+// the same over the two 16-bit types only
+template <typename F>
+static inline bool by_h16(int dtype, F&& f) {
+    switch (dtype) {
+        case MOREC_BF16: f((bf16*)nullptr); return true;
+        case MOREC_F16: f((f16*)nullptr); return true;
+        default: return false;
+    }
+}
+#define MOREC_TAG_T(tag) typename std::remove_pointer<decltype(tag)>::type
 #define MOREC_CHECK_LAUNCH()                        \
     do {                                            \
         hipError_t e__ = hipGetLastError();         \

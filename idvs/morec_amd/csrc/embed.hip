@@ -95,7 +95,7 @@ extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const
     if (p_out < 0.f || p_out >= 1.f) return MOREC_E_ARG;
     const DropRng dout = make_drop(p_out, seed_out);
     if (!ids || !word || !pos || !type0 || !gamma || !beta || !y || M <= 0 || T <= 0 || H <= 0) return MOREC_E_ARG;
-    const int ev = dtype == MOREC_BF16 ? 8 : 4;
+    const int ev = dtype == MOREC_F32 ? 4 : 8;
     if (H % ev) return MOREC_E_ALIGN;
     const int vpl = (H + 64 * ev - 1) / (64 * ev);
     dim3 grid((M + 3) / 4), block(256);
@@ -114,6 +114,7 @@ extern "C" int morec_bert_embed_fwd(const int32_t* ids, const float* word, const
     } while (0)
     if (dtype == MOREC_F32) EMB_DISPATCH(float);
     else if (dtype == MOREC_BF16) EMB_DISPATCH(bf16);
+    else if (dtype == MOREC_F16) EMB_DISPATCH(f16);
     else return MOREC_E_DTYPE;
 #undef EMB
 #undef EMB_DISPATCH
@@ -246,24 +247,20 @@ extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* d
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int spb = 64;
     dim3 g1((M + 3) / 4), g2(T, (M / T + spb - 1) / spb);
-    const int ev = dtype == MOREC_BF16 ? 8 : 4;
+    const int ev = dtype == MOREC_F32 ? 4 : 8;
     const bool vec = H % ev == 0 && H / ev <= 256;          // one 16-byte column vector per thread
     const int rpw = 32;                                   // sorted rows per wave
     dim3 g3((((M + rpw - 1) / rpw) + 3) / 4);
     const bool sorted = order != nullptr && H <= 1024;
-    if (dtype == MOREC_F32) {
-        if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<float, 4>), g3, dim3(256), 0, s, ids, order, (const float*)dz, dword, pad_id, M, H, rpw);
-        else hipLaunchKernelGGL((word_scatter_kernel<float>), g1, dim3(256), 0, s, ids, (const float*)dz, dword, pad_id, M, H);
-        if (vec) pos_type_grad_launch<float>((const float*)dz, dpos, dtype0, M / T, T, H, s);
-        else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<float>), g2, dim3(256), 0, s, (const float*)dz, dpos, dtype0, M / T, T, H, spb);
-    } else if (dtype == MOREC_BF16) {
-        if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<bf16, 4>), g3, dim3(256), 0, s, ids, order, (const bf16*)dz, dword, pad_id, M, H, rpw);
-        else hipLaunchKernelGGL((word_scatter_kernel<bf16>), g1, dim3(256), 0, s, ids, (const bf16*)dz, dword, pad_id, M, H);
-        if (vec) pos_type_grad_launch<bf16>((const bf16*)dz, dpos, dtype0, M / T, T, H, s);
-        else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<bf16>), g2, dim3(256), 0, s, (const bf16*)dz, dpos, dtype0, M / T, T, H, spb);
-    } else {
+    const int T_ = T;      // (the lambda below names its storage type T)
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<T, 4>), g3, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H, rpw);
+            else hipLaunchKernelGGL((word_scatter_kernel<T>), g1, dim3(256), 0, s, ids, (const T*)dz, dword, pad_id, M, H);
+            if (vec) pos_type_grad_launch<T>((const T*)dz, dpos, dtype0, M / T_, T_, H, s);
+            else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<T>), g2, dim3(256), 0, s, (const T*)dz, dpos, dtype0, M / T_, T_, H, spb);
+        }))
         return MOREC_E_DTYPE;
-    }
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -288,11 +285,10 @@ extern "C" int morec_gather_rows(const float* table, const int32_t* idx, void* o
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((R + 3) / 4);
-    if (dtype == MOREC_F32)
-        hipLaunchKernelGGL((gather_rows_kernel<float>), grid, dim3(256), 0, s, table, idx, (float*)out, R, D);
-    else if (dtype == MOREC_BF16)
-        hipLaunchKernelGGL((gather_rows_kernel<bf16>), grid, dim3(256), 0, s, table, idx, (bf16*)out, R, D);
-    else
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((gather_rows_kernel<T>), grid, dim3(256), 0, s, table, idx, (T*)out, R, D);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -321,11 +317,10 @@ extern "C" int morec_scatter_add_rows(const void* d, const int32_t* idx, float* 
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((R + 3) / 4);
-    if (dtype == MOREC_F32)
-        hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)d, idx, dtable, R, D, pad_id);
-    else if (dtype == MOREC_BF16)
-        hipLaunchKernelGGL((scatter_add_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)d, idx, dtable, R, D, pad_id);
-    else
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((scatter_add_rows_kernel<T>), grid, dim3(256), 0, s, (const T*)d, idx, dtable, R, D, pad_id);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -350,11 +345,10 @@ extern "C" int morec_strided_rows_copy(const void* in, void* out, int R, int D, 
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((R + 3) / 4);
-    if (dtype == MOREC_F32)
-        hipLaunchKernelGGL((strided_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, R, D, in_row_stride, out_row_stride);
-    else if (dtype == MOREC_BF16)
-        hipLaunchKernelGGL((strided_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, R, D, in_row_stride, out_row_stride);
-    else
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((strided_rows_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (T*)out, R, D, in_row_stride, out_row_stride);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -384,11 +378,10 @@ extern "C" int morec_indexed_rows_copy(const void* in, void* out, const int32_t*
     if (D % 8) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((R + 3) / 4);
-    if (dtype == MOREC_F32)
-        hipLaunchKernelGGL((indexed_rows_kernel<float>), grid, dim3(256), 0, s, (const float*)in, (float*)out, in_idx, out_idx, R, D);
-    else if (dtype == MOREC_BF16)
-        hipLaunchKernelGGL((indexed_rows_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, in_idx, out_idx, R, D);
-    else
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((indexed_rows_kernel<T>), grid, dim3(256), 0, s, (const T*)in, (T*)out, in_idx, out_idx, R, D);
+        }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;

@@ -66,7 +66,7 @@ struct TileXY {
     int krem;      // elements of K inside the unit's last K-tile (64 unless the unit ends at a K that is not a multiple of 64)
 };
 
-template <typename TO, int ACT, bool CS>
+template <typename TI, typename TO, int ACT, bool CS>
 __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const bf16* __restrict__ Acur, const bf16* __restrict__ Bcur,
                                           const bf16* __restrict__ Anext, const bf16* __restrict__ Bnext, const TileXY cur, const TileXY nxt,
                                           const bool first) {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
         constexpr int NST = 16 * (int)sizeof(TO) / 2;
         const int younger = (first || (p.debug & 3) || (p.debug & 64)) ? 0 : (p.aux_out ? 2 * NST : NST);
-        mainloop8p(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), cur.nkt, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
+        mainloop8p<TI>(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), cur.nkt, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
     }
     G8_STAMPW(1, cur.wg);
     if (cur.tail >= 0) {
@@ -314,7 +314,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
                             }
                         }
                         io<TO>::store4(cell(q), d);
-                        park[q] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        park[q] = make_uint2(h16<TI>::pack2(v[0], v[1]), h16<TI>::pack2(v[2], v[3]));
                         if (q & 1) pin();      // keeps the scheduler from computing every group ahead of the first store (VGPR pressure)
                     }
                     wfence();
@@ -376,8 +376,8 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
                 } else if constexpr (ACT >= 3) {
                     float u[4];
                     if constexpr (ES == 2) {
-                        u[0] = bfbits2f(uraw[q][0] & 0xffffu); u[1] = bfbits2f(uraw[q][0] >> 16);
-                        u[2] = bfbits2f(uraw[q][1] & 0xffffu); u[3] = bfbits2f(uraw[q][1] >> 16);
+                        u[0] = h16<TI>::bits2f(uraw[q][0] & 0xffffu); u[1] = h16<TI>::bits2f(uraw[q][0] >> 16);
+                        u[2] = h16<TI>::bits2f(uraw[q][1] & 0xffffu); u[3] = h16<TI>::bits2f(uraw[q][1] >> 16);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) u[r] = __uint_as_float(uraw[q][r]);
@@ -414,8 +414,8 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        cs8[2 * w] += bfbits2f(q[i][w] & 0xffffu);
-                        cs8[2 * w + 1] += bfbits2f(q[i][w] >> 16);
+                        cs8[2 * w] += h16<TI>::bits2f(q[i][w] & 0xffffu);
+                        cs8[2 * w + 1] += h16<TI>::bits2f(q[i][w] >> 16);
                     }
                 if (!(p.debug & 1)) {
 #pragma unroll
@@ -446,7 +446,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
     }
 }
 
-template <typename TO, int ACT, bool CS>
+template <typename TI, typename TO, int ACT, bool CS>
 __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     for (int i = 0; i < n_units; ++i) {
         const bool more = i + 1 < n_units;
         const TileXY nxt = more ? unit_at(i + 1) : cur;
-        tile_body<TO, ACT, CS>(p, smem, A + (size_t)cur.m0 * p.lda + cur.k0 * KE, B + (size_t)cur.n0 * p.ldb + cur.k0 * KE,
+        tile_body<TI, TO, ACT, CS>(p, smem, A + (size_t)cur.m0 * p.lda + cur.k0 * KE, B + (size_t)cur.n0 * p.ldb + cur.k0 * KE,
                                A + (size_t)nxt.m0 * p.lda + nxt.k0 * KE, B + (size_t)nxt.n0 * p.ldb + nxt.k0 * KE, cur, nxt, i == 0);
         cur = nxt;
     }
@@ -543,12 +543,12 @@ int g_reserve_cus = 0;      // tuning key "gemm8p_reserve_cus"
 // projection, -24 % on FFN-up + GELU, -23 % on its backward at equal launch times; profiles/r03_gemm8p_tile_order_pmc.txt), n = groups of n N-tiles
 int g_ngroup = -1;
 
-template <typename TO, int ACT, bool CS>
+template <typename TI, typename TO, int ACT, bool CS>
 int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     a.tiles_m = (d->M + TM - 1) / TM;
     a.tiles_n = (d->N + TN - 1) / TN;
     static const int n_cu_dev = [] {      // thread-safe one-time set-up (function-local static)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TO, ACT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TI, TO, ACT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_TOTAL);
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -573,7 +573,7 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     // turns that into +-1e-2 on the step-0 loss (tests/test_bench_mode_parity_gpu.py); the default keeps the summation order of
     // the two-buffer kernels (bit-identical outputs) for 0.35 % of the step time.
     if (a.tail_split && nwg > n_cu && nwg % n_cu && 2 * (nwg % n_cu) <= n_cu && d->K >= 24 * KE && !(a.debug & 128)) tail_workspace(s, n_cu, a);
-    hipLaunchKernelGGL((gemm8p_kernel<TO, ACT, CS>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<TI, TO, ACT, CS>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     if constexpr (CS) return colsum_f32_launch(a.colsum, a.colsum_dst, a.tiles_m * 2, d->N, s);
     return MOREC_OK;
@@ -611,10 +611,33 @@ int gemm8p_mode() {
     return g_mode8p;
 }
 
+template <typename TI>
+static int dispatch8p(const morec_gemm_desc* d, GemmArgs& a, int mode, hipStream_t s) {
+    if (d->out_dtype == MOREC_F32) {
+        if (mode != 0 || a.colsum) return G8_NOT_TAKEN;
+        return launch8p<TI, float, 0, false>(d, a, s);
+    }
+    if (d->out_dtype != h16<TI>::dtype) return G8_NOT_TAKEN;
+    if (a.colsum) {
+        if (mode == 3) return launch8p<TI, TI, 3, true>(d, a, s);
+        if (mode == 4) return launch8p<TI, TI, 4, true>(d, a, s);
+        if (mode == 5) return launch8p<TI, TI, 5, true>(d, a, s);
+        return G8_NOT_TAKEN;
+    }
+    switch (mode) {
+        case 1: return launch8p<TI, TI, 1, false>(d, a, s);
+        case 2: return launch8p<TI, TI, 2, false>(d, a, s);
+        case 3: return launch8p<TI, TI, 3, false>(d, a, s);
+        case 4: return launch8p<TI, TI, 4, false>(d, a, s);
+        case 5: return launch8p<TI, TI, 5, false>(d, a, s);
+        default: return launch8p<TI, TI, 0, false>(d, a, s);
+    }
+}
+
 int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     (void)gemm8p_mode();
     if (g_mode8p == 1) return G8_NOT_TAKEN;
-    if (d->in_dtype != MOREC_BF16 || a.accumulate != 0 || !a.vec_store || d->split_k > 1) return G8_NOT_TAKEN;
+    if (!is_h16(d->in_dtype) || a.accumulate != 0 || !a.vec_store || d->split_k > 1) return G8_NOT_TAKEN;
     if (d->K % 8 || d->K <= KE || d->N < 64 || d->M < 1) return G8_NOT_TAKEN;      // 16-byte slots; at least two K-tiles (the last may be partial)
     const long tiles = (long)((d->M + TM - 1) / TM) * ((d->N + TN - 1) / TN);
     if (a.colsum && d->M < 128) return G8_NOT_TAKEN;      // partial-row workspace is sized per 64 rows
@@ -629,23 +652,6 @@ int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     a.tail_bias = g_tail_bias;
     a.tail_split = g_tail_split;
     a.stamps = reinterpret_cast<unsigned long long*>(g_stamps);
-    if (d->out_dtype == MOREC_F32) {
-        if (mode != 0 || a.colsum) return G8_NOT_TAKEN;
-        return launch8p<float, 0, false>(d, a, s);
-    }
-    if (d->out_dtype != MOREC_BF16) return G8_NOT_TAKEN;
-    if (a.colsum) {
-        if (mode == 3) return launch8p<bf16, 3, true>(d, a, s);
-        if (mode == 4) return launch8p<bf16, 4, true>(d, a, s);
-        if (mode == 5) return launch8p<bf16, 5, true>(d, a, s);
-        return G8_NOT_TAKEN;
-    }
-    switch (mode) {
-        case 1: return launch8p<bf16, 1, false>(d, a, s);
-        case 2: return launch8p<bf16, 2, false>(d, a, s);
-        case 3: return launch8p<bf16, 3, false>(d, a, s);
-        case 4: return launch8p<bf16, 4, false>(d, a, s);
-        case 5: return launch8p<bf16, 5, false>(d, a, s);
-        default: return launch8p<bf16, 0, false>(d, a, s);
-    }
+    if (d->in_dtype == MOREC_F16) return dispatch8p<f16>(d, a, mode, s);
+    return dispatch8p<bf16>(d, a, mode, s);
 }

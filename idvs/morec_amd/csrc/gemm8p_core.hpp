@@ -5,7 +5,7 @@
 #include "gemm_core.hpp"
 
 namespace g8 {
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef f32x16c_t f32x16_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr int TM = 256, TN = 256, KE = 64;      // tile; K elements per K-tile
@@ -59,7 +59,7 @@ __device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast
 
 // ZERO: the first K-tile of an output tile starts its accumulators from the MFMA's inline-constant 0 operand instead of 128
 // v_mov per lane ahead of the loop.
-template <int M0, int NQ, bool ZERO>
+template <typename T16, int M0, int NQ, bool ZERO>
 __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4 (&fa)[2][4], const uint4 (&fb)[4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -73,8 +73,7 @@ __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4
                     for (int v = 0; v < 16; ++v) cin[v] = 0.f;
                 }
             }
-            acc[M0 + mi][NQ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fb[ks]),
-                                                                       __builtin_bit_cast(bf16x8_t, fa[mi][ks]), cin, 0, 0, 0);
+            acc[M0 + mi][NQ] = h16<T16>::mma32(__builtin_bit_cast(bf16x8_t, fb[ks]), __builtin_bit_cast(bf16x8_t, fa[mi][ks]), cin);
         }
     __builtin_amdgcn_s_setprio(0);
 }
@@ -92,7 +91,7 @@ __device__ __forceinline__ void vm_wait_tail() {
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
 // last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
 // BAUX: cache policy of the B-panel loads (see dma2)
-template <int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0>
+template <typename T16, int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0>
 __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
     const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
     const uint32_t m2 = last2 ? 0xffffffffu : 0u;
@@ -117,7 +116,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
-    mfma_quadrant<0, 0, ZERO>(acc, fa, fb0);
+    mfma_quadrant<T16, 0, 0, ZERO>(acc, fa, fb0);
     bar();
     // ---- phase 1: B-second fragments; refill A-second of t+1
 #pragma unroll
@@ -126,7 +125,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
-    mfma_quadrant<0, 1, ZERO>(acc, fa, fb1);
+    mfma_quadrant<T16, 0, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 2: A-second fragments; refill A-first of t+2 (this buffer)
 #pragma unroll
@@ -137,14 +136,14 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
-    mfma_quadrant<2, 1, ZERO>(acc, fa, fb1);
+    mfma_quadrant<T16, 2, 1, ZERO>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
-    mfma_quadrant<2, 0, ZERO>(acc, fa, fb0);
+    mfma_quadrant<T16, 2, 0, ZERO>(acc, fa, fb0);
     bar();
 }
 
@@ -203,7 +202,7 @@ __device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk)
     do {                                                                                \
         if (st && threadIdx.x == 0) st[(i)] = __builtin_readcyclecounter();              \
     } while (0)
-template <int SLACK, int BAUX = 0>
+template <typename T16, int SLACK, int BAUX = 0>
 __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char* smem, f32x16_t (&acc)[4][2], unsigned long long* st) {
     G8_MSTAMP(8);
     vm_wait<8 + SLACK>();    // A-first, B-first of K-tile 0 (this wave's pieces)
@@ -214,7 +213,7 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     int cb = 0;
     int t = 0;
     if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<2, SLACK, true, BAUX>(smem, c, cb, 0, acc, nk == 3);
+        ktile<T16, 2, SLACK, true, BAUX>(smem, c, cb, 0, acc, nk == 3);
         cb ^= BUF_BYTES;
         t = 1;
     } else {
@@ -227,23 +226,23 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
-        ktile<2, 0, false, BAUX>(smem, c, cb, t * KB, acc, t + 3 == nk);
+        ktile<T16, 2, 0, false, BAUX>(smem, c, cb, t * KB, acc, t + 3 == nk);
         cb ^= BUF_BYTES;
         if (t == 1) G8_MSTAMP(12);
     }
     G8_MSTAMP(13);
-    ktile<1, 0, false, BAUX>(smem, c, cb, t * KB, acc);
-    ktile<0, 0, false, BAUX>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
+    ktile<T16, 1, 0, false, BAUX>(smem, c, cb, t * KB, acc);
+    ktile<T16, 0, 0, false, BAUX>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
     G8_MSTAMP(14);
     if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
     G8_MSTAMP(15);
 }
 // `younger`: VMEM operations this wave has issued since the tile's prologue (only a LOWER bound matters: see vm_wait_tail)
-template <int BAUX = 0>
+template <typename T16, int BAUX = 0>
 __device__ __forceinline__ void mainloop8p(const Ctx& c, int wr, int nk, int younger, char* smem, f32x16_t (&acc)[4][2],
                                            unsigned long long* st) {
-    if (younger >= 32) mainloop8p_s<32, BAUX>(c, wr, nk, smem, acc, st);
-    else if (younger >= 16) mainloop8p_s<16, BAUX>(c, wr, nk, smem, acc, st);
-    else mainloop8p_s<0, BAUX>(c, wr, nk, smem, acc, st);
+    if (younger >= 32) mainloop8p_s<T16, 32, BAUX>(c, wr, nk, smem, acc, st);
+    else if (younger >= 16) mainloop8p_s<T16, 16, BAUX>(c, wr, nk, smem, acc, st);
+    else mainloop8p_s<T16, 0, BAUX>(c, wr, nk, smem, acc, st);
 }
 }  // namespace g8

@@ -57,6 +57,10 @@ __device__ __forceinline__ void mfma_step<bf16>(f32x4_t& acc, const uint4& fn, c
                                                   acc, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ void mfma_step<f16>(f32x4_t& acc, const uint4& fn, const uint4& fm) {
+    acc = h16<f16>::mma16(__builtin_bit_cast(bf16x8_t, fn), __builtin_bit_cast(bf16x8_t, fm), acc);
+}
+template <>
 __device__ __forceinline__ void mfma_step<float>(f32x4_t& acc, const uint4& fn, const uint4& fm) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fn.x), __uint_as_float(fm.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fn.y), __uint_as_float(fm.y), acc, 0, 0, 0);

@@ -13,7 +13,7 @@
 #include "gemm_args.hpp"
 
 int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_stride, int M, int N, int K, int ldy, int ldx, int ldo,
-                         int mchunk, int zs, hipStream_t s);
+                         int mchunk, int zs, int dtype, hipStream_t s);
 
 namespace {
 constexpr int TT = 64;                 // tokens per stage
@@ -48,6 +48,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int ks, int blk) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+template <typename T16>
 __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < KI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < KI; ++j) acc[i][j] = h16<T16>::mma16(fx[j], fy[i], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
             *dst = s;
         } else {
             const float o[4] = {s.x, s.y, s.z, s.w};
-            io<bf16>::store4(C + (size_t)n * ldc + k, o);
+            io<TO>::store4(C + (size_t)n * ldc + k, o);
         }
     }
 }
@@ -191,7 +192,8 @@ extern "C" size_t morec_gemm_tn_workspace_bytes(int N, int K, int split_m) {
 int gemm_tn_launch(const void* DY, const void* X, void* C, int c_dtype, int M, int N, int K, int ldy, int ldx, int ldc, int dtype, int split_m,
                    int accumulate, float* workspace, void* stream) {
     if (!DY || !X || !C || M <= 0 || N <= 0 || K <= 0) return MOREC_E_ARG;
-    if (dtype != MOREC_BF16) return MOREC_E_UNSUPPORTED;   // the exact-fp32 path uses transposed copies + morec_gemm_nt
+    if (!is_h16(dtype)) return MOREC_E_UNSUPPORTED;   // the exact-fp32 path uses transposed copies + morec_gemm_nt
+    if (c_dtype != MOREC_F32 && c_dtype != dtype) return MOREC_E_DTYPE;
     if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldc % 4 || !aligned16(DY) || !aligned16(X) || !aligned16(C)) return MOREC_E_ALIGN;
     if (split_m > 1 && !accumulate && !workspace) return MOREC_E_ARG;      // the atomic path needs a caller-zeroed C
     TnArgs a;
@@ -209,15 +211,17 @@ int gemm_tn_launch(const void* DY, const void* X, void* C, int c_dtype, int M, i
     if (zs > 1 && !a.slabs && !accumulate) return MOREC_E_ARG;
     int r8 = G8_NOT_TAKEN;
     if (a.slabs)                    // split-m partials -> slabs: the eight-phase kernel (gemm_tn8p.hip) when the launch is large enough
-        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.slabs, (size_t)N * K, M, N, K, ldy, ldx, K, mchunk, zs, reinterpret_cast<hipStream_t>(stream));
+        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.slabs, (size_t)N * K, M, N, K, ldy, ldx, K, mchunk, zs, dtype, reinterpret_cast<hipStream_t>(stream));
     else if (zs == 1 && !accumulate)
-        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, reinterpret_cast<hipStream_t>(stream));
+        r8 = gemm_tn8p_try_launch(a.DY, a.X, a.C, 0, M, N, K, ldy, ldx, ldc, mchunk, 1, dtype, reinterpret_cast<hipStream_t>(stream));
     if (r8 != G8_NOT_TAKEN && r8 != MOREC_OK) return r8;
     if (r8 == G8_NOT_TAKEN) {
-        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);   // thread-safe one-time set-up
-        (void)attr_rc;
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN,
-                           reinterpret_cast<hipStream_t>(stream), a);
+        by_h16(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TN);   // thread-safe one-time set-up
+            (void)attr_rc;
+            hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(a.tiles_n * a.tiles_k, 1, zs), dim3(NTHREADS), LDS_TN, reinterpret_cast<hipStream_t>(stream), a);
+        });
         MOREC_CHECK_LAUNCH();
     }
     if (a.slabs) {
@@ -226,9 +230,12 @@ int gemm_tn_launch(const void* DY, const void* X, void* C, int c_dtype, int M, i
         if (c_dtype == MOREC_F32)
             hipLaunchKernelGGL(reduce_slabs_kernel<float>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs, a.C, N,
                                K, ldc, zs, accumulate ? 1 : 0);
-        else
+        else if (c_dtype == MOREC_BF16)
             hipLaunchKernelGGL(reduce_slabs_kernel<bf16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs,
                                reinterpret_cast<bf16*>(C), N, K, ldc, zs, 0);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel<f16>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a.slabs,
+                               reinterpret_cast<f16*>(C), N, K, ldc, zs, 0);
         MOREC_CHECK_LAUNCH();
     }
     return MOREC_OK;

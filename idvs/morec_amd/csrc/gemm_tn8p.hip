@@ -87,20 +87,20 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem, int addr, int ks) 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int N0, int KQ>
+template <typename T16, int N0, int KQ>
 __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const bf16x8_t (&fy)[2][4], const bf16x8_t (&fx)[4]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)      // X fragment as the instruction's A operand: the lane owns ONE n and runs of 4 consecutive k
-            acc[N0 + ni][KQ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[ks], fy[ni][ks], acc[N0 + ni][KQ], 0, 0, 0);
+            acc[N0 + ni][KQ] = h16<T16>::mma32(fx[ks], fy[ni][ks], acc[N0 + ni][KQ]);
     __builtin_amdgcn_s_setprio(0);
 }
 
 // One stage (64 tokens) out of the buffer at byte offset cb.  mo = byte offset (rows x pitch) of this stage's first token in DY
 // (mo * ldx / ldy for X is passed separately); left = tokens of the chunk from this stage's first row on.
-template <int REM>
+template <typename T16, int REM>
 __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy, int sox, int dy_step, int dx_step, int left,
                                       f32x16_t (&acc)[4][2]) {
     char* cur = smem + cb;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 8, 2>();
     bar();
-    mfma_quadrant<0, 0>(acc, fy, fx0);
+    mfma_quadrant<T16, 0, 0>(acc, fy, fx0);
     bar();
     // ---- phase 1: X-second fragments; refill DY-second of t+1
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 8, 0>();
     bar();
-    mfma_quadrant<0, 1>(acc, fy, fx1);
+    mfma_quadrant<T16, 0, 1>(acc, fy, fx1);
     bar();
     // ---- phase 2: DY-second fragments; refill DY-first of t+2 (this buffer)
 #pragma unroll
@@ -140,20 +140,21 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 6, 0>();
     bar();
-    mfma_quadrant<2, 1>(acc, fy, fx1);
+    mfma_quadrant<T16, 2, 1>(acc, fy, fx1);
     bar();
     // ---- phase 3: nothing to read (X-first is still in registers); refill X-first of t+2
     if constexpr (REM >= 2) dma2(c.rx, c.x1, c.tok, left - 2 * TT, sox + 2 * dx_step, cur + OP_BYTES + c.dpiece);
     pin();
     vm_wait_tail<REM, 4, 0>();
     bar();
-    mfma_quadrant<2, 0>(acc, fy, fx0);
+    mfma_quadrant<T16, 2, 0>(acc, fy, fx0);
     bar();
 }
 
 // The panel pointers are __restrict__ for hipcc's s_waitcnt insertion (see gemm8p.hip::tile_body): it tags the LDS-DMA
 // instructions with alias scopes and every ds_read with "does not alias them"; untagged, each ds_read after an LDS-DMA gets
 // a full `s_waitcnt vmcnt(0)`.
+template <typename T16>
 __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16* __restrict__ DYt, const bf16* __restrict__ Xt, int n0, int k0,
                                         int mbeg, int mend, float* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
@@ -211,11 +212,11 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
     if (wr == 1) bar();
     int cb = 0, t = 0;
     for (; t < nt - 2; ++t) {
-        stage<2>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
+        stage<T16, 2>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
         cb ^= BUF_BYTES;
     }
-    stage<1>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
-    stage<0>(smem, c, cb ^ BUF_BYTES, (t + 1) * dy_step, (t + 1) * dx_step, dy_step, dx_step, left0 - (t + 1) * TT, acc);
+    stage<T16, 1>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
+    stage<T16, 0>(smem, c, cb ^ BUF_BYTES, (t + 1) * dy_step, (t + 1) * dx_step, dy_step, dx_step, left0 - (t + 1) * TT, acc);
     if (wr == 0) bar();
 
     // ---- epilogue: acc[Ni][Ki][4 g + r] = C[n0 + wr*128 + Ni*32 + (lane & 31)][k0 + wc*64 + Ki*32 + 8 g + 4 (lane >> 5) + r], fp32.
@@ -258,6 +259,7 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
     }
 }
 
+template <typename T16>
 __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Work items in (token chunk, n-tile, k-tile) order, k fastest, dealt to the XCDs in CONTIGUOUS runs (xcd_remap over the whole
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     const int z = item / tiles, wg = item - z * tiles;
     const int n0 = (wg / p.tiles_k) * 256, k0 = (wg % p.tiles_k) * 256;
     const int mbeg = z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
-    tn_body(p, smem, p.DY + (size_t)mbeg * p.ldy + n0, p.X + (size_t)mbeg * p.ldx + k0, n0, k0, mbeg, mend,
+    tn_body<T16>(p, smem, p.DY + (size_t)mbeg * p.ldy + n0, p.X + (size_t)mbeg * p.ldx + k0, n0, k0, mbeg, mend,
             p.out + (size_t)z * p.slab_stride);
 }
 }  // namespace
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
 // Runs the launch on the eight-phase kernel when it is eligible: returns MOREC_OK / an error, or G8_NOT_TAKEN.
 // `out` = slab workspace ([zs][N][K], fp32) when zs > 1, else C (plain stores: accumulate must be 0).
 int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_stride, int M, int N, int K, int ldy, int ldx, int ldo,
-                         int mchunk, int zs, hipStream_t s) {
+                         int mchunk, int zs, int dtype, hipStream_t s) {
     const int mode = gemm8p_mode();
     if (mode == 1) return G8_NOT_TAKEN;
     if (N % 8 || K % 8 || ldo % 4) return G8_NOT_TAKEN;
@@ -296,9 +298,13 @@ int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_
     TnArgs8 a;
     a.DY = DY; a.X = X; a.out = out; a.M = M; a.N = N; a.K = K; a.ldy = ldy; a.ldx = ldx; a.ldo = ldo; a.mchunk = mchunk;
     a.tiles_n = tiles_n; a.tiles_k = tiles_k; a.zs = zs; a.slab_stride = slab_stride;
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // thread-safe one-time set-up
-    (void)attr_rc;
-    hipLaunchKernelGGL(gemm_tn8p_kernel, dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
+    if (!by_h16(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // thread-safe one-time set-up
+            (void)attr_rc;
+            hipLaunchKernelGGL(gemm_tn8p_kernel<T>, dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
+        }))
+        return G8_NOT_TAKEN;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -264,7 +264,7 @@ extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
     const size_t es = elt_size(d->dtype);
     const size_t ldc = pad8((int)Nc), ldr = pad8((int)Nr);
     size_t bwd = (Nr * ldc + Nc * ldr + D * ldr + D * ldc) * es + 256;
-    if (d->dtype == MOREC_BF16 && Nc % 8 == 0 && D % 8 == 0) {
+    if (is_h16(d->dtype) && Nc % 8 == 0 && D % 8 == 0) {
         const size_t tn = (Nr * ldc + D * ldc) * es + Nc * D * sizeof(float) + (size_t)ce_tn_split((int)Nr, (int)Nc, (int)D) * Nc * D * sizeof(float) + 1024;
         bwd = tn > bwd ? tn : bwd;
     }
@@ -281,7 +281,7 @@ extern "C" size_t morec_inbatch_ce_workspace_bytes(const morec_ce_desc* d) {
 static int ce_fill(const morec_ce_desc* d, CeArgs& a) {
     if (!d || d->B <= 0 || d->S <= 0 || d->D <= 0 || d->Nc <= 0) return MOREC_E_ARG;
     if ((d->D * elt_size(d->dtype)) % 16) return MOREC_E_ALIGN;
-    if (d->dtype != MOREC_F32 && d->dtype != MOREC_BF16) return MOREC_E_DTYPE;
+    if (d->dtype != MOREC_F32 && !is_h16(d->dtype)) return MOREC_E_DTYPE;
     if (d->col_offset < 0 || d->col_offset + d->B * (d->S + 1) > d->Nc) return MOREC_E_ARG;
     a.B = d->B; a.S = d->S; a.D = d->D; a.Nr = d->B * d->S; a.Nc = d->Nc; a.col_offset = d->col_offset;
     a.tiles_m = (a.Nr + 127) / 128; a.tiles_n = (a.Nc + 127) / 128; a.K2 = 2 * a.tiles_n;
@@ -313,16 +313,13 @@ extern "C" int morec_inbatch_ce_fwd(const morec_ce_desc* d, const void* P, const
         rc = ce8p_fwd(d, P, E, row_ids, col_ids, col_logpop, col_valid, row_valid, workspace, &a.pmax, &a.psum, &a.pos, &part8, &a.K2, s);
         if (rc) return rc;
         log2_domain = 1;
-    } else if (d->dtype == MOREC_F32) {
-        using G = GemmTile<float, 2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, dim3(256), G::LDS_BYTES, s, a);
     } else {
-        using G = GemmTile<bf16, 2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<bf16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        hipLaunchKernelGGL((ce_fwd_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
+        by_dtype(d->dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            using G = GemmTile<T, 2>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            hipLaunchKernelGGL((ce_fwd_kernel<T>), grid, dim3(256), G::LDS_BYTES, s, a);
+        });
     }
     MOREC_CHECK_LAUNCH();
     const int n_blocks = (a.Nr + 3) / 4;
@@ -364,21 +361,16 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
     a.dl = dl; a.ld_dl = ldc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid(a.tiles_m * a.tiles_n);
-    if (d->dtype == MOREC_F32) {
-        using G = GemmTile<float, 2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_bwd_dl_kernel<float>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        hipLaunchKernelGGL((ce_bwd_dl_kernel<float>), grid, dim3(256), G::LDS_BYTES, s, a);
-    } else {
-        using G = GemmTile<bf16, 2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_bwd_dl_kernel<bf16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        hipLaunchKernelGGL((ce_bwd_dl_kernel<bf16>), grid, dim3(256), G::LDS_BYTES, s, a);
-    }
+    by_dtype(d->dtype, [&](auto* t) {
+        using T = MOREC_TAG_T(t);
+        using G = GemmTile<T, 2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_bwd_dl_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipLaunchKernelGGL((ce_bwd_dl_kernel<T>), grid, dim3(256), G::LDS_BYTES, s, a);
+    });
     MOREC_CHECK_LAUNCH();
     morec_gemm_desc g{};
     g.in_dtype = d->dtype; g.out_dtype = d->dtype; g.alpha = 1.0f; g.split_k = 1;
-    if (d->dtype == MOREC_BF16 && a.Nc % 8 == 0 && a.D % 8 == 0) {
+    if (is_h16(d->dtype) && a.Nc % 8 == 0 && a.D % 8 == 0) {
         // dE[Nc, D] = dl^T . P straight from the row-major dl and P (transposing LDS reads, morec_gemm_tn): no transposed copies of the
         // Nr x Nc matrix, fp32 result -- handed out as it is when the caller reduces it over ranks (dE_fp32), else cast
         char* Et2 = dl + (((size_t)a.Nr * ldc * es + 15) & ~(size_t)15);
@@ -387,10 +379,10 @@ extern "C" int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const
         float* dEo = d->dE_fp32 ? reinterpret_cast<float*>(dE) : dE32;
         const int split = ce_tn_split(a.Nr, a.Nc, a.D);
         if (split > 1) (void)hipMemsetAsync(dEo, 0, (size_t)a.Nc * a.D * sizeof(float), s);
-        rc = morec_gemm_tn(dl, P, dEo, a.Nr, a.Nc, a.D, ldc, a.D, a.D, MOREC_BF16, split, split > 1 ? 1 : 0, split > 1 ? slabs : nullptr, stream);
+        rc = morec_gemm_tn(dl, P, dEo, a.Nr, a.Nc, a.D, ldc, a.D, a.D, d->dtype, split, split > 1 ? 1 : 0, split > 1 ? slabs : nullptr, stream);
         if (rc) return rc;
         if (!d->dE_fp32) {
-            rc = morec_cast(dE32, dE, (size_t)a.Nc * a.D, MOREC_F32, MOREC_BF16, stream);
+            rc = morec_cast(dE32, dE, (size_t)a.Nc * a.D, MOREC_F32, d->dtype, stream);
             if (rc) return rc;
         }
         // dP[Nr, D] = dl[Nr, Nc] . Et[D, Nc]^T
@@ -508,9 +500,11 @@ extern "C" int morec_bce_fwd(const void* P, const void* E, const uint8_t* row_va
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((B * S + 3) / 4);
-    if (dtype == MOREC_F32) hipLaunchKernelGGL((bce_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)P, (const float*)E, row_valid, scores, loss_sum, B, S, D);
-    else if (dtype == MOREC_BF16) hipLaunchKernelGGL((bce_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)P, (const bf16*)E, row_valid, scores, loss_sum, B, S, D);
-    else return MOREC_E_DTYPE;
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((bce_fwd_kernel<T>), grid, dim3(256), 0, s, (const T*)P, (const T*)E, row_valid, scores, loss_sum, B, S, D);
+        }))
+        return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -521,9 +515,11 @@ extern "C" int morec_bce_bwd(const void* P, const void* E, const uint8_t* row_va
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((B * (S + 1) + 3) / 4);
-    if (dtype == MOREC_F32) hipLaunchKernelGGL((bce_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)P, (const float*)E, row_valid, scores, gscale, (float*)dP, (float*)dE, B, S, D);
-    else if (dtype == MOREC_BF16) hipLaunchKernelGGL((bce_bwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)P, (const bf16*)E, row_valid, scores, gscale, (bf16*)dP, (bf16*)dE, B, S, D);
-    else return MOREC_E_DTYPE;
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((bce_bwd_kernel<T>), grid, dim3(256), 0, s, (const T*)P, (const T*)E, row_valid, scores, gscale, (T*)dP, (T*)dE, B, S, D);
+        }))
+        return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -43,11 +43,13 @@ __host__ __device__ inline int lane_order(int c64) {
 }
 
 // ---- prep: tab[u][Ncp] flags and lpp[Ncp] = log2(e) * log-popularity, both in lane order per 64-column chunk (Ncp = tiles_n * 256)
+template <typename T16>
 __device__ __forceinline__ void ce8p_pos_rows(const bf16* __restrict__ P, const bf16* __restrict__ E, const float* __restrict__ col_logpop,
                                               const uint8_t* __restrict__ col_valid, float* __restrict__ pos, int u, int j, int S, int D, int col_offset);
 
 // blockIdx.y = user.  Blocks x < prep_blocks build the flag table / log-pop row; the blocks behind them compute the user's positive
 // logits (four rows each): one launch for the two independent pieces of bookkeeping.
+template <typename T16>
 __global__ __launch_bounds__(256) void ce8p_prep_kernel(const int32_t* __restrict__ row_ids, const int32_t* __restrict__ col_ids,
                                                         const float* __restrict__ col_logpop, const uint8_t* __restrict__ col_valid,
                                                         uint8_t* __restrict__ tab, float* __restrict__ lpp, int B, int S1, int Nc, int Ncp,
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void ce8p_prep_kernel(const int32_t* __restric
     const int u = blockIdx.y;
     if ((int)blockIdx.x >= prep_blocks) {
         const int j = ((int)blockIdx.x - prep_blocks) * 4 + (int)(threadIdx.x >> 6);
-        if (j < S1 - 1) ce8p_pos_rows(P, E, col_logpop, col_valid, pos, u, j, S1 - 1, D, col_offset);
+        if (j < S1 - 1) ce8p_pos_rows<T16>(P, E, col_logpop, col_valid, pos, u, j, S1 - 1, D, col_offset);
         return;
     }
     for (int i = threadIdx.x; i < S1; i += blockDim.x) s_uid[i] = row_ids[u * S1 + i];
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void ce8p_prep_kernel(const int32_t* __restric
 // slot, :51-52 -- only on rows that are dropped anyway): one wavefront per row.  Separate from the tile kernel so that its inner loop
 // carries no "is this my label" select per cell; the forward needs it for loss = lse - pos, the backward for the one cell per row
 // whose gradient is softmax - 1.  Runs in the tail blocks of ce8p_prep_kernel.
+template <typename T16>
 __device__ __forceinline__ void ce8p_pos_rows(const bf16* __restrict__ P, const bf16* __restrict__ E, const float* __restrict__ col_logpop,
                                               const uint8_t* __restrict__ col_valid, float* __restrict__ pos, int u, int j, int S, int D, int col_offset) {
     const int lane = threadIdx.x & 63;
@@ -106,8 +109,8 @@ __device__ __forceinline__ void ce8p_pos_rows(const bf16* __restrict__ P, const 
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            acc = fmaf(bfbits2f(aw[k] & 0xffffu), bfbits2f(bw[k] & 0xffffu), acc);
-            acc = fmaf(bfbits2f(aw[k] >> 16), bfbits2f(bw[k] >> 16), acc);
+            acc = fmaf(h16<T16>::bits2f(aw[k] & 0xffffu), h16<T16>::bits2f(bw[k] & 0xffffu), acc);
+            acc = fmaf(h16<T16>::bits2f(aw[k] >> 16), h16<T16>::bits2f(bw[k] >> 16), acc);
         }
     }
     acc = wave_sum(acc);
@@ -141,7 +144,7 @@ __device__ __forceinline__ void logits2_row(float (&x)[32], const f32x16_t (&a)[
     }
 }
 
-template <bool BWD>
+template <typename T16, bool BWD>
 __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16* __restrict__ Pc, const bf16* __restrict__ Ec,
                                         const bf16* __restrict__ Pn, const bf16* __restrict__ En, const Tile8 cur, const Tile8 nxt,
                                         const bool first, const int nk, const int krem) {
@@ -152,7 +155,7 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
         Ctx c;
         make_ctx(c, tid_m, Pc, Ec, p.Nr - cur.m0, p.Nc - cur.n0, p.D, p.D, krem);
         if (first) issue_prologue<E_AUX<BWD>>(c, smem, nk);
-        mainloop8p<E_AUX<BWD>>(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, 0, smem, acc, nullptr);
+        mainloop8p<T16, E_AUX<BWD>>(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), nk, 0, smem, acc, nullptr);
     }
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
@@ -254,7 +257,7 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
 #pragma unroll
             for (int k = 0; k < 32; k += 2) {      // pairs k, k + 1 = consecutive columns, same row: two 2-byte cells of different LDS rows
                 const float d0 = w * __builtin_amdgcn_exp2f(x[k] - lse2), d1 = w * __builtin_amdgcn_exp2f(x[k + 1] - lse2);
-                const uint32_t pk = pack_bf16x2(d0, d1);
+                const uint32_t pk = h16<T16>::pack2(d0, d1);
                 const int cl = (k >> 4) * 32 + ((k >> 2) & 3) * 8 + 4 * h + (k & 3);     // column within the chunk
                 ws16[cl * 32 + r5] = (unsigned short)(pk & 0xffffu);
                 ws16[(cl + 1) * 32 + r5] = (unsigned short)(pk >> 16);
@@ -264,7 +267,7 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
                 const int cl = (k >> 4) * 32 + ((k >> 2) & 3) * 8 + 4 * h + (k & 3);
                 const float pos = rpos2[Mi];
                 const float d = pos == MASKED_LOGIT ? 0.f : w * (__builtin_amdgcn_exp2f(pos * LOG2E - lse2) - 1.f);
-                ws16[cl * 32 + r5] = f2bf_bits(d);
+                ws16[cl * 32 + r5] = h16<T16>::bits(d);
             }
             wfence();
             // read back [64 columns][64 B]: lane -> column (lane >> 2) + 16 i, 16-byte slot lane & 3 (8 rows m)
@@ -281,7 +284,7 @@ __device__ __forceinline__ void ce_tile(const Ce8Args& p, char* smem, const bf16
     }
 }
 
-template <bool BWD>
+template <typename T16, bool BWD>
 __global__ __launch_bounds__(THREADS) void ce8p_kernel(Ce8Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(THREADS) void ce8p_kernel(Ce8Args p) {
     Tile8 cur = unit_at(0);
     for (int i = 0; i < n_units; ++i) {
         const Tile8 nxt = i + 1 < n_units ? unit_at(i + 1) : cur;
-        ce_tile<BWD>(p, smem, p.P + (size_t)cur.m0 * p.D, p.E + (size_t)cur.n0 * p.D, p.P + (size_t)nxt.m0 * p.D, p.E + (size_t)nxt.n0 * p.D,
+        ce_tile<T16, BWD>(p, smem, p.P + (size_t)cur.m0 * p.D, p.E + (size_t)cur.n0 * p.D, p.P + (size_t)nxt.m0 * p.D, p.E + (size_t)nxt.n0 * p.D,
                      cur, nxt, i == 0, nk, krem);
         cur = nxt;
     }
@@ -324,7 +327,7 @@ int g_ce8p_mode = 0;
 bool ce8p_eligible(const morec_ce_desc* d) {
     const long Nr = (long)d->B * d->S;
     if (g_ce8p_mode == 1) return false;
-    if (d->dtype != MOREC_BF16 || d->D % 8 || d->D <= KE || d->Nc % 8 || Nr % 8) return false;
+    if (!is_h16(d->dtype) || d->D % 8 || d->D <= KE || d->Nc % 8 || Nr % 8) return false;
     if ((long)d->Nc * d->D * 2 >= 0x7fffffffL || Nr * d->D * 2 >= 0x7fffffffL) return false;      // 32-bit DMA offsets within a panel run
     // enough 256 x 256 tiles to give most CUs one (below that the 128 x 128 kernels fill the chip better)
     if (g_ce8p_mode == 2) return true;
@@ -369,10 +372,13 @@ static int ce8p_prep(const morec_ce_desc* d, const Ce8Layout& L, char* ws, const
     const int S1 = d->S + 1;
     const int prep_blocks = (L.Ncp / 4 + 255) / 256;
     dim3 grid(prep_blocks + (d->S + 3) / 4, d->B);
-    hipLaunchKernelGGL(ce8p_prep_kernel, grid, dim3(256), S1 * sizeof(int32_t), s, row_ids, col_ids, col_logpop, col_valid,
+    by_h16(d->dtype, [&](auto* t) {
+        using T = MOREC_TAG_T(t);
+        hipLaunchKernelGGL(ce8p_prep_kernel<T>, grid, dim3(256), S1 * sizeof(int32_t), s, row_ids, col_ids, col_logpop, col_valid,
                        reinterpret_cast<uint8_t*>(ws + L.off_tab), reinterpret_cast<float*>(ws + L.off_lpp), d->B, S1, d->Nc, L.Ncp, prep_blocks,
                        reinterpret_cast<const bf16*>(P), reinterpret_cast<const bf16*>(E), reinterpret_cast<float*>(ws + L.off_pos), d->D,
                        d->col_offset);
+    });
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -386,12 +392,12 @@ static void ce8p_fill(const morec_ce_desc* d, const Ce8Layout& L, char* ws, cons
     a.K2 = L.K2; a.Ncp = L.Ncp; a.ldr = L.ldr; a.tiles_m = L.tiles_m; a.tiles_n = L.tiles_n;
 }
 
-template <bool BWD>
+template <typename T16, bool BWD>
 static int ce8p_launch(const Ce8Args& a, hipStream_t s) {
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&ce8p_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&ce8p_kernel<T16, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     (void)attr_rc;
     const int nwg = a.tiles_m * a.tiles_n, ncu = n_cus();
-    hipLaunchKernelGGL((ce8p_kernel<BWD>), dim3(nwg < ncu ? nwg : ncu), dim3(THREADS), LDS_TOTAL, s, a);
+    hipLaunchKernelGGL((ce8p_kernel<T16, BWD>), dim3(nwg < ncu ? nwg : ncu), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
@@ -410,7 +416,7 @@ int ce8p_fwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t
     a.pmax = reinterpret_cast<float*>(ws + L.off_pmax); a.psum = reinterpret_cast<float*>(ws + L.off_psum);
     *pmax = a.pmax; *psum = a.psum; *pos = a.pos; *K2 = L.K2;
     *part = reinterpret_cast<float*>(ws + L.off_part);
-    return ce8p_launch<false>(a, s);
+    return d->dtype == MOREC_F16 ? ce8p_launch<f16, false>(a, s) : ce8p_launch<bf16, false>(a, s);
 }
 
 int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t* row_ids, const int32_t* col_ids, const float* col_logpop,
@@ -427,26 +433,26 @@ int ce8p_bwd(const morec_ce_desc* d, const void* P, const void* E, const int32_t
     a.row_lse = row_lse; a.gscale_dev = gscale_dev; a.gscale = gscale;
     a.dlt = reinterpret_cast<bf16*>(ws + L.off_dlt);
     // (every column m < ldr of every row c < Nc is written by some tile -- tiles_m * 256 >= ldr -- with zeros for m >= Nr)
-    rc = ce8p_launch<true>(a, s);
+    rc = d->dtype == MOREC_F16 ? ce8p_launch<f16, true>(a, s) : ce8p_launch<bf16, true>(a, s);
     if (rc) return rc;
     void* stream = reinterpret_cast<void*>(s);
     // dE[Nc, D] = dlt[Nc, Nr] . Pt[D, Nr]^T: one NT GEMM, fp32 (handed out as it is when the caller reduces it over ranks)
     bf16* Pt = reinterpret_cast<bf16*>(ws + L.off_pt);
     // (the pad columns of Pt / dlt are never read: K = Nr with pitch ldr, a partial last K-tile is zero-filled by the GEMM)
-    rc = morec_transpose(P, Pt, Nr, D, D, L.ldr, MOREC_BF16, MOREC_BF16, stream);
+    rc = morec_transpose(P, Pt, Nr, D, D, L.ldr, d->dtype, d->dtype, stream);
     if (rc) return rc;
     morec_gemm_desc g{};
-    g.in_dtype = MOREC_BF16; g.alpha = 1.0f; g.split_k = 1;
+    g.in_dtype = d->dtype; g.alpha = 1.0f; g.split_k = 1;
     g.M = Nc; g.N = D; g.K = Nr; g.lda = L.ldr; g.ldb = L.ldr; g.ldc = D;
-    g.out_dtype = d->dE_fp32 ? MOREC_F32 : MOREC_BF16;
+    g.out_dtype = d->dE_fp32 ? MOREC_F32 : d->dtype;
     rc = morec_gemm_nt(&g, a.dlt, Pt, dE, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     // dP[Nr, D] = sum_c dlt[c, r] E[c, d]: the transposing GEMM, contraction over the Nc columns cut into tn_split chunks
     if (L.tn_split > 1)      // the slab fold rounds the sum straight into dP: no zero-fill, no fp32 copy, no conversion pass
-        return gemm_tn_launch(a.dlt, E, dP, MOREC_BF16, Nc, Nr, D, L.ldr, D, D, MOREC_BF16, L.tn_split, 0, reinterpret_cast<float*>(ws + L.off_slabs),
+        return gemm_tn_launch(a.dlt, E, dP, d->dtype, Nc, Nr, D, L.ldr, D, D, d->dtype, L.tn_split, 0, reinterpret_cast<float*>(ws + L.off_slabs),
                               stream);
     float* dP32 = reinterpret_cast<float*>(ws + L.off_dp32);
-    rc = morec_gemm_tn(a.dlt, E, dP32, Nc, Nr, D, L.ldr, D, D, MOREC_BF16, 1, 0, nullptr, stream);
+    rc = morec_gemm_tn(a.dlt, E, dP32, Nc, Nr, D, L.ldr, D, D, d->dtype, 1, 0, nullptr, stream);
     if (rc) return rc;
-    return morec_cast(dP32, dP, (size_t)Nr * D, MOREC_F32, MOREC_BF16, stream);
+    return morec_cast(dP32, dP, (size_t)Nr * D, MOREC_F32, d->dtype, stream);
 }

@@ -360,6 +360,8 @@ extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void*
         return ln_fwd_dispatch<float>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, rowscale, rows_per_scale, s);
     if (dtype == MOREC_BF16)
         return ln_fwd_dispatch<bf16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, rowscale, rows_per_scale, s);
+    if (dtype == MOREC_F16)
+        return ln_fwd_dispatch<f16>(x, bias, res, pos, pos_period, gamma, beta, eps, z_out, y, mean, rstd, M, N, din, dout, rowscale, rows_per_scale, s);
     return MOREC_E_DTYPE;
 }
 
@@ -433,6 +435,8 @@ extern "C" int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const voi
         return ln_bwd_dispatch<float>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rows_per_scale, s);
     if (dtype == MOREC_BF16)
         return ln_bwd_dispatch<bf16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rows_per_scale, s);
+    if (dtype == MOREC_F16)
+        return ln_bwd_dispatch<f16>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rows_per_scale, s);
     return MOREC_E_DTYPE;
 }
 
@@ -457,15 +461,12 @@ extern "C" int morec_pos_grad(const void* dz, float* dpos, int M, int N, int per
     dim3 grid(period, (M / period + spb - 1) / spb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 16-byte column vectors, several rows in flight (pos_grad.hpp); the scalar kernel keeps the row widths that do not fit
-    if (dtype == MOREC_F32) {
-        if (!pos_type_grad_launch<float>((const float*)dz, dpos, nullptr, M / period, period, N, s))
-            hipLaunchKernelGGL((pos_grad_kernel<float>), grid, dim3(256), 0, s, (const float*)dz, dpos, M, N, period, spb);
-    } else if (dtype == MOREC_BF16) {
-        if (!pos_type_grad_launch<bf16>((const bf16*)dz, dpos, nullptr, M / period, period, N, s))
-            hipLaunchKernelGGL((pos_grad_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)dz, dpos, M, N, period, spb);
-    } else {
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            if (!pos_type_grad_launch<T>((const T*)dz, dpos, nullptr, M / period, period, N, s))
+                hipLaunchKernelGGL((pos_grad_kernel<T>), grid, dim3(256), 0, s, (const T*)dz, dpos, M, N, period, spb);
+        }))
         return MOREC_E_DTYPE;
-    }
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -22,8 +22,14 @@ def _module(model):
 
 def get_item_embeddings(model, item_content, test_batch_size, args, use_modal, local_rank):
     """``metrics.py:60-74``: encode every item (row 0 = padding item) in eval mode, no grad -> fp32 [item_num+1, D].
-    Stays on the device (the reference round-trips through the CPU)."""
+    Stays on the device (the reference round-trips through the CPU).  Runs under the model's fp32-GEMM mode (``compute_dtype``
+    fp32x3: the encoders called on their own would otherwise fall back to the exact-fp32 MFMA)."""
     model.eval()
+    with ops.fp32_gemm_mode(getattr(_module(model), "fp32_gemm", ops.FP32_GEMM)):
+        return _get_item_embeddings(model, item_content, test_batch_size, args, use_modal, local_rank)
+
+
+def _get_item_embeddings(model, item_content, test_batch_size, args, use_modal, local_rank):
     m = _module(model)
     vision = bool(use_modal and getattr(m, "vision", False))
     # vision (``get_itemLMDB_embeddings``, V/data_utils/metrics.py:63-76): ``item_content`` is the decoded image tensor
@@ -78,7 +84,7 @@ def eval_ranks(model, user_history, eval_seq, item_embeddings, users, args, loca
         hist[r, :len(h)] = h
         target[r] = seq[-1]
     dev = item_embeddings.device
-    with torch.no_grad():
+    with torch.no_grad(), ops.fp32_gemm_mode(getattr(m, "fp32_gemm", ops.FP32_GEMM)):
         embs = item_embeddings[torch.from_numpy(idx).to(dev)]                      # [U, S, D] gather (plumbing)
         prec = m.user_encoder(embs, torch.from_numpy(lm).to(dev), local_rank)[:, -1].float().contiguous()
         return ops.eval_rank(prec, item_embeddings.contiguous(), torch.from_numpy(hist).to(dev),

@@ -124,7 +124,7 @@ class WgradStream:
 
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
     """dw[N, K] += dy[M, N]^T @ x[M, K]  (split over M, slabs folded in a fixed order; on the weight-gradient stream, see ``WgradStream``)."""
-    if dy.dtype == torch.bfloat16 and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+    if ops.is16(dy.dtype) and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
         M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
         side = WgradStream.get(dy.device)
         if side is None:
@@ -617,7 +617,7 @@ def ce_inputs_local(sample_items_id: torch.Tensor, log_mask: torch.Tensor, log_p
 def ce_forward(ci: CeInputs, P: torch.Tensor, E: torch.Tensor, dE_fp32: bool = False):
     """P [B*S, D], E [Nc, D] (compute dtype).  Returns (loss_sum fp32[1] on device, saved).  ``dE_fp32``: the backward hands dE out
     in fp32 (pooled negatives: it is reduce-scattered over ranks before it is rounded to the compute dtype)."""
-    dE_fp32 = bool(dE_fp32) and P.dtype == torch.bfloat16 and E.shape[0] % 8 == 0 and P.shape[1] % 8 == 0
+    dE_fp32 = bool(dE_fp32) and ops.is16(P.dtype) and E.shape[0] % 8 == 0 and P.shape[1] % 8 == 0
     desc = ops.ce_desc(ci.B, ci.S, P.shape[1], E.shape[0], ci.col_offset, P.dtype, dE_fp32)
     ws = ops.ce_workspace(desc, P.device)
     loss_sum, lse, _ = ops.inbatch_ce_fwd(desc, P, E, ci.row_ids, ci.col_ids, ci.col_logpop, ci.col_valid, ci.row_valid, ws)

@@ -7,7 +7,7 @@ from torch import nn
 from torch.nn.init import xavier_normal_
 
 from .. import ops
-from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, resolve_dtype
+from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, resolve_dtype, resolve_fp32_gemm
 
 
 class BceLossFn(torch.autograd.Function):
@@ -39,6 +39,7 @@ class BceModel(nn.Module):
         self.use_modal = use_modal
         self.max_seq_len = args.max_seq_len + 1          # bce model.py:13
         self.compute_dtype = resolve_dtype(args)
+        self.fp32_gemm = resolve_fp32_gemm(args)          # "exact" | "bf16x3": how fp32 GEMMs run for this model (ops.FP32_GEMM)
         self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
                                          num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
                                          n_layers=args.transformer_block, compute_dtype=self.compute_dtype)
@@ -50,6 +51,10 @@ class BceModel(nn.Module):
         self.criterion = nn.BCEWithLogitsLoss()          # attribute compatibility; unused
 
     def forward(self, sample_items, log_mask, local_rank=None):
+        with ops.fp32_gemm_mode(self.fp32_gemm):      # the autograd shells carry the mode into their backward
+            return self._forward(sample_items, log_mask, local_rank)
+
+    def _forward(self, sample_items, log_mask, local_rank=None):
         D = self.args.embedding_dim
         if self.use_modal:
             E = self.bert_encoder.encode(sample_items.reshape(-1, sample_items.shape[-1]))

@@ -19,7 +19,7 @@ def resolve_dtype(args=None) -> torch.dtype:
     tensors everywhere, the GEMMs as three bf16 MFMA passes over hi / lo splits of both operands (``resolve_fp32_gemm``)."""
     name = getattr(args, "compute_dtype", None) or os.environ.get("MOREC_DTYPE", "bf16")
     return {"fp32": torch.float32, "float32": torch.float32, "fp32x3": torch.float32, "bf16": torch.bfloat16,
-            "bfloat16": torch.bfloat16}[str(name)]
+            "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}[str(name)]
 
 
 def resolve_fp32_gemm(args=None) -> str:

@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, AttnDesc, CeDesc, GemmDesc, SwinAttnDesc, check
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F16, F32, AttnDesc, CeDesc, GemmDesc, SwinAttnDesc, check
 
 FLT_MIN_MASK = -3.4028234663852886e38  # torch.finfo(torch.float32).min: HF eager additive key mask
 
@@ -19,6 +19,8 @@ def code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     raise _lib.MorecError(f"unsupported dtype {dt}")
 
 
@@ -36,6 +38,11 @@ def _dev(t):
     if not t.is_contiguous():
         raise _lib.MorecError("tensor must be contiguous")
     return t
+
+
+def is16(dt: torch.dtype) -> bool:
+    """bf16 or fp16: the two 16-bit storage types of the MFMA paths (``MOREC_BF16`` / ``MOREC_F16``)."""
+    return dt in (torch.bfloat16, torch.float16)
 
 
 def pad8(n: int) -> int:
@@ -404,6 +411,43 @@ def bce_bwd(P, E, row_valid, scores, gscale_dev, B, S):
 def adamw_(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     check(_lib.lib().morec_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), param.numel(), lr, beta1,
                                  beta2, eps, wd, step, grad_scale, _stream()), "morec_adamw")
+
+
+class StepParams:
+    """The device-resident step block (``morec_step_params``: step count, bias corrections, loss scale, overflow flag): what the
+    reference keeps in ``GradScaler()`` + AdamW's ``step`` (``T/run.py:210,243-247``).  ``init_scale`` 1.0 = no loss scaling."""
+
+    def __init__(self, device, init_scale=1.0, step=0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, dynamic=True):
+        self.buf = torch.zeros(64, device=device, dtype=torch.uint8)
+        self.f32 = self.buf.view(torch.float32)       # [16]: loss_scale at index 4
+        self.i32 = self.buf.view(torch.int32)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.dynamic = bool(dynamic)
+        check(_lib.lib().morec_step_params_init(_p(self.buf), float(init_scale), int(step), _stream()), "morec_step_params_init")
+
+    @property
+    def loss_scale_dev(self):
+        """fp32 [1] view of the scale the next backward pass multiplies the loss gradient with (no host read)."""
+        return self.f32[4:5]
+
+    def check_finite_(self, grad):
+        check(_lib.lib().morec_grad_check_finite(_p(grad), grad.numel(), _p(self.buf), _stream()), "morec_grad_check_finite")
+
+    def decide_(self, beta1, beta2):
+        check(_lib.lib().morec_step_decide(_p(self.buf), beta1, beta2, self.growth_factor, self.backoff_factor, self.growth_interval,
+                                           int(self.dynamic), _stream()), "morec_step_decide")
+
+    def host(self):
+        """Host copy of the block (synchronises): for logging / checkpoints, never inside the step."""
+        raw = bytes(self.buf.cpu().numpy().tobytes())
+        return _lib.StepParams.from_buffer_copy(raw)
+
+
+def adamw_sp_(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, sp: StepParams):
+    """``morec_adamw_sp``: AdamW with step count / bias corrections / 1 / loss-scale read from the device block; a no-op when the
+    step was marked for skipping (non-finite gradient)."""
+    check(_lib.lib().morec_adamw_sp(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(shadow), code(shadow.dtype) if shadow is not None else BF16,
+                                    param.numel(), lr, beta1, beta2, eps, wd, _p(sp.buf), _stream()), "morec_adamw_sp")
 
 
 def eval_rank(prec, item_emb, hist32, target32):

@@ -36,7 +36,9 @@ def _round8(n: int) -> int:
 class ParamArena:
     """Flat fp32 storage (+ grad, AdamW moments, optional bf16 shadow) for an ordered set of parameters."""
 
-    def __init__(self, named_params, device, shadow: bool):
+    def __init__(self, named_params, device, shadow):
+        """``shadow``: 16-bit compute dtype of the copy the GEMMs read (``torch.bfloat16`` / ``torch.float16``) or None / False."""
+        shadow = torch.bfloat16 if shadow is True else (shadow or None)
         self.offsets = OrderedDict()
         off = 0
         for name, p in named_params:
@@ -47,13 +49,13 @@ class ParamArena:
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
         self.exp_avg = torch.zeros(off, device=device, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(off, device=device, dtype=torch.float32)
-        self.shadow = torch.zeros(off, device=device, dtype=torch.bfloat16) if shadow else None
+        self.shadow = torch.zeros(off, device=device, dtype=shadow) if shadow else None
         for name, p in named_params:
             o, n, shp = self.offsets[name]
             self.data[o:o + n].view(shp).copy_(p.data)
             p.data = self.data[o:o + n].view(shp)       # the module now reads/writes the arena
         if shadow:
-            ops.cast(self.data, torch.bfloat16, out=self.shadow)
+            ops.cast(self.data, shadow, out=self.shadow)
 
     def view(self, buf, name):
         o, n, shp = self.offsets[name]
@@ -129,7 +131,12 @@ def _order_swin(names):
 class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
                  betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False,
-                 force_collectives: bool = False, comm: str | None = None):
+                 force_collectives: bool = False, comm: str | None = None, loss_scale: float | None = None,
+                 dynamic_loss_scale: bool = True, growth_interval: int = 2000):
+        """``loss_scale`` / ``dynamic_loss_scale`` / ``growth_interval``: the GradScaler of the reference's fp16 step (``T/run.py:210``:
+        defaults 65536, x2 after 2000 clean steps, x0.5 and a skipped step on inf / NaN), kept in a device block (``ops.StepParams``).
+        Engaged automatically for ``compute_dtype == "fp16"``; ``loss_scale=`` a number forces it on for the other dtypes too
+        (``MOREC_STEP_PARAMS=1``: with scale 1) -- the device-resident step state without the scaling."""
         self.model = model
         # SURVEY.md §8(f)-2: encode every DISTINCT item of the batch once (the reference re-encodes duplicates: Zipf-popular
         # items fill many of the B (S + 1) slots) and gather the vectors back to the slots; the slot gradients are
@@ -165,7 +172,7 @@ class TrainStep:
         else:
             g0 = _order_bert([n for n in train if "bert_model" in n])      # T/run.py:155: 'bert_model' in name
             g1 = [n for n in train if "bert_model" not in n]
-        use_shadow = self.dtype == torch.bfloat16
+        use_shadow = self.dtype if ops.is16(self.dtype) else None
         self.groups = []
         if g0:
             self.groups.append(dict(arena=ParamArena([(n, named[n]) for n in g0], self.device, use_shadow),
@@ -201,6 +208,13 @@ class TrainStep:
             self.comm, self.comm_grad = MorecComm(), MorecComm()
             self._grad_stream = torch.cuda.Stream(device=self.device)
         self.log_pop = torch.log(model.pop_prob_list).to(self.device)
+        # Device-resident step state (step count, AdamW bias corrections, loss scale, overflow flag).  fp16 activation gradients need the
+        # loss scaling (their range ends at 6e-8); the other dtypes run it on request only.
+        self.sp = None
+        if self.dtype == torch.float16 or loss_scale is not None or os.environ.get("MOREC_STEP_PARAMS", "0") == "1":
+            init = float(loss_scale) if loss_scale is not None else (65536.0 if self.dtype == torch.float16 else 1.0)
+            self.sp = ops.StepParams(self.device, init_scale=init, step=0, growth_interval=growth_interval,
+                                     dynamic=bool(dynamic_loss_scale) and (self.dtype == torch.float16 or loss_scale is not None))
         self.buckets = self._bucket_plan()
         self._pending, self._reduced, self._stepped = [], [], []
         self._fused_update = False
@@ -354,13 +368,13 @@ class TrainStep:
             with torch.cuda.stream(side):
                 ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
                 n_valid = ci.row_valid.sum(dtype=torch.float32)
-                gscale = (1.0 / n_valid).reshape(1)
+                gscale = self._gscale(n_valid)
                 self._prepare_step_buffers()
             engine.WgradStream._dirty.add(self.device)
         else:
             ci = engine.ce_inputs_local(ids, log_mask, self.log_pop)
             n_valid = ci.row_valid.sum(dtype=torch.float32)
-            gscale = (1.0 / n_valid).reshape(1)
+            gscale = self._gscale(n_valid)
             self._prepare_step_buffers()
         self._pending, self._reduced, self._stepped = [], [], []
         # gradient dict handed to the engine: arena views; frozen tensors get scratch buffers
@@ -403,7 +417,7 @@ class TrainStep:
         Epool = E
         if self.collectives and self.pool:      # two collectives: item vectors + one packed (ids | log-pop | validity | n_valid) record
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank, self.comm)
-            gscale = (1.0 / n_valid).reshape(1)
+            gscale = self._gscale(n_valid)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.collectives and self.pool))
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
         dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype, self.comm) if (self.collectives and self.pool) else dEpool
@@ -422,6 +436,12 @@ class TrainStep:
         engine.WgradStream.join(self.device)       # the weight gradients of the side stream are final from here on
         ops.x3_cache_clear()
         return loss_sum[0] / n_valid
+
+    def _gscale(self, n_valid):
+        """Device scalar the loss gradient starts from: 1 / n_valid, times the loss scale of the step block when there is one."""
+        if self.sp is None:
+            return (1.0 / n_valid).reshape(1)
+        return (self.sp.loss_scale_dev / n_valid).reshape(1)
 
     def _prepare_step_buffers(self):
         if self._wt_batch is not None:
@@ -476,7 +496,7 @@ class TrainStep:
         bucket's weight-gradient GEMMs, UNDER the rest of the backward pass (28 B / parameter of HBM traffic next to MFMA-bound
         GEMMs) instead of after it.  Safe: nothing later in this step reads these weights again -- the backward walks the layers
         downwards -- and the bf16 shadow / W^T copies are only read by the next step."""
-        if not self._fused_update:
+        if not self._fused_update or self.sp is not None:      # with a step block the update waits for the overflow verdict of the WHOLE step
             return
         side = engine.WgradStream.get(self.device)
         if side is None:
@@ -546,7 +566,7 @@ class TrainStep:
         for grp in self.groups:
             a = grp["arena"]
             if a.shadow is not None:
-                ops.cast(a.data, torch.bfloat16, out=a.shadow)
+                ops.cast(a.data, a.shadow.dtype, out=a.shadow)
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """``model.load_state_dict`` + ``sync_shadow`` (the parameters are views of the arenas, so the copy lands there)."""
@@ -577,12 +597,13 @@ class TrainStep:
         groups, so that ``save_model`` / ``load_model`` (``T/data_utils/utils.py:107-114``, ``T/run.py:193-195``) and a plain
         ``optim.AdamW`` can exchange checkpoints with a ``--fused_step`` run."""
         state, groups, idx = {}, [], 0
+        n_applied = self.applied_steps()
         for names in self._reference_param_order():
             grp = self._arena_of(names[0])
             ids = []
             for n in names:
                 a = self._arena_of(n)["arena"]
-                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": a.view(a.exp_avg, n).detach().clone(),
+                state[idx] = {"step": torch.tensor(float(n_applied)), "exp_avg": a.view(a.exp_avg, n).detach().clone(),
                               "exp_avg_sq": a.view(a.exp_avg_sq, n).detach().clone()}
                 ids.append(idx)
                 idx += 1
@@ -608,6 +629,23 @@ class TrainStep:
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one step count")
         self.step_count = steps.pop() if steps else 0
+        if self.sp is not None:      # the device block carries the step count the bias corrections are formed from
+            h = self.sp.host()
+            self.sp.i32[0:1].fill_(self.step_count)
+            del h
+
+    def applied_steps(self) -> int:
+        """Optimizer steps that really updated the parameters (synchronises when a step block is in use: steps skipped for a non-finite
+        gradient do not count, exactly as torch's AdamW ``step`` under GradScaler)."""
+        return int(self.sp.host().step) if self.sp is not None else self.step_count
+
+    def scaler_state_dict(self):
+        """``GradScaler.state_dict()`` of the device block (``T/run.py`` never saves it; offered for exact resumption)."""
+        if self.sp is None:
+            return {}
+        h = self.sp.host()
+        return {"scale": float(h.loss_scale), "growth_factor": self.sp.growth_factor, "backoff_factor": self.sp.backoff_factor,
+                "growth_interval": self.sp.growth_interval, "_growth_tracker": int(h.growth_tracker)}
 
     def global_loss(self, loss):
         """With pooled negatives ``step`` returns THIS rank's share ``loss_sum_local / n_valid_global`` (the shares add up to
@@ -622,8 +660,19 @@ class TrainStep:
         return loss
 
     def optimizer_step(self):
-        """AdamW over everything ``_early_adamw`` has not already stepped during this step's backward pass (all of it outside ``step()``)."""
+        """AdamW over everything ``_early_adamw`` has not already stepped during this step's backward pass (all of it outside ``step()``).
+        With a step block (fp16 mode): GradScaler.step + update on the device -- overflow check of every gradient arena, the decision,
+        then the update (or nothing); ``step_count`` then counts the calls, ``applied_steps()`` the updates that happened."""
         self.step_count += 1
+        if self.sp is not None:
+            for grp in self.groups:
+                self.sp.check_finite_(grp["arena"].grad)
+            self.sp.decide_(self.betas[0], self.betas[1])
+            for grp in self.groups:
+                a = grp["arena"]
+                ops.adamw_sp_(a.data, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], self.sp)
+            self._stepped = []
+            return
         for gi, grp in enumerate(self.groups):
             done = sorted((lo, hi) for g_, lo, hi in self._stepped if g_ == gi)
             pos, n = 0, grp["arena"].numel

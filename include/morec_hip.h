@@ -14,7 +14,10 @@
  *   - return 0 on success, a negative MOREC_E_* for bad arguments, a positive value = hipError_t;
  *   - dtype codes: MOREC_F32 = 0 (exact-fp32 MFMA, v_mfma_f32_16x16x4_f32), MOREC_BF16 = 1 (bf16 operands, fp32 accumulate:
  *     v_mfma_f32_32x32x16_bf16 in the 256 x 256 eight-phase GEMMs, v_mfma_f32_16x16x32_bf16 in attention, scoring and the
- *     small-problem GEMMs);
+ *     small-problem GEMMs), MOREC_F16 = 2 (IEEE fp16 operands, fp32 accumulate: v_mfma_f32_32x32x16_f16 / 16x16x32_f16 in the same
+ *     kernels -- the arithmetic of the reference's `torch.cuda.amp.autocast()` step, T/run.py:242-247, three more significand bits
+ *     than bf16 at the same MFMA rate; gradients need the loss scaling of morec_step_params below).  "bf16" in an entry point's
+ *     description means either 16-bit type unless it says otherwise; the Swin kernels and morec_split_bf16x3 take MOREC_BF16 only;
  *   - row-major matrices with explicit leading dimensions in ELEMENTS; every base pointer and
  *     every row pitch must be 16-byte aligned (MOREC_E_ALIGN otherwise);
  *   - item ids are int32 on the device (the host narrows the int64 ids PyTorch provides).
@@ -43,6 +46,7 @@ extern "C" {
 
 #define MOREC_F32 0
 #define MOREC_BF16 1
+#define MOREC_F16 2 /* IEEE half operands / activations, fp32 accumulate: the reference's own GPU arithmetic (fp16 autocast, T/run.py:242) */
 
 #define MOREC_OK 0
 #define MOREC_E_ARG (-1)         /* null pointer / non-positive size */
@@ -337,6 +341,40 @@ int morec_inbatch_ce_bwd(const morec_ce_desc* d, const void* P, const void* E, c
 int morec_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, size_t n,
                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident step state: what the reference keeps in `torch.cuda.amp.GradScaler()` and in AdamW's per-parameter `step`
+ * (T/run.py:210: scaler = GradScaler(); :243-247: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()), held in
+ * one 64-byte DEVICE block so that a step needs no host round trip and no per-step host scalar among its kernel arguments
+ * (a captured graph of the step can be replayed).  Protocol of one step in the fp16 mode:
+ *   forward; backward with the loss gradient multiplied by sp->loss_scale (morec_inbatch_ce_bwd: gscale_dev = loss_scale / n_valid);
+ *   gradient reduction over ranks; morec_grad_check_finite over every gradient arena; morec_step_decide; morec_adamw_sp per group.
+ * A step with a non-finite gradient leaves parameters, moments, shadows and the step count untouched and halves the scale
+ * (GradScaler defaults: init 65536, growth 2 every 2000 clean steps, backoff 0.5 -- passed in by the caller).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t step;           /* optimizer steps APPLIED so far (a skipped step does not count, as torch never calls optimizer.step() for it) */
+    int32_t found_inf;      /* != 0: a non-finite gradient has been seen since the last morec_step_decide */
+    int32_t growth_tracker; /* consecutive clean steps since the scale last changed */
+    int32_t skipped;        /* steps skipped so far (diagnostics) */
+    float loss_scale;       /* S of the NEXT backward pass */
+    float inv_scale;        /* 1 / S of the step being applied: what morec_adamw_sp multiplies the gradients with */
+    float bc1, bc2;         /* 1 - beta1^step, 1 - beta2^step of the step being applied */
+    int32_t apply;          /* decision of the last morec_step_decide: 1 = update, 0 = skip */
+    int32_t reserved[7];
+} morec_step_params;
+/* *sp = {step, loss_scale = init_scale, everything else clear} (init_scale = 1: no scaling, bf16 / fp32 modes) */
+int morec_step_params_init(morec_step_params* sp, float init_scale, int step, void* stream);
+/* sp->found_inf |= any element of grad[0 .. n) is inf or NaN   (GradScaler.unscale_'s found_inf; the division by S is left to AdamW) */
+int morec_grad_check_finite(const float* grad, size_t n, morec_step_params* sp, void* stream);
+/* GradScaler.step + update on the device: apply = !found_inf; on apply: ++step, bias corrections (formed in double), growth
+ * bookkeeping; on skip: ++skipped, scale *= backoff_factor; found_inf is cleared.  dynamic == 0 keeps the scale fixed. */
+int morec_step_decide(morec_step_params* sp, float beta1, float beta2, float growth_factor, float backoff_factor,
+                      int growth_interval, int dynamic, void* stream);
+/* morec_adamw with step count / bias corrections / gradient scale (1 / S) read from *sp; does nothing when sp->apply == 0.
+ * shadow (may be NULL): 16-bit copy of the updated parameters in shadow_dtype (MOREC_BF16 | MOREC_F16). */
+int morec_adamw_sp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow, int shadow_dtype, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, const morec_step_params* sp, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation (T/data_utils/metrics.py:96-102,49-57): rank of the target among all items after
