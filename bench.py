@@ -39,7 +39,10 @@ def parse():
     ap.add_argument("--bert", default="base")
     ap.add_argument("--tower", default="text", help="text (BASELINE.json metric: BERT item encoder) | swin_tiny | swin_base | swin_micro "
                     "(vision configs of BASELINE.json: Swin item encoder, S=10, D=2048, 224x224 images; default --batch 64)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x3"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp32x3"],
+                    help="fp16 (default; text towers): IEEE-half operands on the MFMA + GradScaler loss scaling -- the reference's own GPU arithmetic "
+                         "(T/run.py:210,242-247) and the 16-bit mode whose loss stays within north_star's 1e-3 of the fp32 parity mode; bf16: the "
+                         "same kernels on bf16 operands (no loss scaling; the vision towers' mode); fp32 / fp32x3: the parity modes")
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -107,6 +110,8 @@ def self_launch(a):
 
 def main():
     a = parse()
+    if a.tower not in ("text", "id") and a.dtype == "fp16":
+        a.dtype = "bf16"      # the Swin kernels take bf16 / fp32 only (include/morec_hip.h); the vision lines are bf16 lines
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline(a)))
         return
@@ -419,7 +424,7 @@ def main():
     fp32_info = fp32x3_info = None
     main_gemm_log = list(gemm_log)
     main_ce_log, main_ce_shapes = list(ce_log), list(ce_shapes)
-    if not vision and not id_tower and a.dtype == "bf16" and not a.no_secondary and world == 1:
+    if not vision and not id_tower and a.dtype in ("bf16", "fp16") and not a.no_secondary and world == 1:
         def fp32_mode_line(mode):
             nonlocal ts
             info = None
@@ -528,11 +533,21 @@ def main():
 
     # the scoring kernels at the 8-rank POOLED size (this rank's B S rows against eight ranks' worth of item vectors, emulated on one
     # GPU): the size north_star's multi-GPU step runs them at; never part of `value`
-    if not a.no_secondary and not vision and world == 1 and a.dtype == "bf16":
+    if not a.no_secondary and not vision and world == 1 and a.dtype in ("bf16", "fp16"):
         try:
-            roof["scoring"]["pooled_8_ranks"] = scoring_pooled(ops, a.batch, S, D, dev, peak)
+            roof["scoring"]["pooled_8_ranks"] = scoring_pooled(ops, a.batch, S, D, dev, peak, dt=torch.float16 if a.dtype == "fp16" else torch.bfloat16)
         except Exception as e:  # noqa: BLE001
             roof["scoring"]["pooled_8_ranks"] = {"error": f"{type(e).__name__}: {e}"}
+
+    eval_info = None
+    if not a.no_secondary and not vision and not id_tower and world == 1 and a.dtype in ("bf16", "fp16"):
+        keep = (list(gemm_log), list(ce_log), list(ce_shapes))
+        eval_info = eval_lines(model, ops, args, content, a.item_num, S, D, dev, gemm_log, timing_on, peak)
+        gemm_log[:], ce_log[:], ce_shapes[:] = keep
+    scaler_state = None
+    if ts.sp is not None:
+        h_ = ts.sp.host()
+        scaler_state = {"scale": float(h_.loss_scale), "applied_steps": int(h_.step), "skipped_steps": int(h_.skipped)}
 
     out = {"metric": "user-sequences/sec end-to-end train step, SASRec+BERT-base", "value": round(world * a.batch * a.steps / dt, 2),
            "unit": "user-seq/s", "n_gpus": world, "world_size_observed": (dist.get_world_size() if world > 1 else 1), "steps": a.steps, "warmup": a.warmup,
@@ -546,10 +561,14 @@ def main():
            "final_loss": round(loss_v, 4), "roofline": roof, "steps_executed": n_run["v"]}
     if sustained is not None:
         out["sustained"] = sustained
+    if eval_info is not None:
+        out["eval"] = eval_info
+    if scaler_state is not None:
+        out["loss_scaler_state"] = scaler_state
     if reduce_trace is not None:
         out["gradient_reduce_trace"] = reduce_trace
     if world > 1:
-        out["config"]["gemm8p_reserve_cus"] = int(os.environ.get("MOREC_GEMM8P_RESERVE_CUS", "16"))
+        out["config"]["gemm8p_reserve_cus"] = int(ts.reserve_cus)      # CUs kept out of the GEMM grid during the backward pass (0 without an RCCL ring)
     if id_tower:
         out["metric"] = "user-sequences/sec end-to-end train step, IDRec SASRec (embedding table)"
         out["config"]["workload"] = (f"SASRec(2 blocks, 2 heads, D=512) + ID embedding table ({a.item_num} items, dense AdamW over the table), "
@@ -563,7 +582,7 @@ def main():
     # secondary lines (never `value`): the other BASELINE.json configurations, each measured by a child run of this file so that the
     # driver's record carries a time for every config: configs[3] Swin-T (V/train_swin_tiny.py:22-41: B = 64/GPU, 704 images per
     # step), configs[4] Swin-B (B = 32/GPU, 352 images per step), configs[0] IDRec (T/train_id.py:22-26), configs[1] BERT-tiny
-    if not vision and not id_tower and a.dtype == "bf16" and not a.no_secondary and world == 1 and a.bert == "base":
+    if not vision and not id_tower and a.dtype in ("bf16", "fp16") and not a.no_secondary and world == 1 and a.bert == "base":
         import subprocess
 
         def child(extra, timeout=240):
@@ -571,7 +590,9 @@ def main():
                                capture_output=True, text=True, timeout=timeout)
             return json.loads(r.stdout.strip().splitlines()[-1])
 
-        for key, extra, per_seq in (("vision_swin_tiny", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2"], 11),
+        other16 = "bf16" if a.dtype == "fp16" else "fp16"
+        for key, extra, per_seq in ((other16 + "_mode", ["--dtype", other16, "--batch", str(a.batch), "--steps", "20", "--warmup", "5"], 0),
+                                    ("vision_swin_tiny", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2"], 11),
                                     ("vision_swin_base", ["--tower", "swin_base", "--batch", "32", "--steps", "4", "--warmup", "2"], 11),
                                     ("id_tower", ["--tower", "id", "--batch", "128", "--steps", "20", "--warmup", "5"], 0),
                                     ("bert_tiny", ["--bert", "tiny", "--batch", "128", "--steps", "20", "--warmup", "5"], 0)):
@@ -584,10 +605,19 @@ def main():
                     out[key]["images_per_s"] = round(vj["value"] * per_seq, 1)
             except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
+    TOL = {"fp16": "fp16 vs the exact-fp32 parity mode AT THIS CONFIGURATION (tests/test_fp16_mode_gpu.py, asserted): step-0 loss 1e-3 relative "
+                   "(measured 3.1e-4; 3.4e-3 absolute on 10.90), gradient norms 1.5e-2 (measured 7.9e-3), 20-step loss curve 1e-2 relative; reference "
+                   "golden g6 BERT-base loss 1e-3 relative (measured 5.3e-4); HR@10 of the modal eval golden g17 equal to the reference's",
+           "bf16": "bf16 vs the exact-fp32 parity mode at this configuration (tests/test_bench_mode_parity_gpu.py, asserted): step-0 loss 3e-2 absolute "
+                   "(measured 1.3e-3 ... 1.5e-2 depending on the GEMM summation order), gradient norms 5e-2 (0.6e-2 ... 2.3e-2), 20-step loss curve 2 %"}
+    if a.dtype in TOL and not vision and not id_tower:
+        out["config"]["tolerance_vs_fp32_mode"] = TOL[a.dtype]
+    if a.dtype == "fp16":
+        out["config"]["loss_scaling"] = ("GradScaler protocol on the device (morec_step_params: init 65536, x0.5 + skipped step on inf / NaN, x2 after 2000 clean "
+                                         "steps); the overflow check, the decision and AdamW are inside the timed step")
     if fp32_info is not None:
         out["fp32_parity_mode"] = fp32_info
         out["fp32x3_mode"] = fp32x3_info
-        out["config"]["bf16_tolerance_vs_fp32_mode"] = "step-0 loss 3e-2, gradient norms 5e-2, 20-step loss curve 2 % (bounds asserted by tests/test_bench_mode_parity_gpu.py at B=128 BERT-base; measured 1.3e-3 ... 1.5e-2 depending on the GEMM summation order / 0.6e-2 ... 2.3e-2 / 0.9 %)"
     if a.dedup:
         out["config"]["item_dedup"] = True
     if vision:
@@ -620,10 +650,80 @@ def main():
         dist.destroy_process_group()
 
 
-def scoring_pooled(ops, B, S, D, dev, peak, ranks=8, rank=3, iters=20):
+def eval_lines(model, ops, args, content, item_num, S, D, dev, gemm_log, timing_on, peak, n_users=16384, test_bs=4096):
+    """The evaluation pass of an epoch (T/data_utils/metrics.py:60-107; never part of `value`): (1) encode ALL items -- `get_item_embeddings`
+    over the whole synthetic catalogue, host token rows uploaded chunk by chunk as the reference does -- items/s and the MFMA rate of its
+    GEMMs; (2) `eval_model`'s ranking: user states from the SASRec encoder + `morec_eval_rank` (count-greater over exact-fp32 MFMA score
+    tiles against every item, history masked in the tile) -- users/s end to end and the rank kernel's own rate against the fp32 MFMA peak."""
+    from idvs.morec_amd.data_utils.metrics import PackedEvalUsers, eval_ranks_packed, get_item_embeddings
+    was_training = model.training
+    out = {}
+    try:
+        model.eval()
+        get_item_embeddings(model, content[:test_bs + 1], test_bs, args, True, dev)        # warm-up (allocator, first-call set-up)
+        torch.cuda.synchronize()
+        del gemm_log[:]
+        timing_on["v"] = True
+        t0 = time.perf_counter()
+        emb = get_item_embeddings(model, content, test_bs, args, True, dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timing_on["v"] = False
+        fl = sum(g_[0] for g_ in gemm_log)
+        ms = sum(g_[1].elapsed_time(g_[2]) for g_ in gemm_log)
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out["encode_all_items"] = {"items": int(content.shape[0]), "seconds": round(dt, 4), "items_per_s": round(content.shape[0] / dt, 1),
+                                   "gemm_tflops": round(tf, 1), "gemm_frac_of_mfma_peak": round(tf / peak, 4), "gemm_ms": round(ms, 2),
+                                   "chunk": test_bs, "note": "get_item_embeddings(use_modal=True): pinned-free H2D of each chunk's token rows + BERT forward on the real tokens "
+                                                             "+ fc/GELU head, eval mode, no grad; wall clock of the whole pass"}
+        # synthetic eval users: full-length sequences (S inputs + the target), history = the inputs (what run.py masks)
+        rng = np.random.default_rng(777)
+        seqs = rng.integers(1, item_num + 1, size=(n_users, S + 1))
+        eval_seq = {u: seqs[u] for u in range(n_users)}
+        hist = {u: seqs[u, :-1] for u in range(n_users)}
+        users = list(range(n_users))
+        packed = PackedEvalUsers(hist, eval_seq, users, S)
+        eval_ranks_packed(model, packed, 0, test_bs, emb, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        packed = PackedEvalUsers(hist, eval_seq, users, S)      # the host-side packing is part of the pass
+        t_pack = time.perf_counter() - t0
+        for s0 in range(0, n_users, test_bs):
+            eval_ranks_packed(model, packed, s0, min(n_users, s0 + test_bs), emb, dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the rank kernel alone (launch sequence of the C-ABI call), HIP events
+        prec = torch.randn(test_bs, D, device=dev)
+        h_d = torch.from_numpy(packed.hist[:test_bs]).to(dev)
+        t_d = torch.from_numpy(packed.target[:test_bs]).to(dev)
+        ops.eval_rank(prec, emb, h_d, t_d)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.eval_rank(prec, emb, h_d, t_d)
+        e1.record()
+        torch.cuda.synchronize()
+        kms = e0.elapsed_time(e1) / 5
+        kfl = 2.0 * test_bs * emb.shape[0] * D
+        ktf = kfl / (kms * 1e-3) / 1e12
+        out["rank_users"] = {"users": n_users, "items": int(emb.shape[0]), "seconds": round(dt, 4), "users_per_s": round(n_users / dt, 1),
+                             "host_packing_s": round(t_pack, 4),
+                             "rank_kernel": {"users_per_call": test_bs, "ms_per_call": round(kms, 3), "tflops": round(ktf, 1), "bound": "mfma (exact fp32)",
+                                             "peak": MFMA_PEAK_TFLOPS["f32"], "frac": round(ktf / MFMA_PEAK_TFLOPS["f32"], 4),
+                                             "scores_bytes_never_written": int(test_bs) * int(emb.shape[0]) * 4},
+                             "note": "eval_model's inner loop: vectorised host packing of the users, item-vector gather, SASRec user encoder, morec_eval_rank "
+                                     "(rank = 1 + #{unmasked items scoring above the target}; the [users, items] score matrix is never stored)"}
+    except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
+        out["error"] = f"{type(e).__name__}: {e}"
+        timing_on["v"] = False
+    if was_training:
+        model.train()
+    return out
+
+
+def scoring_pooled(ops, B, S, D, dev, peak, ranks=8, rank=3, iters=20, dt=torch.bfloat16):
     """Fused in-batch CE forward + backward at the pooled-negative size of an `ranks`-GPU step, bf16: call-level times (every launch of
     the C-ABI call: table prep, positive logits, tile kernel, combine / dl^T GEMMs) and the executed FLOP rate."""
-    dt = torch.bfloat16
     Nr, Nc = B * S, ranks * B * (S + 1)
     g = torch.Generator(device=dev).manual_seed(ranks)
     P = (torch.randn(Nr, D, device=dev, generator=g) * 0.3).to(dt)

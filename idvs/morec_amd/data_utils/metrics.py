@@ -64,31 +64,62 @@ def metrics_from_ranks(ranks: torch.Tensor, topK: int = 10):
     return hit, ndcg
 
 
-def eval_ranks(model, user_history, eval_seq, item_embeddings, users, args, local_rank):
-    """1-based target ranks for ``users`` (list of user ids): user states from the SASRec encoder, ranks by the HIP kernel."""
+class PackedEvalUsers:
+    """The evaluation inputs of a list of users as dense arrays, built ONCE per ``eval_model`` call with array operations (the reference
+    walks the users one by one in Python, ``metrics.py:92-102``; so did the first version of this file, per batch):
+    ``idx`` int64 [U, S] = the right-aligned input sequence ``seq[:-1]`` (0 = padding), ``lm`` float32 [U, S] its mask, ``target`` int32 [U]
+    = ``seq[-1]``, ``hist`` int32 [U, Hmax] = the history items to mask, padded with -1."""
+
+    def __init__(self, user_history, eval_seq, users, S):
+        U = len(users)
+        seq_len = np.fromiter((len(eval_seq[u]) for u in users), dtype=np.int64, count=U)
+        if U and int(seq_len.min()) < 1:
+            raise ValueError("an evaluation sequence needs at least its target item")
+        flat = np.concatenate([np.asarray(eval_seq[u], dtype=np.int64) for u in users]) if U else np.zeros(0, np.int64)
+        ends = np.cumsum(seq_len)
+        starts = ends - seq_len
+        self.target = flat[ends - 1].astype(np.int32) if U else np.zeros(0, np.int32)
+        n_in = np.minimum(seq_len - 1, S)                        # inputs kept: the last S of seq[:-1] (sequences are <= S + 1 long by construction)
+        rows = np.repeat(np.arange(U), n_in)
+        k = np.arange(int(n_in.sum())) - np.repeat(np.cumsum(n_in) - n_in, n_in)          # 0 .. n_in-1 within each user
+        src = np.repeat(ends - 1 - n_in, n_in) + k               # positions of those inputs in `flat`
+        cols = np.repeat(S - n_in, n_in) + k                     # right-aligned
+        self.idx = np.zeros((U, S), dtype=np.int64)
+        self.lm = np.zeros((U, S), dtype=np.float32)
+        self.idx[rows, cols] = flat[src]
+        self.lm[rows, cols] = 1.0
+        h_len = np.fromiter((len(user_history[u]) for u in users), dtype=np.int64, count=U)
+        hmax = max(1, int(h_len.max()) if U else 1)
+        self.hist = np.full((U, hmax), -1, dtype=np.int32)
+        if U and int(h_len.sum()):
+            hflat = np.concatenate([np.asarray(user_history[u], dtype=np.int64).reshape(-1) for u in users])
+            hrows = np.repeat(np.arange(U), h_len)
+            hcols = np.arange(int(h_len.sum())) - np.repeat(np.cumsum(h_len) - h_len, h_len)
+            self.hist[hrows, hcols] = hflat.astype(np.int32)
+        self.U, self.S = U, S
+
+    def slice(self, a, b):
+        hist = self.hist[a:b]
+        used = max(1, int((hist >= 0).sum(1).max()) if b > a else 1)     # the chunk's own widest history: what the kernel's LDS table holds
+        return self.idx[a:b], self.lm[a:b], np.ascontiguousarray(hist[:, :used]), self.target[a:b]
+
+
+def eval_ranks_packed(model, packed: PackedEvalUsers, a, b, item_embeddings, local_rank):
+    """1-based target ranks of users [a, b) of a ``PackedEvalUsers``: user states from the SASRec encoder, ranks by the HIP kernel."""
     m = _module(model)
-    S = args.max_seq_len
-    U = len(users)
-    D = item_embeddings.shape[1]
-    idx = np.zeros((U, S), dtype=np.int64)
-    lm = np.zeros((U, S), dtype=np.float32)
-    hmax = max(1, max(len(user_history[u]) for u in users))
-    hist = np.full((U, hmax), -1, dtype=np.int32)
-    target = np.zeros(U, dtype=np.int32)
-    for r, u in enumerate(users):
-        seq = eval_seq[u]
-        toks = seq[:-1]
-        idx[r, S - len(toks):] = toks
-        lm[r, S - len(toks):] = 1
-        h = np.asarray(user_history[u])
-        hist[r, :len(h)] = h
-        target[r] = seq[-1]
+    idx, lm, hist, target = packed.slice(a, b)
     dev = item_embeddings.device
     with torch.no_grad(), ops.fp32_gemm_mode(getattr(m, "fp32_gemm", ops.FP32_GEMM)):
         embs = item_embeddings[torch.from_numpy(idx).to(dev)]                      # [U, S, D] gather (plumbing)
         prec = m.user_encoder(embs, torch.from_numpy(lm).to(dev), local_rank)[:, -1].float().contiguous()
         return ops.eval_rank(prec, item_embeddings.contiguous(), torch.from_numpy(hist).to(dev),
                              torch.from_numpy(target).to(dev)).long()
+
+
+def eval_ranks(model, user_history, eval_seq, item_embeddings, users, args, local_rank):
+    """1-based target ranks for ``users`` (list of user ids)."""
+    packed = PackedEvalUsers(user_history, eval_seq, users, args.max_seq_len)
+    return eval_ranks_packed(model, packed, 0, packed.U, item_embeddings, local_rank)
 
 
 def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, args, item_num, Log_file, v_or_t, local_rank):
@@ -103,8 +134,9 @@ def eval_model(model, user_history, eval_seq, item_embeddings, test_batch_size, 
     mine = list(iter(sampler))
     item_embeddings = item_embeddings.to(local_rank)
     hits, ndcgs = [], []
+    packed = PackedEvalUsers(user_history, eval_seq, mine, args.max_seq_len)      # one vectorised pass over this rank's users
     for s in range(0, len(mine), test_batch_size):
-        ranks = eval_ranks(model, user_history, eval_seq, item_embeddings, mine[s:s + test_batch_size], args, local_rank)
+        ranks = eval_ranks_packed(model, packed, s, min(len(mine), s + test_batch_size), item_embeddings, local_rank)
         h, n = metrics_from_ranks(ranks)
         hits.append(h)
         ndcgs.append(n)

@@ -78,20 +78,37 @@ def run_eval(model, item_content, user_history, users_eval, batch_size, item_num
     return hit10
 
 
-def model_dir_of(args, world: int = 1):
-    """The reference's checkpoint directory, label for label (``T/run.py:326-337``): ``<root>/checkpoint_<dir_label>/cpt_<model>_ed_<D>_bs_
-    <batch_size * gpus>_lr_<lr>_Flr_<fine_tune_lr>_L2_<l2>_FL2_<fine_tune_l2>`` with ``dir_label = <item_tower>_<model>_freeze_<n>``
-    for modal towers and ``<item_tower>`` / model ``id`` for the ID tower, so that ``--load_ckpt_name epoch-N.pt`` finds a checkpoint
-    the reference wrote in place (``--checkpoint_root .``).  ``world`` = number of ranks (the reference multiplies the per-GPU batch
-    size by ``torch.cuda.device_count()``)."""
-    if "modal" in args.item_tower:
-        enc = args.CV_model_load if getattr(args, "CV_model_load", "None") != "None" else args.bert_model_load
+def model_dir_candidates(args, world: int = 1):
+    """The reference's checkpoint directory, label for label, first; then the other spellings a checkpoint may sit under.
+    TEXT (``T/run.py:326-337``): ``checkpoint_<dir_label>/cpt_<model>_ed_<D>_bs_<batch_size * gpus>_lr_<lr>_Flr_<Flr>_L2_<l2>_FL2_<Fl2>`` with
+    ``model = bert_model_load``, ``dir_label = <item_tower>_<model>_freeze_<n>``; the ID tower: ``model = id``, ``dir_label = <item_tower>``
+    (batch size times the GPU count there too).  VISION (``V/run.py:307-324``): ``model = CV_model_load`` WITHOUT its ``.pth``, the
+    label starts ``<model>-<freeze_paras_before>_ed_...``; V's ID branch does not multiply the batch size by the GPU count.
+    ``world`` = number of ranks (the reference uses ``torch.cuda.device_count()``)."""
+    tail = f"_lr_{args.lr}_Flr_{args.fine_tune_lr}_L2_{args.l2_weight}_FL2_{args.fine_tune_l2_weight}"
+    root = args.checkpoint_root
+    vision = "modal" in args.item_tower and getattr(args, "CV_model_load", "None") != "None"
+    out = []
+    if vision:
+        enc = args.CV_model_load.replace(".pth", "")
         dir_label = f"{args.item_tower}_{enc}_freeze_{args.freeze_paras_before}"
+        out.append((dir_label, f"{enc}-{args.freeze_paras_before}_ed_{args.embedding_dim}_bs_{args.batch_size * world}" + tail))
+        # what earlier versions of THIS driver wrote (the text run's label with the vision tower's name, '.pth' kept)
+        old = args.CV_model_load
+        out.append((f"{args.item_tower}_{old}_freeze_{args.freeze_paras_before}", f"{old}_ed_{args.embedding_dim}_bs_{args.batch_size * world}" + tail))
+    elif "modal" in args.item_tower:
+        enc = args.bert_model_load
+        out.append((f"{args.item_tower}_{enc}_freeze_{args.freeze_paras_before}", f"{enc}_ed_{args.embedding_dim}_bs_{args.batch_size * world}" + tail))
     else:
-        enc, dir_label = "id", str(args.item_tower)
-    label = (f"{enc}_ed_{args.embedding_dim}_bs_{args.batch_size * world}_lr_{args.lr}_Flr_{args.fine_tune_lr}"
-             f"_L2_{args.l2_weight}_FL2_{args.fine_tune_l2_weight}")
-    return os.path.join(args.checkpoint_root, "checkpoint_" + dir_label, "cpt_" + label)
+        out.append((str(args.item_tower), f"id_ed_{args.embedding_dim}_bs_{args.batch_size * world}" + tail))      # T/run.py:331-337
+        if world > 1:
+            out.append((str(args.item_tower), f"id_ed_{args.embedding_dim}_bs_{args.batch_size}" + tail))          # V/run.py:318-323
+    return [os.path.join(root, "checkpoint_" + d, "cpt_" + l) for d, l in out]
+
+
+def model_dir_of(args, world: int = 1):
+    """Where this run WRITES its checkpoints: the reference's own directory for the tower (``model_dir_candidates``)."""
+    return model_dir_candidates(args, world)[0]
 
 
 def normalize_pretrained_bert_keys(sd: dict) -> dict:
@@ -202,9 +219,13 @@ def train(args, use_modal, local_rank):
     model_dir = model_dir_of(args, world)
     ckpt, start_epoch, is_early_stop = None, 0, True
     if "None" not in args.load_ckpt_name:                               # T/run.py:130-139: BEFORE the arenas / DDP are built
-        ckpt_path = get_checkpoint(model_dir, args.load_ckpt_name)
+        ckpt_path = None
+        for cand in model_dir_candidates(args, world):      # the reference's directory first, then the older spellings
+            ckpt_path = get_checkpoint(cand, args.load_ckpt_name)
+            if ckpt_path is not None:
+                break
         if ckpt_path is None:
-            raise SystemExit(f"--load_ckpt_name {args.load_ckpt_name}: not found under {model_dir}")
+            raise SystemExit(f"--load_ckpt_name {args.load_ckpt_name}: not found under any of {model_dir_candidates(args, world)}")
         start_epoch = load_model(model, ckpt_path)
         ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
         if ckpt.get("rng_state") is not None:

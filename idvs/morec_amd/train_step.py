@@ -198,9 +198,14 @@ class TrainStep:
         # round (2x the launch).  Leave CUs out of the grid while collectives overlap the backward pass (scripts/rccl_cu_probe.py;
         # MOREC_GEMM8P_RESERVE_CUS overrides, 0 = none).
         self.overlap_reduce = os.environ.get("MOREC_OVERLAP_REDUCE", "1") != "0"
-        if self.collectives and self.overlap_reduce and self.device.type == "cuda" and "MOREC_GEMM8P_RESERVE_CUS" not in os.environ:
-            from . import _lib
-            _lib.lib().morec_tuning_set(b"gemm8p_reserve_cus", 16)
+        # CUs left out of the persistent GEMM grid WHILE bucket collectives can overlap the backward pass -- set at the start of the
+        # backward, cleared in reduce_gradients -- and only when a real RCCL ring exists (more than one rank, not gloo): forward, eval and
+        # single-rank runs keep all 256 CUs.  Default 16 (a guess until an 8-GPU A/B run says otherwise: bench.py --sweep);
+        # MOREC_GEMM8P_RESERVE_CUS (or the attribute) overrides.
+        rccl_ring = (self.world > 1 and self.overlap_reduce and self.device.type == "cuda" and dist.is_initialized() and dist.get_backend() != "gloo")
+        env_r = os.environ.get("MOREC_GEMM8P_RESERVE_CUS")
+        self.reserve_cus = (int(env_r) if env_r is not None else 16) if rccl_ring else 0
+        self._reserved = False
         comm = comm if comm is not None else os.environ.get("MOREC_COMM", "")
         self.comm = self.comm_grad = self._grad_stream = None
         if comm == "rccl" and self.collectives and self.device.type == "cuda":
@@ -419,6 +424,7 @@ class TrainStep:
             Epool, ci, n_valid = pool_exchange(E, ci, n_valid, self.world, self.rank, self.comm)
             gscale = self._gscale(n_valid)
         loss_sum, saved_c = engine.ce_forward(ci, P, Epool, dE_fp32=(self.collectives and self.pool))
+        self._reserve(True)      # the backward pass starts: bucket collectives may run beside its GEMMs from here on
         dP, dEpool = engine.ce_backward(ci, P, Epool, saved_c, gscale, 1.0)
         dE = reduce_scatter_dE(dEpool, self.world, self.rank, self.dtype, self.comm) if (self.collectives and self.pool) else dEpool
         dx = engine.sasrec_backward(p, prep_s, saved_s, dP, grads, engine.UE)
@@ -442,6 +448,15 @@ class TrainStep:
         if self.sp is None:
             return (1.0 / n_valid).reshape(1)
         return (self.sp.loss_scale_dev / n_valid).reshape(1)
+
+    def _reserve(self, on: bool):
+        """Launch-time knob of the persistent GEMM grid (``morec_tuning_set("gemm8p_reserve_cus")``): ``reserve_cus`` CUs stay free for the
+        RCCL ring kernel between the start of the backward pass and the join of the gradient collectives, none outside that window."""
+        if self.reserve_cus <= 0 or on == self._reserved:
+            return
+        from . import _lib
+        _lib.lib().morec_tuning_set(b"gemm8p_reserve_cus", self.reserve_cus if on else 0)
+        self._reserved = on
 
     def _prepare_step_buffers(self):
         if self._wt_batch is not None:
@@ -556,6 +571,7 @@ class TrainStep:
             if not self.pool:   # rank-local negatives: the reference's DDP MEAN over ranks (T/run.py:148)
                 for grp in self.groups:
                     grp["arena"].grad.mul_(1.0 / self.world)
+        self._reserve(False)
 
     # -----------------------------------------------------------------------------------------------
     def sync_shadow(self):

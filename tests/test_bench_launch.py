@@ -51,4 +51,4 @@ def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
     assert "error" not in tr and len(tr["buckets"]) >= 3            # recommender group, encoder layers, closing sweep
     issued = [b["issued_at_ms"] for b in tr["buckets"]]
     assert issued == sorted(issued) and tr["join_begin_ms"] >= issued[-1] and tr["join_end_ms"] >= tr["join_begin_ms"]
-    assert out["config"]["gemm8p_reserve_cus"] == 16
+    assert out["config"]["gemm8p_reserve_cus"] == 0      # gloo ranks: no RCCL ring kernel to leave CUs for (train_step.TrainStep.reserve_cus)

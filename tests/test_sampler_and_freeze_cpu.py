@@ -83,6 +83,18 @@ def test_pretrained_bert_key_normalisation_and_checkpoint_dir():
     assert run.model_dir_of(a, 8) == "./checkpoint_modal_bert_base_uncased_freeze_165/cpt_bert_base_uncased_ed_512_bs_1024_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
     a.item_tower = "id"
     assert run.model_dir_of(a, 1) == "./checkpoint_id/cpt_id_ed_512_bs_128_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"
+    # the vision run's label (V/run.py:307-324: '.pth' stripped, '<model>-<freeze>' prefix) -- pinned string for string; an older
+    # spelling of this driver and V's ID label (no GPU factor) are searched when LOADING
+    v = types.SimpleNamespace(item_tower="modal", bert_model_load="bert_base_uncased", CV_model_load="swin_tiny.pth", freeze_paras_before=0,
+                              embedding_dim=2048, batch_size=64, lr=1e-4, fine_tune_lr=1e-4, l2_weight=0.1, fine_tune_l2_weight=0.0,
+                              checkpoint_root=".")
+    cands = run.model_dir_candidates(v, 4)
+    assert cands[0] == "./checkpoint_modal_swin_tiny_freeze_0/cpt_swin_tiny-0_ed_2048_bs_256_lr_0.0001_Flr_0.0001_L2_0.1_FL2_0.0"
+    assert run.model_dir_of(v, 4) == cands[0]
+    assert "./checkpoint_modal_swin_tiny.pth_freeze_0/cpt_swin_tiny.pth_ed_2048_bs_256_lr_0.0001_Flr_0.0001_L2_0.1_FL2_0.0" in cands[1:]
+    a.item_tower = "id"
+    assert run.model_dir_candidates(a, 4) == ["./checkpoint_id/cpt_id_ed_512_bs_512_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02",
+                                              "./checkpoint_id/cpt_id_ed_512_bs_128_lr_0.0001_Flr_5e-05_L2_0.01_FL2_0.02"]
 
 
 def test_token_packing_host_equals_device_bookkeeping():
