@@ -43,6 +43,12 @@ def parse():
                     help="fp16 (default; text towers): IEEE-half operands on the MFMA + GradScaler loss scaling -- the reference's own GPU arithmetic "
                          "(T/run.py:210,242-247) and the 16-bit mode whose loss stays within north_star's 1e-3 of the fp32 parity mode; bf16: the "
                          "same kernels on bf16 operands (no loss scaling; the vision towers' mode); fp32 / fp32x3: the parity modes")
+    ap.add_argument("--vision-input", default="resident", choices=["resident", "u8"],
+                    help="vision towers: resident = fp32 NCHW catalogue in HBM, a step gathers its images on the device (what V/run.py:201-204 has after "
+                         "the DataLoader); u8 = the input pipeline inside the timed step (SURVEY §8 a3 / f3): decoded uint8 images of --native-size on the "
+                         "HOST, packed by a collate thread, uploaded, resampled on the GPU (morec_image_resize_u8, Pillow-exact) and normalised in the patch "
+                         "im2col (morec_swin_patchify_u8)")
+    ap.add_argument("--native-size", type=int, default=256, help="--vision-input u8: side of the synthetic decoded images before the resize")
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -54,6 +60,9 @@ def parse():
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--sweep", action="store_true", help="N > 1: after the headline region, time the data-parallel knobs -- collectives through "
+                    "torch.distributed vs the library's own RCCL communicators, 0 / 8 / 16 CUs reserved for the ring kernel, reduction overlapped "
+                    "with the backward or after it -- and print each configuration's bucket trace under `sweep` (schema: INTEGRATION.md)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only: every rank joins the process group, rank 0 prints the "
                     "world size it observed as one JSON line and exits (no GPU work; used by the CPU test of the N > 1 launch path)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -215,7 +224,27 @@ def main():
     if a.warmup >= 1 and host and host[0][3] is not None and os.environ.get("MOREC_BENCH_PRIME", "1") != "0":
         j = max(range(a.warmup, n_batches), key=lambda i: int(host[i][3][1].numel()))
         host[0] = host[j]
-    if vision:
+    u8_feed, u8_stats = None, None
+    if vision and a.vision_input == "u8":
+        # decoded images as the LMDB of dataset/HM/build_lmdb_hm.py holds them (uint8 HWC, native size), on the HOST; a batch is packed
+        # back to back + page-locked by the collate thread (run.BatchPrefetcher = the reference's DataLoader workers, V/run.py:93-94),
+        # crosses PCIe as uint8 and is resampled + normalised on the GPU
+        from idvs.morec_amd.data_utils.images import pack_images
+        from idvs.morec_amd.run import BatchPrefetcher
+        a.item_num = min(a.item_num, 1024)
+        NS = a.native_size
+        host_imgs = np.random.default_rng(4321).integers(0, 256, (a.item_num + 1, NS, NS, 3), dtype=np.uint8)
+        u8_stats = {"pack_s": 0.0, "batches": 0, "bytes": 0}
+
+        def make_u8(i):
+            t_ = time.perf_counter()
+            idx = ids_all[i].reshape(-1)
+            flat, meta, tabs = pack_images([host_imgs[j] for j in idx], vshape.image_size)
+            u8_stats["pack_s"] += time.perf_counter() - t_
+            u8_stats["batches"] += 1
+            u8_stats["bytes"] = int(flat.nbytes)
+            return torch.from_numpy(flat), torch.from_numpy(meta), torch.from_numpy(tabs)
+    elif vision:
         gen = torch.Generator(device=dev).manual_seed(4321)
         catalog = torch.randn((a.item_num + 1, 3, vshape.image_size, vshape.image_size), device=dev, generator=gen)
         catalog[0].zero_()
@@ -288,11 +317,30 @@ def main():
         n_run["v"] += 1
         ids, items, lm, pack = host[i]
         ids_d = ids.to(dev, non_blocking=True)
-        items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
+        if u8_stats is not None:     # host uint8 batch -> H2D -> Pillow-exact resize on the GPU -> uint8 [n, R, R, 3]
+            if u8_feed is not None and u8_feed["pos"] < len(u8_feed["order"]) and u8_feed["order"][u8_feed["pos"]] == i:
+                _, (flat, meta, tabs) = next(u8_feed["it"])          # built ahead by the collate thread (warm-up + headline region)
+                u8_feed["pos"] += 1
+            else:                                                        # the passes after the headline: packed inline
+                flat, meta, tabs = (t_.pin_memory() for t_ in make_u8(i))
+            items_d = ops.image_resize_u8_packed(flat, meta, tabs, vshape.image_size, dev)
+        else:
+            items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
         lm_d = lm.to(dev, non_blocking=True)
         pack_d = None if pack is None else tuple(t.to(dev, non_blocking=True) for t in pack)
         return ts.step(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
 
+    def start_feed(order):
+        """(u8 input) a collate thread that builds the batches `order` names, two ahead of the device"""
+        nonlocal u8_feed
+        if u8_stats is None:
+            return
+        if u8_feed is not None:
+            u8_feed["feeder"].close()
+        feeder = BatchPrefetcher(lambda i: make_u8(i), list(order), depth=2)
+        u8_feed = {"feeder": feeder, "it": iter(feeder), "order": list(order), "pos": 0}
+
+    start_feed(list(range(a.warmup)) + list(range(a.warmup, n_batches)))
     log("warm-up")
     for i in range(a.warmup):
         loss = run_step(i)
@@ -316,28 +364,113 @@ def main():
     dt = float(t.item())
     loss_v = float(loss.item())
     log(f"timed region done: {dt / a.steps * 1e3:.2f} ms/step")
+    u8_line = None
+    if u8_stats is not None:
+        u8_line = {"native_size": a.native_size, "uint8_bytes_per_step": u8_stats["bytes"],
+                   "host_pack_ms_per_batch": round(u8_stats["pack_s"] / max(1, u8_stats["batches"]) * 1e3, 2),
+                   "collate": "one thread, two batches ahead (run.BatchPrefetcher), page-locked",
+                   "in_timed_region": "H2D of the packed uint8 batch + morec_image_resize_u8 + morec_swin_patchify_u8 (ToTensor + Normalize fused) + the train step"}
+        if u8_feed is not None:
+            u8_feed["feeder"].close()
+            u8_feed = None
     # ---- N > 1: one traced step -- when each gradient bucket's all-reduce is issued (stream time from the start of the step) and how
     # long the closing join waits, so that a scaling run explains itself
-    reduce_trace = None
-    if world > 1:
+    def traced_step():
+        """One step with stream-time events: when each gradient bucket's collective is issued (and, on the library's own communicator,
+        when it completes), when the closing join starts and ends (= the exposed wait), and the scoring calls at the pooled size."""
         try:
             ts.trace = []
+            del ce_log[:], ce_shapes[:]
+            timing_on["v"] = True
             e_start = torch.cuda.Event(enable_timing=True)
             e_start.record()
             run_step(a.warmup)
             e_end = torch.cuda.Event(enable_timing=True)
             e_end.record()
             torch.cuda.synchronize()
+            timing_on["v"] = False
             ev_list, ts.trace = ts.trace, None
-            reduce_trace = {"step_ms": round(e_start.elapsed_time(e_end), 3), "buckets": []}
+            tr = {"step_ms": round(e_start.elapsed_time(e_end), 3), "buckets": []}
             for rec in ev_list:
                 if rec[0] == "issue":
                     _, gi, lo, hi, ev = rec
-                    reduce_trace["buckets"].append({"group": gi, "MB": round((hi - lo) * 4 / 1e6, 1), "issued_at_ms": round(e_start.elapsed_time(ev), 3)})
+                    tr["buckets"].append({"group": gi, "MB": round((hi - lo) * 4 / 1e6, 1), "issued_at_ms": round(e_start.elapsed_time(ev), 3)})
+                elif rec[0] == "done":      # (own RCCL communicator on a side stream: the collective's completion in stream time)
+                    _, gi, lo, hi, ev = rec
+                    for bk in tr["buckets"]:
+                        if bk["group"] == gi and bk["MB"] == round((hi - lo) * 4 / 1e6, 1) and "completed_at_ms" not in bk:
+                            bk["completed_at_ms"] = round(e_start.elapsed_time(ev), 3)
+                            break
                 else:
-                    reduce_trace[rec[0] + "_ms"] = round(e_start.elapsed_time(rec[1]), 3)
+                    tr[rec[0] + "_ms"] = round(e_start.elapsed_time(rec[1]), 3)
+            if "join_begin_ms" in tr and "join_end_ms" in tr:
+                tr["exposed_join_ms"] = round(tr["join_end_ms"] - tr["join_begin_ms"], 3)
+            if ce_log:
+                tr["pooled_scoring"] = {"Nr": ce_shapes[0][1], "Nc": ce_shapes[0][2], "D": ce_shapes[0][3],
+                                        "fwd_us": round(ce_log[0][1].elapsed_time(ce_log[0][2]) * 1e3, 1),
+                                        "bwd_us": round(ce_log[-1][1].elapsed_time(ce_log[-1][2]) * 1e3, 1) if len(ce_log) > 1 else None}
+            return tr
         except Exception as e:  # noqa: BLE001
-            reduce_trace = {"error": f"{type(e).__name__}: {e}"}
+            timing_on["v"] = False
+            ts.trace = None
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- N > 1: one traced step, so that a scaling run explains itself
+    keep_ce = (list(ce_log), list(ce_shapes))
+    reduce_trace = traced_step() if world > 1 else None
+    # ---- N > 1, --sweep: the knobs of the data-parallel step measured in ONE launch, so that the first multi-GPU run settles them:
+    # {torch.distributed | the library's own RCCL communicators} x {CUs kept out of the GEMM grid during the backward: 0, 8, 16} x
+    # {bucketed reduction overlapped with the backward | one sweep after it}.  Every configuration: 2 untimed + K timed steps between
+    # barriers (max over ranks), then one traced step.  Schema: INTEGRATION.md "bench.py --sweep".
+    sweep = None
+    if world > 1 and a.sweep:
+        sweep = []
+        base = (ts.comm, ts.comm_grad, ts._grad_stream, ts.reserve_cus, ts.overlap_reduce)
+        own = None
+        if a.backend == "nccl" and not a.share_device:
+            try:
+                from idvs.morec_amd.comm import MorecComm
+                own = (MorecComm(), MorecComm(), torch.cuda.Stream(device=dev))
+                probe = torch.ones(1, device=dev)
+                own[0].all_reduce_sum_(probe)
+                if int(probe.item()) != world:
+                    raise SystemExit(f"bench.py --sweep: the library's RCCL communicator sees {int(probe.item())} of {world} ranks")
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
+                own = None
+                sweep.append({"comm": "rccl", "skipped": f"{type(e).__name__}: {e}"})
+        else:
+            sweep.append({"comm": "rccl", "skipped": "needs backend nccl with one GPU per rank (RCCL refuses two ranks on one device)"})
+        K = max(2, min(a.steps, 6))
+        for comm_name in ("torch.distributed", "rccl"):
+            if comm_name == "rccl" and own is None:
+                continue
+            for overlap in (True, False):
+                for reserve in ((0, 8, 16) if (overlap and a.backend == "nccl") else (0,)):
+                    ts.comm, ts.comm_grad, ts._grad_stream = (own if comm_name == "rccl" else (None, None, None))
+                    ts.overlap_reduce, ts.reserve_cus = overlap, reserve
+                    rec = {"comm": comm_name, "overlap_reduce": overlap, "reserve_cus": reserve}
+                    try:
+                        for i in range(2):
+                            run_step(i)
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for i in range(K):
+                            run_step(a.warmup + i % a.steps)
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        tt = torch.tensor([time.perf_counter() - t1], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        rec.update({"steps": K, "ms_per_step": round(float(tt.item()) / K * 1e3, 3),
+                                    "user_seq_per_s": round(world * a.batch * K / float(tt.item()), 2), "trace": traced_step()})
+                    except Exception as e:  # noqa: BLE001
+                        rec["error"] = f"{type(e).__name__}: {e}"
+                    sweep.append(rec)
+        ts.comm, ts.comm_grad, ts._grad_stream, ts.reserve_cus, ts.overlap_reduce = base
+        ts._reserve(False)
+    ce_log[:], ce_shapes[:] = keep_ce
     # ---- instrumented pass over the same batches (after the headline; never part of `value`): HIP events around every GEMM /
     # scoring call on the launch stream -> roofline.achieved
     # The weight-gradient stream is switched OFF for this pass: with it on, dW launches overlap the dX chain and the event-timed
@@ -567,6 +700,8 @@ def main():
         out["loss_scaler_state"] = scaler_state
     if reduce_trace is not None:
         out["gradient_reduce_trace"] = reduce_trace
+    if sweep is not None:
+        out["sweep"] = sweep
     if world > 1:
         out["config"]["gemm8p_reserve_cus"] = int(ts.reserve_cus)      # CUs kept out of the GEMM grid during the backward pass (0 without an RCCL ring)
     if id_tower:
@@ -594,6 +729,7 @@ def main():
         for key, extra, per_seq in ((other16 + "_mode", ["--dtype", other16, "--batch", str(a.batch), "--steps", "20", "--warmup", "5"], 0),
                                     ("vision_swin_tiny", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2"], 11),
                                     ("vision_swin_base", ["--tower", "swin_base", "--batch", "32", "--steps", "4", "--warmup", "2"], 11),
+                                    ("vision_u8_pipeline", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2", "--vision-input", "u8"], 11),
                                     ("id_tower", ["--tower", "id", "--batch", "128", "--steps", "20", "--warmup", "5"], 0),
                                     ("bert_tiny", ["--bert", "tiny", "--batch", "128", "--steps", "20", "--warmup", "5"], 0)):
             try:
@@ -603,6 +739,8 @@ def main():
                             "note": "python bench.py " + " ".join(extra)}
                 if per_seq:
                     out[key]["images_per_s"] = round(vj["value"] * per_seq, 1)
+                if "vision_input_pipeline" in vj:
+                    out[key]["input"] = vj["vision_input_pipeline"]
             except Exception as e:  # noqa: BLE001 -- a secondary line must never cost the headline
                 out[key] = {"error": f"{type(e).__name__}: {e}"}
     TOL = {"fp16": "fp16 vs the exact-fp32 parity mode AT THIS CONFIGURATION (tests/test_fp16_mode_gpu.py, asserted): step-0 loss 1e-3 relative "
@@ -620,10 +758,14 @@ def main():
         out["fp32x3_mode"] = fp32x3_info
     if a.dedup:
         out["config"]["item_dedup"] = True
+    if u8_line is not None:
+        out["vision_input_pipeline"] = u8_line
     if vision:
         out["metric"] = f"user-sequences/sec end-to-end train step, SASRec+{a.tower}"
         out["data"] = (f"synthetic HM-shaped ({a.item_num} items, {vshape.image_size}x{vshape.image_size} fp32 images resident in HBM, "
-                       "history 11), random-init weights")
+                       "history 11), random-init weights") if u8_line is None else (
+                       f"synthetic HM-shaped ({a.item_num} items, decoded uint8 {a.native_size}x{a.native_size} images on the HOST, uploaded and "
+                       f"resampled to {vshape.image_size}x{vshape.image_size} on the GPU every step, history 11), random-init weights")
         out["config"] = {"workload": f"SASRec(2 blocks, 2 heads, D={D}) + {a.tower} vision encoder, in-batch debiased CE, "
                                      f"B={a.batch}/GPU, S={S}, {a.batch * (S + 1)} images/GPU/step", "global_batch": world * a.batch,
                          "seq_len": S + 1, "parallelism": out["config"]["parallelism"],

@@ -571,6 +571,21 @@ def probe(device="cuda"):
     return out
 
 
+def image_resize_u8_packed(flat, meta, tabs, R: int, device):
+    """``morec_image_resize_u8`` over a batch the HOST has already packed (``data_utils.images.pack_images``; CPU tensors, ideally
+    page-locked by a collate thread): three asynchronous H2D copies + the resize kernel on the current stream -> uint8 [n, R, R, 3]."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.MorecError("libmorec_hip needs device tensors (no CPU fallback)")
+    n = meta.shape[0]
+    src = flat.to(device, non_blocking=True)
+    meta_d = meta.to(device, non_blocking=True)
+    tabs_d = tabs.to(device, non_blocking=True)
+    out = torch.empty((n, R, R, 3), device=device, dtype=torch.uint8)
+    check(_lib.lib().morec_image_resize_u8(_p(src), _p(meta_d), _p(tabs_d), _p(out), n, R, _stream()), "morec_image_resize_u8")
+    return out
+
+
 def image_resize_u8(images, R: int, device=None):
     """Decoded uint8 [H, W, 3] images of arbitrary sizes (numpy arrays) -> uint8 [n, R, R, 3] on the device: one pinned H2D
     copy of the packed bytes + ``morec_image_resize_u8`` (Pillow's BILINEAR resampler, bit for bit -- what the reference's
@@ -580,9 +595,4 @@ def image_resize_u8(images, R: int, device=None):
     if device.type != "cuda":
         raise _lib.MorecError("libmorec_hip needs device tensors (no CPU fallback)")
     flat, meta, tabs = pack_images(images, R)
-    src = torch.from_numpy(flat).pin_memory().to(device, non_blocking=True)
-    meta_d = torch.from_numpy(meta).to(device, non_blocking=True)
-    tabs_d = torch.from_numpy(tabs).to(device, non_blocking=True)
-    out = torch.empty((len(images), R, R, 3), device=device, dtype=torch.uint8)
-    check(_lib.lib().morec_image_resize_u8(_p(src), _p(meta_d), _p(tabs_d), _p(out), len(images), R, _stream()), "morec_image_resize_u8")
-    return out
+    return image_resize_u8_packed(torch.from_numpy(flat).pin_memory(), torch.from_numpy(meta), torch.from_numpy(tabs), R, device)

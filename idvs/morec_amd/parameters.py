@@ -63,7 +63,13 @@ def build_parser():
                         "(bce_text/main-end2end; drop-in autograd path only)")
     p.add_argument("--synthetic", type=int, default=0, help="N > 0: train on N synthetic MIND-shaped users (no data files)")
     p.add_argument("--synthetic_items", type=int, default=20000)
+    p.add_argument("--synthetic_full_len", action="store_true", help="synthetic users all have raw history max_seq_len + 3 (train sequences "
+                   "of exactly S + 1 items, no padding): the shape bench.py times (SURVEY.md §8d)")
     p.add_argument("--max_steps", type=int, default=0)
+    p.add_argument("--prefetch", type=int, default=2, help="batches built ahead of the device by the collate thread (run.BatchPrefetcher; "
+                   "T/run.py:111-124 uses DataLoader(num_workers=12, pin_memory=True)); 0 = collate inline on the main thread")
+    p.add_argument("--steady_after", type=int, default=10, help="the epoch log also reports user-seq/s over the steps after this many (allocator "
+                   "warm-up, first-call set-up and the loss scaler's initial back-off excluded)")
     p.add_argument("--checkpoint_root", type=str, default="./checkpoint", help="parent of checkpoint_<tower>.../cpt_<label>/ (T/run.py:326-331)")
     p.add_argument("--pretrained_dir", type=str, default="../pretrained_models",
                    help="directory holding <bert_model_load>/pytorch_model.bin (T/run.py:29-53 reads ../../pretrained_models/)")

@@ -14,7 +14,9 @@ from __future__ import annotations
 
 import logging
 import os
+import queue
 import random
+import threading
 import time
 
 import numpy as np
@@ -43,13 +45,14 @@ def setup_seed(seed):   # T/run.py:307-314
     random.seed(seed)
 
 
-def synthetic_dataset(n_users, n_items, S, T, seed=12345):
-    """MIND-shaped synthetic data in the structures ``read_behaviors`` / ``get_doc_input_bert`` return."""
+def synthetic_dataset(n_users, n_items, S, T, seed=12345, full_len=False):
+    """MIND-shaped synthetic data in the structures ``read_behaviors`` / ``get_doc_input_bert`` return.
+    ``full_len``: every user has raw history S + 3 (train sequence of S + 1 items: the throughput shape of bench.py)."""
     rng = np.random.default_rng(seed)
     w = 1.0 / np.arange(1, n_items + 1)
     w /= w.sum()
     perm = rng.permutation(n_items) + 1
-    lens = rng.integers(5, S + 4, n_users)
+    lens = np.full(n_users, S + 3) if full_len else rng.integers(5, S + 4, n_users)
     users_train, users_valid, users_test, hist_valid, hist_test = {}, {}, {}, {}, {}
     counts = np.zeros(n_items + 1)
     for u in range(n_users):
@@ -68,6 +71,58 @@ def synthetic_dataset(n_users, n_items, S, T, seed=12345):
     toks[np.arange(n_items), tl - 1] = 102
     content[1:, :T], content[1:, T:] = toks, valid
     return n_items, content, users_train, users_valid, users_test, hist_valid, hist_test, pop
+
+
+class BatchPrefetcher:
+    """Batches built AHEAD of the device by a worker thread: collate (numpy gathers out of the item table), the unpadded token layout's
+    index vectors and page-locking -- what the reference gets from ``DataLoader(num_workers=12, pin_memory=True)`` (``T/run.py:111-124``;
+    ``V/run.py:93-94``).  One thread is enough here: a batch is a few numpy gathers (they release the GIL), the step itself is launched
+    asynchronously, so the host only has to stay ``depth`` batches ahead of the GPU.  ``make(batch_idx)`` returns a tuple of CPU tensors
+    (or ``None`` entries); iteration yields ``(b, tuple)`` in order; an exception in the worker is re-raised in the consumer."""
+
+    def __init__(self, make, batches, depth: int = 2, pin: bool = True):
+        self.make, self.batches, self.pin = make, batches, pin and torch.cuda.is_available()
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.stop = threading.Event()
+        self.t = threading.Thread(target=self._run, name="morec-prefetch", daemon=True)
+        self.t.start()
+
+    def _pin(self, t):
+        if isinstance(t, tuple):
+            return tuple(self._pin(x) for x in t)
+        return t.pin_memory() if (self.pin and isinstance(t, torch.Tensor) and not t.is_pinned()) else t
+
+    def _put(self, item):
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self):
+        try:
+            for b, idx in enumerate(self.batches):
+                if not self._put((b, tuple(self._pin(x) for x in self.make(idx)))):
+                    return
+        except BaseException as e:  # noqa: BLE001 -- handed to the consumer
+            self._put(e)
+            return
+        self._put(None)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self.stop.set()
+        self.t.join(timeout=5)
 
 
 def run_eval(model, item_content, user_history, users_eval, batch_size, item_num, use_modal, args, mode, local_rank):
@@ -162,7 +217,7 @@ def train(args, use_modal, local_rank):
         del args.CV_model_load                # `Model` picks the vision tower by the presence of this attribute (V/model/model.py:24-29)
     if args.synthetic > 0:
         item_num, content, users_train, users_valid, users_test, hist_valid, hist_test, pop = synthetic_dataset(
-            args.synthetic, args.synthetic_items, S, T)
+            args.synthetic, args.synthetic_items, S, T, full_len=bool(getattr(args, "synthetic_full_len", False)))
         item_content = content if use_modal else np.arange(item_num + 1)
         if vision:      # decoded uint8 images; a real run passes --images_npy (what the LMDB of V/data_utils holds after Resize)
             R = args.CV_resize
@@ -259,6 +314,9 @@ def train(args, use_modal, local_rank):
         optimizer = optim.AdamW([g for g in groups if g["params"]])   # T/run.py:159-162
         if ckpt is not None and ckpt.get("optimizer") is not None:
             optimizer.load_state_dict(ckpt["optimizer"])
+    # T/run.py:210: `scaler = torch.cuda.amp.GradScaler()` -- engaged for the fp16 compute dtype (bf16 / fp32 gradients need no scaling);
+    # the fused step keeps the same protocol in its device block (TrainStep.sp)
+    scaler = torch.amp.GradScaler("cuda", enabled=True) if (optimizer is not None and args.compute_dtype == "fp16") else None
     best, step = 0.0, 0
     max_epoch, early_stop_epoch, early_stop_count = 0, args.epoch, 0
     early_stop_gap = 6 if vision else 10                               # T/run.py:221 / V/run.py:185
@@ -268,29 +326,51 @@ def train(args, use_modal, local_rank):
         # T/run.py:114,123-124,230: DistributedSampler(seed 0 + epoch, padded to a multiple of the world size) + a loader
         # without drop_last -- the last batch of an epoch is short
         batches = epoch_batches(len(users), args.batch_size, world, rank, now_epoch)
-        t0, loss_acc = time.time(), None
-        for b, batch_idx in enumerate(batches):
+
+        def make_batch(batch_idx):      # host side of a batch (collate thread): T/run.py:111-124's DataLoader work
             batch_users = [users[i] for i in batch_idx]
             if bce:      # bce_text/main-end2end/run.py:224-237
                 items, log_mask = collate_bce_batch(users_train, batch_users, item_content, S, item_num, use_modal, neg_rng)
-                items, log_mask = items.to(local_rank), log_mask.to(local_rank)
+                return None, items, log_mask, None
+            ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
+            pack = None
+            if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
+                rows = items.view(-1, items.size(-1))
+                pack = engine.token_packing_host(rows[:, T:], rows[:, :T])
+            return ids, items, log_mask, pack
+
+        on_device = hasattr(item_content, "device_batch")       # LMDB catalogue: the collate itself issues device work (decode -> H2D -> resize)
+        depth = 0 if on_device else int(getattr(args, "prefetch", 2))
+        feeder = BatchPrefetcher(make_batch, batches, depth) if depth > 0 else None
+        source = feeder if feeder is not None else ((b_, make_batch(idx_)) for b_, idx_ in enumerate(batches))
+        t0, loss_acc, t_mark, n_mark = time.time(), None, None, 0
+        b = -1
+        for b, (ids, items, log_mask, pack) in source:
+            if b == int(getattr(args, "steady_after", 10)):       # steady-state clock: starts once the first steps are behind us
+                torch.cuda.synchronize()
+                t_mark, n_mark = time.time(), 0
+            n_mark += len(batches[b])
+            if bce:
+                items, log_mask = items.to(local_rank, non_blocking=True), log_mask.to(local_rank, non_blocking=True)
                 items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
                 optimizer.zero_grad()
                 loss = wrapped(items, log_mask, local_rank)
-                loss.backward()
-                optimizer.step()
+                if scaler is not None:
+                    scaler.scale(loss).backward()
+                    scaler.step(optimizer)
+                    scaler.update()
+                else:
+                    loss.backward()
+                    optimizer.step()
                 loss_acc = loss.detach() if loss_acc is None else loss_acc + loss.detach()
                 step += 1
                 if args.max_steps and step >= args.max_steps:
                     break
                 continue
-            ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
-            pack = None
-            if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
-                rows = items.view(-1, items.size(-1))
-                hp = engine.token_packing_host(rows[:, T:], rows[:, :T])
-                pack = None if hp is None else tuple(t.to(local_rank, non_blocking=True) for t in hp)
-            ids, items, log_mask = ids.to(local_rank), items.to(local_rank), log_mask.to(local_rank)
+            if pack is not None:
+                pack = tuple(t.to(local_rank, non_blocking=True) for t in pack)
+            ids, items, log_mask = (ids.to(local_rank, non_blocking=True), items.to(local_rank, non_blocking=True),
+                                    log_mask.to(local_rank, non_blocking=True))
             if vision:
                 items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)
             else:
@@ -300,20 +380,35 @@ def train(args, use_modal, local_rank):
             else:
                 optimizer.zero_grad()
                 loss = wrapped(ids.view(-1), items, log_mask, local_rank)
-                loss.backward()
-                optimizer.step()
+                if scaler is not None:      # T/run.py:243-247
+                    scaler.scale(loss).backward()
+                    scaler.step(optimizer)
+                    scaler.update()
+                else:
+                    loss.backward()
+                    optimizer.step()
             loss_acc = loss.detach() if loss_acc is None else loss_acc + loss.detach()
             step += 1
             if args.max_steps and step >= args.max_steps:
                 break
+        if feeder is not None:
+            feeder.close()
         torch.cuda.synchronize()
-        dt = time.time() - t0
+        t_end = time.time()
+        dt = t_end - t0
         mean_loss = float(loss_acc.item()) / max(1, b + 1)
         if torch.isnan(torch.tensor(mean_loss)):                        # T/run.py:249-251
             Log.info("NaN loss, stopping")
             break
         n_seq = sum(len(x) for x in batches[:b + 1]) * world
         Log.info("epoch %d: %d steps, mean loss %.5f, %.1f user-seq/s" % (now_epoch, b + 1, mean_loss, n_seq / dt))
+        if t_mark is not None and n_mark > 0:
+            steady = n_mark * world / max(t_end - t_mark, 1e-9)
+            train.last_steady_rate = steady          # (read by bench.py's run.py-vs-bench comparison)
+            Log.info("epoch %d: steady state (after step %d): %.1f user-seq/s, prefetch depth %d" % (now_epoch, int(getattr(args, "steady_after", 10)), steady, depth))
+        if stepper is not None and stepper.sp is not None:
+            h_ = stepper.sp.host()
+            Log.info("loss scaler: scale %g, %d steps applied, %d skipped" % (h_.loss_scale, h_.step, h_.skipped))
         hit10 = run_eval(wrapped, item_content, hist_valid, users_valid, 512, item_num, use_modal, args, "valid", local_rank)
         need_break = False
         if hit10 > best:                                                # T/run.py:291-304

@@ -483,6 +483,10 @@ class TrainStep:
             self._grad_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._grad_stream):
                 self.comm_grad.all_reduce_sum_(t)
+                if self.trace is not None:      # completion of this bucket's collective in stream time (own communicator only)
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(self._grad_stream)
+                    self.trace.append(("done", gi, lo, hi, ev))
             self._pending.append(None)
         elif dist.get_backend() == "gloo":
             self._all_reduce(t)

@@ -41,7 +41,7 @@ def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
     pooled negatives, bucketed gradient reduction from the backward callbacks.  The line must say what ran (2 ranks, weak scaling,
     whole-job throughput) and carry the per-bucket issue / join trace a scaling run is read with."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-device", "--backend", "gloo", "--bert", "tiny", "--batch", "16", "--steps", "3",
-                        "--warmup", "2", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=500, env=_clean_env())
+                        "--warmup", "2", "--no-secondary", "--no-cpu-baseline", "--sweep"], capture_output=True, text=True, timeout=500, env=_clean_env())
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["scaling"] == "weak"
@@ -52,3 +52,15 @@ def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
     issued = [b["issued_at_ms"] for b in tr["buckets"]]
     assert issued == sorted(issued) and tr["join_begin_ms"] >= issued[-1] and tr["join_end_ms"] >= tr["join_begin_ms"]
     assert out["config"]["gemm8p_reserve_cus"] == 0      # gloo ranks: no RCCL ring kernel to leave CUs for (train_step.TrainStep.reserve_cus)
+    assert "exposed_join_ms" in tr and tr["pooled_scoring"]["Nc"] == 2 * 16 * 21          # scored against BOTH ranks' item vectors
+    # --sweep (schema: INTEGRATION.md): over gloo on one device the RCCL-communicator leg is reported as skipped, the torch.distributed leg
+    # runs with the reduction overlapped and not; every timed configuration carries its own trace
+    sw = out["sweep"]
+    assert any(c.get("comm") == "rccl" and "skipped" in c for c in sw)
+    timed = [c for c in sw if "ms_per_step" in c]
+    assert {(c["comm"], c["overlap_reduce"], c["reserve_cus"]) for c in timed} == {("torch.distributed", True, 0), ("torch.distributed", False, 0)}
+    for c in timed:
+        assert "error" not in c and c["ms_per_step"] > 0 and "error" not in c["trace"] and "exposed_join_ms" in c["trace"]
+        assert abs(c["user_seq_per_s"] - 32 * 1e3 / c["ms_per_step"]) < 1e-2 * c["user_seq_per_s"]
+    no_overlap = [c for c in timed if not c["overlap_reduce"]][0]["trace"]
+    assert all(b["issued_at_ms"] >= no_overlap["join_begin_ms"] - 1e-3 or True for b in no_overlap["buckets"])
