@@ -181,7 +181,8 @@ def main():
         from idvs.morec_amd.swin_engine import SwinShape
         S, T, D = 10, 0, (2048 if a.tower != "swin_micro" else 64)
         vshape = SwinShape.named(a.tower)
-        a.item_num = min(a.item_num, 4096)        # the image catalog lives in HBM (fp32 NCHW, what V/run.py:201-204 uploads)
+        a.item_num = min(a.item_num, 4096 if a.vision_input == "resident" else 1024)   # the image catalogue lives in HBM (fp32 NCHW, what
+        #                                                                                 V/run.py:201-204 uploads) or, decoded uint8, on the host
         args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
                                      CV_model_load=a.tower, compute_dtype=a.dtype)
     else:
@@ -231,7 +232,6 @@ def main():
         # crosses PCIe as uint8 and is resampled + normalised on the GPU
         from idvs.morec_amd.data_utils.images import pack_images
         from idvs.morec_amd.run import BatchPrefetcher
-        a.item_num = min(a.item_num, 1024)
         NS = a.native_size
         host_imgs = np.random.default_rng(4321).integers(0, 256, (a.item_num + 1, NS, NS, 3), dtype=np.uint8)
         u8_stats = {"pack_s": 0.0, "batches": 0, "bytes": 0}

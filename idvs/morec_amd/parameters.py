@@ -66,7 +66,7 @@ def build_parser():
     p.add_argument("--synthetic_full_len", action="store_true", help="synthetic users all have raw history max_seq_len + 3 (train sequences "
                    "of exactly S + 1 items, no padding): the shape bench.py times (SURVEY.md §8d)")
     p.add_argument("--max_steps", type=int, default=0)
-    p.add_argument("--prefetch", type=int, default=2, help="batches built ahead of the device by the collate thread (run.BatchPrefetcher; "
+    p.add_argument("--prefetch", type=int, default=4, help="batches built ahead of the device by the collate thread (run.BatchPrefetcher; "
                    "T/run.py:111-124 uses DataLoader(num_workers=12, pin_memory=True)); 0 = collate inline on the main thread")
     p.add_argument("--steady_after", type=int, default=10, help="the epoch log also reports user-seq/s over the steps after this many (allocator "
                    "warm-up, first-call set-up and the loss scaler's initial back-off excluded)")

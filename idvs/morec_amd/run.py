@@ -84,6 +84,7 @@ class BatchPrefetcher:
         self.make, self.batches, self.pin = make, batches, pin and torch.cuda.is_available()
         self.q = queue.Queue(maxsize=max(1, depth))
         self.stop = threading.Event()
+        self.wait_s, self.make_s, self.n = 0.0, 0.0, 0      # consumer time blocked on an empty queue; worker time building batches
         self.t = threading.Thread(target=self._run, name="morec-prefetch", daemon=True)
         self.t.start()
 
@@ -104,7 +105,11 @@ class BatchPrefetcher:
     def _run(self):
         try:
             for b, idx in enumerate(self.batches):
-                if not self._put((b, tuple(self._pin(x) for x in self.make(idx)))):
+                t_ = time.perf_counter()
+                item = (b, tuple(self._pin(x) for x in self.make(idx)))
+                self.make_s += time.perf_counter() - t_
+                self.n += 1
+                if not self._put(item):
                     return
         except BaseException as e:  # noqa: BLE001 -- handed to the consumer
             self._put(e)
@@ -113,7 +118,9 @@ class BatchPrefetcher:
 
     def __iter__(self):
         while True:
+            t_ = time.perf_counter()
             item = self.q.get()
+            self.wait_s += time.perf_counter() - t_
             if item is None:
                 return
             if isinstance(item, BaseException):
@@ -406,6 +413,8 @@ def train(args, use_modal, local_rank):
             steady = n_mark * world / max(t_end - t_mark, 1e-9)
             train.last_steady_rate = steady          # (read by bench.py's run.py-vs-bench comparison)
             Log.info("epoch %d: steady state (after step %d): %.1f user-seq/s, prefetch depth %d" % (now_epoch, int(getattr(args, "steady_after", 10)), steady, depth))
+            if feeder is not None and feeder.n:
+                Log.info("collate thread: %.2f ms per batch; the training loop waited %.1f ms in total for batches" % (feeder.make_s / feeder.n * 1e3, feeder.wait_s * 1e3))
         if stepper is not None and stepper.sp is not None:
             h_ = stepper.sp.host()
             Log.info("loss scaler: scale %g, %d steps applied, %d skipped" % (h_.loss_scale, h_.step, h_.skipped))
