@@ -203,8 +203,10 @@ def main():
     model = Model(args, a.item_num, not id_tower, tower, pop).to(dev)
     model.train()
     log("model on device; building TrainStep arenas")
+    # defer_update: with a step block (fp16) the AdamW launches of step t run under the forward pass of step t + 1 (TrainStep docstring);
+    # the timed region ends with a device synchronisation, so every update it issued is inside it
     ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool,
-                   dedup_items=a.dedup)
+                   dedup_items=a.dedup, defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0")
 
     # host batches in pinned memory: what the reference's DataLoader hands to T/run.py:232-234
     host = []

@@ -47,6 +47,10 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
     }
     a.vec_store = ((d->N * os) % 16 == 0) && ((d->ldc * os) % 16 == 0) && (!aux_out || aligned16(aux_out));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    {   // narrow outputs over very many rows (Swin stage 1 / 2): the streaming kernel (gemm_skinny.hip)
+        const int rs = gemm_skinny_try_launch(d, a, s);
+        if (rs != G8_NOT_TAKEN) return rs;
+    }
     {   // bf16, large: the 256 x 256 eight-phase kernel (gemm8p.hip)
         const int r8 = gemm8p_try_launch(d, a, s);
         if (r8 != G8_NOT_TAKEN) return r8;

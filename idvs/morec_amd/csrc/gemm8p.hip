@@ -589,6 +589,7 @@ extern "C" int morec_tuning_set(const char* key, int value) {
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_split")) { g_tail_split = value != 0; return MOREC_OK; }
     if (!strcmp(key, "ce8p")) { g_ce8p_mode = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm_skinny")) { g_skinny_mode = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_ngroup")) { g_ngroup = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_reserve_cus")) { g_reserve_cus = value < 0 ? 0 : value > 128 ? 128 : value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_bias")) { g_tail_bias = value < 0 ? 0 : value > 16 ? 16 : value; return MOREC_OK; }

@@ -33,6 +33,8 @@ struct GemmArgs {
 // reports "not eligible" with G8_NOT_TAKEN so that the caller falls through to the generic kernels.
 #define G8_NOT_TAKEN 0x7fff0001
 int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);
+int gemm_skinny_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm_skinny.hip: N <= 128, K <= 384, plain product
+extern int g_skinny_mode;
 int gemm_nt_f16_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm_f16.hip
 int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
 // morec_gemm_tn with a choice of output type for the slab fold (gemm_tn.hip)

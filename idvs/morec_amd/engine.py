@@ -457,7 +457,7 @@ def bert_needs_grad_buffer(name: str, grad_from: int, prefix: str = TE) -> bool:
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
                  mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None,
-                 grad_from: int = -1, packing=None):
+                 grad_from: int = -1, packing=None, on_use=None):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
 
     ``unpad``: run the encoder layers on the REAL tokens only (packed rows + ``cu_seqlens``) instead of all T positions of
@@ -465,7 +465,12 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     ``finfo.min`` mask, i.e. probability exactly 0, so they never reach a real token, and every other operator is row-wise.
     Requires the mask to be a run of ones followed by zeros (what ``get_doc_input_bert``, preprocess.py:131-172, builds);
     an all-zero row (the padding item, preprocess.py:135-136) keeps its first token -- its vector reaches nothing
-    (masked columns / keys, dropped rows)."""
+    (masked columns / keys, dropped rows).
+    ``on_use(key)`` (optional) is called right before the first kernel that reads a parameter set -- ``"pre"`` (embeddings and whatever
+    sits outside the encoder layers), ``("layer", l)``, ``"head"`` (the projection) -- so that a driver whose previous optimizer update
+    is still running on another stream can make this stream wait for just that slice (``TrainStep(defer_update=True)``)."""
+    if on_use is not None:
+        on_use("pre")
     bm = prefix + "bert_model."
     Nc, T2 = text.shape
     T = T2 // 2
@@ -502,6 +507,8 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
             keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
     saved_layers = []
     for l, w in enumerate(prep["layers"]):
+        if on_use is not None:
+            on_use(("layer", l))
         ng = need_grad and l >= grad_from      # layers below the first trainable one keep nothing for a backward that never reaches them
         if l == n_layers - 1:     # only hidden[:, 0] is consumed (encoders.py:69): row-wise work on the [CLS] rows only
             cls, sv = layer_forward_cls(cfg, w, x, keep, Nc, ng, drop, 1 + 3 * l, cu)
@@ -510,6 +517,8 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
         saved_layers.append(sv)
     if n_layers == 0:
         cls = ops.strided_rows_copy(x, torch.empty((Nc, H), device=x.device, dtype=dtype), Nc, H, T, 1)
+    if on_use is not None:
+        on_use("head")
     D = prep["fc"].w.shape[0]
     pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)

@@ -305,7 +305,8 @@ def train(args, use_modal, local_rank):
     stepper, optimizer = None, None
     if args.fused_step:
         stepper = TrainStep(model, lr=args.lr, fine_tune_lr=args.fine_tune_lr, l2_weight=args.l2_weight,
-                            fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives)
+                            fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives,
+                            defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0")      # (the epoch ends with a device synchronisation before eval / save)
         if ckpt is not None and ckpt.get("optimizer") is not None:     # T/run.py:193-195
             stepper.load_optimizer_state_dict(ckpt["optimizer"])
         wrapped = model

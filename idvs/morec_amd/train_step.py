@@ -132,11 +132,18 @@ class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
                  betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False,
                  force_collectives: bool = False, comm: str | None = None, loss_scale: float | None = None,
-                 dynamic_loss_scale: bool = True, growth_interval: int = 2000):
+                 dynamic_loss_scale: bool = True, growth_interval: int = 2000, defer_update: bool | None = None):
         """``loss_scale`` / ``dynamic_loss_scale`` / ``growth_interval``: the GradScaler of the reference's fp16 step (``T/run.py:210``:
         defaults 65536, x2 after 2000 clean steps, x0.5 and a skipped step on inf / NaN), kept in a device block (``ops.StepParams``).
         Engaged automatically for ``compute_dtype == "fp16"``; ``loss_scale=`` a number forces it on for the other dtypes too
-        (``MOREC_STEP_PARAMS=1``: with scale 1) -- the device-resident step state without the scaling."""
+        (``MOREC_STEP_PARAMS=1``: with scale 1) -- the device-resident step state without the scaling.
+        ``defer_update`` (``MOREC_DEFER_UPDATE=1``; text tower with a step block, i.e. the fp16 mode): ``step()`` leaves the AdamW launches of
+        step t on the side stream, slice by slice in the order the forward pass reads the parameters, and the forward pass of step t + 1
+        waits for each slice right before its first use -- the update (28 B / parameter of HBM traffic) then runs under the MFMA-bound
+        encoder GEMMs of the next step instead of behind the overflow verdict at the end of its own (the other dtypes hide it under their
+        own backward pass, ``_early_adamw``; a step block rules that out: the verdict covers the whole step).  CONTRACT: between two
+        ``step()`` calls the parameters may still be in flight on the side stream -- read them only after ``flush()`` (which
+        ``optimizer_state_dict`` / ``load_state_dict`` / ``applied_steps`` call) or a device synchronisation."""
         self.model = model
         # SURVEY.md §8(f)-2: encode every DISTINCT item of the batch once (the reference re-encodes duplicates: Zipf-popular
         # items fill many of the B (S + 1) slots) and gather the vectors back to the slots; the slot gradients are
@@ -216,13 +223,18 @@ class TrainStep:
         # Device-resident step state (step count, AdamW bias corrections, loss scale, overflow flag).  fp16 activation gradients need the
         # loss scaling (their range ends at 6e-8); the other dtypes run it on request only.
         self.sp = None
+        self._param_ready = {}      # deferred update: key -> event recorded behind that slice's AdamW on the side stream
         if self.dtype == torch.float16 or loss_scale is not None or os.environ.get("MOREC_STEP_PARAMS", "0") == "1":
             init = float(loss_scale) if loss_scale is not None else (65536.0 if self.dtype == torch.float16 else 1.0)
             self.sp = ops.StepParams(self.device, init_scale=init, step=0, growth_interval=growth_interval,
                                      dynamic=bool(dynamic_loss_scale) and (self.dtype == torch.float16 or loss_scale is not None))
         self.buckets = self._bucket_plan()
+        if defer_update is None:
+            defer_update = os.environ.get("MOREC_DEFER_UPDATE", "0") == "1"
+        self.defer_update = bool(defer_update) and self.sp is not None and model.use_modal and not self.vision and self.device.type == "cuda"
         self._pending, self._reduced, self._stepped = [], [], []
         self._fused_update = False
+        self._in_step = False
         self.trace = None           # list -> _reduce_slice / reduce_gradients record stream-time events of the gradient collectives
         self._inflight = []         # end-of-step events of the steps the host has issued and not yet waited for (at most two)
 
@@ -406,7 +418,8 @@ class TrainStep:
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
             E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
                                              self.bert_mask_value, engine.TE, d_item, grad_from=self.bert_grad_from,
-                                             packing=None if dedup else token_packing)
+                                             packing=None if dedup else token_packing, on_use=self._await_params if self._param_ready else None)
+            self._await_params(None)      # whatever the tower did not ask for (the recommender group's slice) before SASRec reads it
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
             E = ops.gather_rows(p["id_embedding.weight"], idx32, self.dtype)
@@ -590,6 +603,7 @@ class TrainStep:
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """``model.load_state_dict`` + ``sync_shadow`` (the parameters are views of the arenas, so the copy lands there)."""
+        self.flush()
         out = self.model.load_state_dict(state_dict, strict=strict)
         self.sync_shadow()
         return out
@@ -657,6 +671,7 @@ class TrainStep:
     def applied_steps(self) -> int:
         """Optimizer steps that really updated the parameters (synchronises when a step block is in use: steps skipped for a non-finite
         gradient do not count, exactly as torch's AdamW ``step`` under GradScaler)."""
+        self.flush()
         return int(self.sp.host().step) if self.sp is not None else self.step_count
 
     def scaler_state_dict(self):
@@ -679,18 +694,67 @@ class TrainStep:
             return t[0]
         return loss
 
+    def _await_params(self, key):
+        """Deferred update: make the CURRENT stream wait for the AdamW of the slice the forward pass is about to read (``key`` None: all
+        that is left)."""
+        if not self._param_ready:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for k in ([key] if key is not None else list(self._param_ready)):
+            ev = self._param_ready.pop(k, None)
+            if ev is not None:
+                cur.wait_event(ev)
+
+    def flush(self):
+        """Deferred update: the current stream waits for every AdamW launch still in flight on the side stream.  Call before reading
+        parameters / optimizer state between steps (a device synchronisation does the same)."""
+        self._await_params(None)
+
+    def _update_plan(self):
+        """Slices of the arenas in the order the forward pass first reads them: everything of the tower group outside the per-layer
+        buckets (the embeddings) -> "pre", the encoder layers, then the recommender group (projection head + SASRec) -> "head"."""
+        plan = []
+        if len(self.groups) > 1:
+            n0 = self.groups[0]["arena"].numel
+            layers = sorted((lo, hi, k) for k, (lo, hi) in self.buckets.items())
+            pos = 0
+            for lo, hi, k in layers:
+                if lo > pos:
+                    plan.append(("pre", 0, pos, lo))
+                pos = hi
+            if pos < n0:
+                plan.append(("pre", 0, pos, n0))
+            plan = [x for x in plan if x[0] == "pre"] + [(k, 0, lo, hi) for lo, hi, k in layers]
+        gi = len(self.groups) - 1
+        plan.append(("head", gi, 0, self.groups[gi]["arena"].numel))
+        return plan
+
     def optimizer_step(self):
         """AdamW over everything ``_early_adamw`` has not already stepped during this step's backward pass (all of it outside ``step()``).
         With a step block (fp16 mode): GradScaler.step + update on the device -- overflow check of every gradient arena, the decision,
         then the update (or nothing); ``step_count`` then counts the calls, ``applied_steps()`` the updates that happened."""
         self.step_count += 1
         if self.sp is not None:
+            self.flush()      # (a deferred update of the previous step that nothing has waited for yet)
             for grp in self.groups:
                 self.sp.check_finite_(grp["arena"].grad)
             self.sp.decide_(self.betas[0], self.betas[1])
-            for grp in self.groups:
-                a = grp["arena"]
-                ops.adamw_sp_(a.data, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], self.sp)
+            side = engine.WgradStream.get(self.device) if (self.defer_update and self._in_step) else None
+            if side is None:
+                for grp in self.groups:
+                    a = grp["arena"]
+                    ops.adamw_sp_(a.data, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], self.sp)
+            else:      # deferred: slice by slice in forward order on the side stream, an event behind each (see __init__)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for key, gi, lo, hi in self._update_plan():
+                        grp = self.groups[gi]
+                        a = grp["arena"]
+                        ops.adamw_sp_(a.data[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], None if a.shadow is None else a.shadow[lo:hi],
+                                      grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], self.sp)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        self._param_ready[key] = ev          # (several "pre" slices: the last event covers them all -- one stream)
             self._stepped = []
             return
         for gi, grp in enumerate(self.groups):
@@ -722,7 +786,11 @@ class TrainStep:
         finally:
             self._fused_update = False
         self.reduce_gradients()
-        self.optimizer_step()
+        self._in_step = True
+        try:
+            self.optimizer_step()
+        finally:
+            self._in_step = False
         if self.device.type == "cuda":
             self._inflight[-1].record(torch.cuda.current_stream(self.device))
         return loss

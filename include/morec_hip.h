@@ -26,7 +26,7 @@
  * behind thread-safe function-local statics).  One process drives one GPU (the reference's process model, T/run.py:305-321):
  *   1. process-wide kernel-SELECTION knobs, morec_tuning_set() and the environment variables read once at the first GEMM
  *      launch: MOREC_GEMM8P (0 automatic | 1 never | 2 always the eight-phase kernel), MOREC_GEMM8P_TAIL_SPLIT (0 | 1),
- *      MOREC_GEMM8P_NGROUP (tile order), MOREC_GEMM8P_RESERVE_CUS, MOREC_CE8P, MOREC_GEMM8P_DEBUG (ablation bits), MOREC_GEMM_TILE /
+ *      MOREC_GEMM8P_NGROUP (tile order), MOREC_GEMM8P_RESERVE_CUS, MOREC_GEMM_SKINNY, MOREC_CE8P, MOREC_GEMM8P_DEBUG (ablation bits), MOREC_GEMM_TILE /
  *      MOREC_GEMM_EPI (two-buffer kernel variants), MOREC_SWIN_BWD_WIDE.  Every selectable kernel computes the same function
  *      to the same accuracy; "gemm8p_tail_split" = 1 is the only knob that changes the fp32 SUMMATION ORDER (and with it the
  *      last-bit rounding pattern of bf16 outputs), which is why it is off unless asked for.  Set knobs before the first
@@ -68,6 +68,7 @@ int morec_version(void);
  *   "gemm8p_tail_bias"   share of K the first part takes in that split;
  *   "gemm8p_ngroup"      tile order: -1 = automatic column groups (default), 0 = row-major, n = column groups of n N-tiles;
  *   "gemm8p_reserve_cus" CUs (multiple of 8) left out of the persistent grid for a concurrent RCCL kernel;
+ *   "gemm_skinny"        0 = automatic, 1 = never use the streaming kernel for narrow outputs (N <= 128, K <= 384, M >= 8192, plain product);
  *   "ce8p"               scoring kernels: 0 = automatic, 1 = always the 128 x 128 kernels, 2 = the 256 x 256 eight-phase kernels
  *                        wherever the shape rules allow (bf16, D > 64, D % 8 == Nc % 8 == (B S) % 8 == 0);
  *   "gemm8p_debug", "gemm8p_stamps_lo/hi"  ablation bits / device address of a cycle-stamp buffer (diagnostics).

@@ -186,6 +186,59 @@ def test_loss_scaler_skips_overflowing_steps_whole_and_backs_off():
     assert int(float(sd["state"][0]["step"])) == h.step
 
 
+def test_deferred_update_equals_the_inline_one():
+    """``TrainStep(defer_update=True)``: the AdamW launches of step t run on the side stream under the forward pass of step t + 1, every
+    layer of which waits for its own slice.  Same arithmetic per element, so the two trajectories may differ only by the run-to-run noise
+    of the step itself (fp32 atomics in the LayerNorm / embedding / bias gradient sums: measured by running the inline form twice), while a
+    forward pass that read a slice BEFORE its update would be off by a whole optimizer step (lr 3e-3: orders of magnitude above that)."""
+    import bench
+    from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    from idvs.morec_amd.train_step import TrainStep
+    B, S, T, D, item_num = 32, 20, 30, 256, 4000
+    shape = BertShape.named("mini")
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_mini", word_embedding_dim=shape.hidden_size, compute_dtype="fp16")
+    content = bench.synth_catalog(item_num, T, np.random.default_rng(1))
+    ids_all = bench.synth_batches(8, B, S, item_num, np.random.default_rng(2))
+    counts = np.bincount(ids_all.reshape(-1), minlength=item_num + 1).astype(np.float64) + 1.0
+    pop = counts / counts[1:].sum()
+    pop[0] = 1.0
+    res = {}
+    for defer in (False, "again", True):
+        torch.manual_seed(7)
+        m = Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), pop).to(DEV).train()
+        ts = TrainStep(m, lr=3e-3, fine_tune_lr=3e-3, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, loss_scale=1024.0,
+                       defer_update=(defer is True))
+        assert ts.defer_update == (defer is True)
+        losses = []
+        for i in range(8):
+            ids = torch.from_numpy(ids_all[i]).to(DEV)
+            items = torch.from_numpy(content[ids_all[i].reshape(-1)]).to(DEV)
+            rows = items.view(-1, items.size(-1)).cpu()
+            from idvs.morec_amd import engine
+            pack = tuple(t.to(DEV) for t in engine.token_packing_host(rows[:, T:], rows[:, :T]))
+            losses.append(ts.step(ids.view(-1), items, torch.ones(B, S, device=DEV), token_packing=pack))
+        if defer is True:
+            assert ts._param_ready, "the last step's update should still be pending on the side stream"
+        assert ts.applied_steps() == 8            # flushes
+        assert not ts._param_ready
+        torch.cuda.synchronize()
+        res[defer] = ([float(x) for x in losses], [g["arena"].data.clone() for g in ts.groups], [g["arena"].exp_avg_sq.clone() for g in ts.groups],
+                      [g["arena"].shadow.clone() for g in ts.groups])
+    def dist(x, y):
+        dl = max(abs(a_ - b_) for a_, b_ in zip(res[x][0], res[y][0]))
+        dp = max(float((a_.double() - b_.double()).norm() / b_.double().norm()) for a_, b_ in zip(res[x][1], res[y][1]))
+        return dl, dp
+    noise_l, noise_p = dist(False, "again")
+    dl, dp = dist(False, True)
+    print(f"deferred vs inline update over 8 steps: max |d loss| {dl:.2e} (run-to-run noise of the inline form {noise_l:.2e}); "
+          f"relative parameter distance {dp:.2e} (noise {noise_p:.2e}); loss {res[True][0][0]:.4f} -> {res[True][0][-1]:.4f}")
+    assert res[False][0][0] == res[True][0][0]                 # step 0 sees the same parameters: identical
+    assert dl <= 10 * noise_l + 2e-4 and dp <= 10 * noise_p + 1e-5
+    assert res[True][0][-1] < res[True][0][0] - 0.3            # eight steps at lr 3e-3 move the loss by far more than either bound
+
+
 @pytest.mark.parametrize("mode", ["fp16", "bf16", "fp32x3"])
 def test_g17_modal_eval_golden_in_the_fast_modes(golden_dir, mode):
     """HR@10 / nDCG@10 through the BERT tower on the device in the modes that are timed (golden g17, captured from the reference's
