@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [("n_seq", C.c_int), ("T", C.c_int), ("n_heads", C.c_int), ("dh", C.c_int), ("causal", C.c_int),
                 ("scale", C.c_float), ("mask_value", C.c_float), ("dtype", C.c_int), ("p_drop", C.c_float),
-                ("seed", C.c_uint64), ("cu_seqlens", C.c_void_p)]
+                ("seed", C.c_uint64), ("cu_seqlens", C.c_void_p), ("total_rows", C.c_int), ("spare_rows_max", C.c_int)]
 
 
 class TransposeItem(C.Structure):      # morec_transpose_item
@@ -51,7 +51,7 @@ class CeDesc(C.Structure):
 class StepParams(C.Structure):       # morec_step_params (64 bytes, lives on the DEVICE; this mirror is for host-side reads of a copy)
     _fields_ = [("step", C.c_int32), ("found_inf", C.c_int32), ("growth_tracker", C.c_int32), ("skipped", C.c_int32),
                 ("loss_scale", C.c_float), ("inv_scale", C.c_float), ("bc1", C.c_float), ("bc2", C.c_float), ("apply", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("pad0", C.c_int32), ("drop_seed", C.c_uint64), ("drop_seed_mixed", C.c_uint64), ("reserved", C.c_int32 * 2)]
 
 
 class SwinAttnDesc(C.Structure):
@@ -98,6 +98,7 @@ _SIGS = {
     "morec_bce_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_adamw": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                               C.c_int, C.c_float, _P]),
+    "morec_dropout_seed_source": (C.c_int, [_P]),
     "morec_step_params_init": (C.c_int, [_P, C.c_float, C.c_int, _P]),
     "morec_grad_check_finite": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "morec_step_decide": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _P]),

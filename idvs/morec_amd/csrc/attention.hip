@@ -29,6 +29,7 @@ struct AttnArgs {
     float scale, mask_value;
     DropRng drop;      // attention-probability dropout (modules.py:30; HF attention_probs_dropout_prob)
     const int32_t* cu; // packed-row offsets (unpadded layout) or nullptr
+    int total_rows;    // rows of the packed buffers (>= cu[n_seq]); the spare ones are zero-filled by the blocks behind the grid
 };
 
 // stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to 32 rows
@@ -160,6 +161,11 @@ __device__ __forceinline__ void store_rows(T* __restrict__ dst, size_t row0, int
 
 template <typename T, int DC>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows of a bucket-padded packed layout: ctx = 0 there
+        zero_dead_rows(a.ctx, a.cu, a.n_seq, a.total_rows, (size_t)a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
     constexpr int P = DC + 4;
     const int seq_ = blockIdx.x / a.n_heads;
     const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
@@ -215,6 +221,11 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
 //   dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(P o dP)) * scale, dQ = dS K, dK = dS^T Q.
 template <typename T, int DC>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows: dqkv = 0 there
+        zero_dead_rows(a.dqkv, a.cu, a.n_seq, a.total_rows, (size_t)3 * a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
     constexpr int P = DC + 4;
     const int seq_ = blockIdx.x / a.n_heads;
     const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
@@ -306,9 +317,12 @@ int check_desc(const morec_attn_desc* d) {
     if (d->T > TP) return MOREC_E_UNSUPPORTED;
     if (d->dh % 8) return MOREC_E_ALIGN;
     if (d->p_drop < 0.f || d->p_drop >= 1.f) return MOREC_E_ARG;
+    if (d->total_rows < 0 || d->spare_rows_max < 0 || (d->spare_rows_max > 0 && (!d->cu_seqlens || d->total_rows <= 0))) return MOREC_E_ARG;
     return MOREC_OK;
 }
 }  // namespace
+// blocks appended behind the (sequence, head) grid: 16 spare rows each (morec_attn_desc.spare_rows_max)
+int attn_spare_blocks(const morec_attn_desc* d) { return (d->cu_seqlens && d->total_rows > 0) ? (d->spare_rows_max + 15) / 16 : 0; }
 
 // bf16 fast path on the matrix cores (attention_mfma.hip); MOREC_E_UNSUPPORTED = shape outside it
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
@@ -336,8 +350,8 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc) return rc;
     if (!qkv || !key_keep || !ctx) return MOREC_E_ARG;
     AttnArgs a{qkv, key_keep, ctx, nullptr, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
-               make_drop(d->p_drop, d->seed), d->cu_seqlens};
-    dim3 grid(d->n_seq * d->n_heads), block(64);
+               make_drop(d->p_drop, d->seed), d->cu_seqlens, d->total_rows};
+    dim3 grid(d->n_seq * d->n_heads + attn_spare_blocks(d)), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
@@ -357,8 +371,8 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc) return rc;
     if (!qkv || !key_keep || !dctx || !dqkv) return MOREC_E_ARG;
     AttnArgs a{qkv, key_keep, const_cast<void*>(dctx), dqkv, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale,
-               d->mask_value, make_drop(d->p_drop, d->seed), d->cu_seqlens};
-    dim3 grid(d->n_seq * d->n_heads), block(64);
+               d->mask_value, make_drop(d->p_drop, d->seed), d->cu_seqlens, d->total_rows};
+    dim3 grid(d->n_seq * d->n_heads + attn_spare_blocks(d)), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;

@@ -33,6 +33,7 @@ struct AttnMArgs {
     float scale, mask_value;
     DropRng drop;
     const int32_t* cu;  // packed-row offsets (unpadded layout) or nullptr
+    int total_rows;     // rows of the packed buffers; the spare ones (>= cu[n_seq]) are zero-filled by the blocks behind the grid
 };
 
 
@@ -301,6 +302,11 @@ __device__ __forceinline__ void bwd_products(const AttnMArgs& a, const char* sQ,
 
 template <typename T16>
 __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows of a bucket-padded packed layout: ctx = 0 there
+        zero_dead_rows(a.ctx, a.cu, a.n_seq, a.total_rows, (size_t)a.n_heads * a.dh * 2, (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
     __shared__ __attribute__((aligned(16))) char sV[TILE];
     const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
     const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
@@ -377,6 +383,11 @@ __global__ __launch_bounds__(64) void attn_fwd_mfma_kernel(AttnMArgs a) {
 
 template <typename T16>
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows: dqkv = 0 there
+        zero_dead_rows(a.dqkv, a.cu, a.n_seq, a.total_rows, (size_t)3 * a.n_heads * a.dh * 2, (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
     __shared__ __attribute__((aligned(16))) char sQ[TILE];
     __shared__ __attribute__((aligned(16))) char sK[TILE];
     __shared__ __attribute__((aligned(16))) char sO[TILE];
@@ -503,14 +514,15 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
 
 }  // namespace
 
+int attn_spare_blocks(const morec_attn_desc* d);      // attention.hip
 // returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
                            void* dqkv, bool backward, hipStream_t s, float* csum) {
     if (!is_h16(d->dtype) || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
     AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
                 reinterpret_cast<bf16*>(dqkv), csum, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,
-                make_drop(d->p_drop, d->seed), d->cu_seqlens};
-    dim3 grid(d->n_seq * d->n_heads), block(64);
+                make_drop(d->p_drop, d->seed), d->cu_seqlens, d->total_rows};
+    dim3 grid(d->n_seq * d->n_heads + attn_spare_blocks(d)), block(64);
     by_h16(d->dtype, [&](auto* t) {
         using T = MOREC_TAG_T(t);
         if (backward)

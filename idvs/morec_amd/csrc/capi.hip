@@ -15,7 +15,16 @@ extern "C" const char* morec_strerror(int code) {
     return "unknown morec error";
 }
 
-extern "C" int morec_version(void) { return 100; }
+extern "C" int morec_version(void) { return 104; }
+
+// Process-wide dropout seed source (see morec_hip.h): a device uint64 folded into every dropout / DropPath stream at kernel entry.
+static const uint64_t* g_drop_seed_src = nullptr;
+const uint64_t* morec_drop_seed_src() { return g_drop_seed_src; }
+extern "C" int morec_dropout_seed_source(const void* dev_u64) {
+    if (reinterpret_cast<uintptr_t>(dev_u64) & 7u) return MOREC_E_ALIGN;
+    g_drop_seed_src = reinterpret_cast<const uint64_t*>(dev_u64);
+    return MOREC_OK;
+}
 
 // Probe: (a) MFMA fragment/accumulator layouts with recognisable integer data, (b) what each lane of
 // ds_read_b64_tr_b16 receives when lane l supplies address base + 8*l over an LDS image lds16[x] = x.
@@ -67,6 +76,7 @@ extern "C" int morec_probe(int32_t* out, void* stream) {
 
 // test hook: the keep-mask the kernels derive from (p, seed) for element indices 0 .. n-1
 __global__ void drop_mask_kernel(uint8_t* out, size_t n, DropRng d) {
+    d = drop_resolve(d);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = drop_keep(d, i) ? 1 : 0;
 }

@@ -298,14 +298,28 @@ __device__ __forceinline__ void dgelu4_mul(float (&v)[4], const float (&u)[4]) {
 struct DropRng {
     uint32_t s0, s1, thresh;   // keep iff 16-bit draw >= thresh, thresh = round-down(p * 2^16)
     float inv_keep;            // 1 / (1 - thresh / 2^16): exactly unbiased for the probability actually applied
+    const uint64_t* src;       // device word XOR-ed into (s0, s1) at kernel entry (morec_dropout_seed_source), or null
 };
-__host__ __device__ inline DropRng make_drop(float p, uint64_t seed) {
+// The process-wide seed source (capi.hip; include/morec_hip.h: morec_dropout_seed_source): with it, the masks of a launch are a function of
+// (seed argument, *source) -- a captured graph whose seed ARGUMENTS are frozen still draws fresh masks at every replay.
+const uint64_t* morec_drop_seed_src();
+inline DropRng make_drop(float p, uint64_t seed) {
     DropRng d;
+    d.src = p > 0.f ? morec_drop_seed_src() : nullptr;
     d.s0 = (uint32_t)seed;
     d.s1 = (uint32_t)(seed >> 32);
     const double t = (double)p * 65536.0;
     d.thresh = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (uint32_t)t));
     d.inv_keep = 1.0f / (1.0f - (float)d.thresh / 65536.0f);
+    return d;
+}
+// kernel entry: fold the device-resident seed word in (one scalar load; a no-op without a source)
+__device__ __forceinline__ DropRng drop_resolve(DropRng d) {
+    if (d.src) {
+        const uint64_t v = *d.src;
+        d.s0 ^= (uint32_t)v;
+        d.s1 ^= (uint32_t)(v >> 32);
+    }
     return d;
 }
 // hash of element pair `pair` (= element index >> 1)
@@ -328,6 +342,19 @@ __device__ __forceinline__ void drop_keep_vec(const DropRng& d, uint64_t idx0, b
         keep[k] = (h & 0xffffu) >= d.thresh;
         keep[k + 1] = (h >> 16) >= d.thresh;
     }
+}
+
+// ---- packed ("varlen") token layouts with SPARE rows: the blocks a launcher appends behind its (sequence, head) grid zero the rows
+// [cu[n_seq], total_rows) of a row-major output, 16 rows per block -- rows no sequence owns (a layout padded up to a bucket size so that
+// one captured graph serves every batch of the bucket) then hold exact zeros instead of whatever the allocator left there, and the
+// weight-gradient products that sum over ALL rows are unaffected by them.
+__device__ __forceinline__ void zero_dead_rows(void* base, const int32_t* cu, int n_seq, int total_rows, size_t rowbytes, int eblock) {
+    const int r0 = cu[n_seq] + eblock * 16;
+    const int r1 = min(r0 + 16, total_rows);
+    if (r0 >= r1) return;
+    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (size_t)r0 * rowbytes);
+    const size_t n16 = (size_t)(r1 - r0) * rowbytes / 16;
+    for (size_t i = threadIdx.x; i < n16; i += blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ---- host-side argument checks -------------------------------------------------------------------------

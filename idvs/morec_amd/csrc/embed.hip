@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const int32_t* __re
                                                              T* __restrict__ z_out, T* __restrict__ y,
                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                              int M, int Tlen, int H, DropRng dout) {
+    dout = drop_resolve(dout);
     constexpr int EV = vio<T>::EV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);

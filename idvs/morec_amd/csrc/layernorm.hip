@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out, int M, int N, DropRng din,
                                                      DropRng dout, const float* __restrict__ rowscale, int rps) {
+    din = drop_resolve(din);
+    dout = drop_resolve(dout);
     constexpr int EV = vio<T>::EV;
     constexpr int GRP = 64 / LPR;
     const int lane = threadIdx.x & (LPR - 1);
@@ -149,6 +151,8 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
                                                      float* __restrict__ dbeta, float* __restrict__ dbias, int M, int N,
                                                      int rows_per_block, DropRng din, DropRng dout,
                                                      const T* __restrict__ dres, const float* __restrict__ rowscale, int rps) {
+    din = drop_resolve(din);
+    dout = drop_resolve(dout);
     constexpr int EV = vio<T>::EV;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int GRP = 64 / LPR, NP = 4 * GRP;     // row groups per wave, column-partial sets per block

@@ -103,6 +103,11 @@ __global__ void step_params_init_kernel(morec_step_params* sp, float init_scale,
         z.inv_scale = 1.0f / init_scale;
         z.bc1 = 1.f; z.bc2 = 1.f;
         z.apply = 1;
+        z.drop_seed = 0x9E3779B97F4A7C15ull * (uint64_t)(step + 1);
+        uint64_t x = z.drop_seed;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        z.drop_seed_mixed = x ^ (x >> 31);
         *sp = z;
     }
 }
@@ -158,6 +163,12 @@ __global__ void step_decide_kernel(morec_step_params* sp, float beta1, float bet
         }
     }
     z.found_inf = 0;
+    {   // the dropout seed word of the NEXT forward / backward pair (splitmix64 step): every decide call draws a new one
+        uint64_t x = (z.drop_seed += 0x9E3779B97F4A7C15ull);
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        z.drop_seed_mixed = x ^ (x >> 31);
+    }
     *sp = z;
 }
 extern "C" int morec_step_decide(morec_step_params* sp, float beta1, float beta2, float growth_factor, float backoff_factor,

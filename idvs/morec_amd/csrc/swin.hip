@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256) void bias_residual_kernel(const T* __restrict_
 }
 
 __global__ void droppath_scale_kernel(float* __restrict__ out, int n, DropRng d) {
+    d = drop_resolve(d);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = drop_keep(d, (uint64_t)i) ? d.inv_keep : 0.f;
 }

@@ -170,7 +170,7 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     both), so the backward's dU = (dZ W2) * act' is a plain multiply in that GEMM's epilogue."""
     dh = cfg.H // cfg.heads
     desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
-                         drop.p_attn, drop.site(site0), cu)
+                         drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
@@ -234,7 +234,7 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     dh = cfg.H // cfg.heads
     H, T = cfg.H, cfg.T
     desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
-                         drop.p_attn, drop.site(site0), cu)
+                         drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
@@ -390,7 +390,7 @@ def token_packing(mask: torch.Tensor):
     return cu, tok_idx
 
 
-def token_packing_host(mask, token_ids=None):
+def token_packing_host(mask, token_ids=None, pad_to: int = 0):
     """The same bookkeeping on the HOST (numpy / CPU tensor ``mask`` int [Nc, T], what the data loader's collate holds before the H2D
     copy, ``T/run.py:232-239``): returns pinned int32 CPU tensors ``(cu_seqlens [Nc + 1], tok_idx [n_tokens])`` or ``None`` when the
     rows are not a run of ones followed by zeros (the padded layout is kept then).  Uploading the two vectors with the batch spares
@@ -399,7 +399,11 @@ def token_packing_host(mask, token_ids=None):
     of the padded layout in token-id order (stable), which the word-embedding gradient's run-length scatter walks -- otherwise a
     device-side ``argsort`` (ten small kernels) at the very end of the backward pass, with nothing left to overlap it -- and a fourth:
     padded row -> packed row (-1 for [PAD] rows), with which the backward spreads the packed gradients over the padded layout in one
-    gather per tensor instead of a fill + scatter."""
+    gather per tensor instead of a fill + scatter.
+    ``pad_to`` > 0: ``tok_idx`` is padded with -1 up to the next multiple of ``pad_to`` (<= ``ops.SPARE_ROWS_MAX``): the packed layout then
+    carries that many SPARE rows behind the last sequence -- zero rows on the way in (``morec_indexed_rows_copy`` writes zeros for a negative
+    index), zero rows in every gradient, skipped by the attention kernels -- so that batches whose token counts fall into the same bucket
+    have identical tensor shapes (``TrainStep.step_graphed`` replays one captured graph for all of them)."""
     import numpy as np
     m = mask.numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
     m = (m != 0)
@@ -414,13 +418,19 @@ def token_packing_host(mask, token_ids=None):
     seq = np.repeat(np.arange(Nc, dtype=np.int64), lens)
     pos = np.arange(n, dtype=np.int64) - np.repeat(cu[:-1].astype(np.int64), lens)
     tok = (seq * T + pos).astype(np.int32)
+    if pad_to and pad_to > 0 and n % pad_to:
+        assert 2 * pad_to <= ops.SPARE_ROWS_MAX, "pad_to exceeds the spare rows the attention launches zero"
+        extra = pad_to - n % pad_to
+        if n + extra == Nc * T:      # (a packed row count of exactly Nc T means "nothing dropped" to bert_forward: stay clear of it)
+            extra += pad_to
+        tok = np.concatenate((tok, np.full(extra, -1, dtype=np.int32)))
     pin = torch.cuda.is_available()
     out = [torch.from_numpy(cu), torch.from_numpy(tok)]
     if token_ids is not None:
         ids = token_ids.numpy() if isinstance(token_ids, torch.Tensor) else np.asarray(token_ids)
         out.append(torch.from_numpy(np.argsort(ids.reshape(-1), kind="stable").astype(np.int32)))
         inv = np.full(Nc * T, -1, dtype=np.int32)      # padded row -> packed row (-1: a [PAD] row), for the way back in the backward pass
-        inv[tok] = np.arange(n, dtype=np.int32)
+        inv[tok[:n]] = np.arange(n, dtype=np.int32)
         out.append(torch.from_numpy(inv))
     return tuple(t.pin_memory() for t in out) if pin else tuple(out)
 

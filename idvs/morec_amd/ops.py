@@ -285,10 +285,18 @@ def pos_grad_(dz, dpos, period):
     check(_lib.lib().morec_pos_grad(_p(dz), _p(dpos), M, N, period, code(dz.dtype), _stream()), "morec_pos_grad")
 
 
-def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0, cu_seqlens=None):
-    """``cu_seqlens``: int32 [n_seq + 1] device tensor for the unpadded token layout (the caller keeps it alive)."""
+# Upper bound of the SPARE rows a packed token layout may carry behind its last sequence (token counts padded up to a multiple of this by
+# ``engine.token_packing_host(pad_to=...)`` so that one captured graph serves every batch of the bucket): the attention launches append
+# ceil(SPARE_ROWS_MAX / 16) blocks that zero those rows of their outputs.
+SPARE_ROWS_MAX = 256
+
+
+def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0, cu_seqlens=None, total_rows=0):
+    """``cu_seqlens``: int32 [n_seq + 1] device tensor for the unpadded token layout (the caller keeps it alive); ``total_rows``: rows of
+    the packed buffers (spare rows behind the last sequence are zero-filled in ctx / dqkv)."""
     return AttnDesc(n_seq, T, n_heads, dh, int(causal), scale, mask_value, code(dtype), p_drop, seed,
-                    None if cu_seqlens is None else cu_seqlens.data_ptr())
+                    None if cu_seqlens is None else cu_seqlens.data_ptr(), int(total_rows) if cu_seqlens is not None else 0,
+                    SPARE_ROWS_MAX if (cu_seqlens is not None and total_rows) else 0)
 
 
 def attn_fwd(desc, qkv, key_keep):
@@ -413,6 +421,9 @@ def adamw_(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, wd, 
                                  beta2, eps, wd, step, grad_scale, _stream()), "morec_adamw")
 
 
+_SEED_SOURCE_OWNER = None      # id() of the StepParams whose seed word the library currently reads (process-wide, like the knob itself)
+
+
 class StepParams:
     """The device-resident step block (``morec_step_params``: step count, bias corrections, loss scale, overflow flag): what the
     reference keeps in ``GradScaler()`` + AdamW's ``step`` (``T/run.py:210,243-247``).  ``init_scale`` 1.0 = no loss scaling."""
@@ -429,6 +440,23 @@ class StepParams:
     def loss_scale_dev(self):
         """fp32 [1] view of the scale the next backward pass multiplies the loss gradient with (no host read)."""
         return self.f32[4:5]
+
+    def use_as_seed_source(self, on: bool = True):
+        """Register (or clear) this block's ``drop_seed_mixed`` word as the library's dropout seed source (``morec_dropout_seed_source``):
+        every ``decide_`` then changes the masks of the following launches, whatever their seed arguments -- what a replayed graph needs."""
+        global _SEED_SOURCE_OWNER
+        if not on and _SEED_SOURCE_OWNER not in (None, id(self)):
+            return                                   # another block is registered: leave it alone
+        ptr = C.c_void_p(self.buf.data_ptr() + _lib.StepParams.drop_seed_mixed.offset) if on else None
+        check(_lib.lib().morec_dropout_seed_source(ptr), "morec_dropout_seed_source")
+        _SEED_SOURCE_OWNER = id(self) if on else None
+
+    def __del__(self):      # the library must not keep a pointer into a block that is going away
+        try:
+            if _SEED_SOURCE_OWNER == id(self):
+                self.use_as_seed_source(False)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def check_finite_(self, grad):
         check(_lib.lib().morec_grad_check_finite(_p(grad), grad.numel(), _p(self.buf), _stream()), "morec_grad_check_finite")

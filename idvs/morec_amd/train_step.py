@@ -132,7 +132,7 @@ class TrainStep:
     def __init__(self, model, *, lr: float, fine_tune_lr: float, l2_weight: float, fine_tune_l2_weight: float,
                  betas=(0.9, 0.999), eps: float = 1e-8, pool_negatives: bool = True, dedup_items: bool = False,
                  force_collectives: bool = False, comm: str | None = None, loss_scale: float | None = None,
-                 dynamic_loss_scale: bool = True, growth_interval: int = 2000, defer_update: bool | None = None):
+                 dynamic_loss_scale: bool = True, growth_interval: int = 2000, defer_update: bool | None = None, graph: bool | None = None):
         """``loss_scale`` / ``dynamic_loss_scale`` / ``growth_interval``: the GradScaler of the reference's fp16 step (``T/run.py:210``:
         defaults 65536, x2 after 2000 clean steps, x0.5 and a skipped step on inf / NaN), kept in a device block (``ops.StepParams``).
         Engaged automatically for ``compute_dtype == "fp16"``; ``loss_scale=`` a number forces it on for the other dtypes too
@@ -143,7 +143,11 @@ class TrainStep:
         encoder GEMMs of the next step instead of behind the overflow verdict at the end of its own (the other dtypes hide it under their
         own backward pass, ``_early_adamw``; a step block rules that out: the verdict covers the whole step).  CONTRACT: between two
         ``step()`` calls the parameters may still be in flight on the side stream -- read them only after ``flush()`` (which
-        ``optimizer_state_dict`` / ``load_state_dict`` / ``applied_steps`` call) or a device synchronisation."""
+        ``optimizer_state_dict`` / ``load_state_dict`` / ``applied_steps`` call) or a device synchronisation.
+        ``graph`` (``MOREC_GRAPH=1``; one rank, no item dedup): ``step_graphed`` captures the whole step -- forward, backward, AdamW, both
+        streams -- into a hipGraph per input shape and replays it (``T/run.py:231-247`` as ONE launch: the ~700 kernel launches of a step
+        and the idle gaps between them go away).  Needs the step block (created with scale 1 for the non-fp16 dtypes: step count, bias
+        corrections and the dropout seed word then live on the device, so no per-step host scalar is frozen into the graph)."""
         self.model = model
         # SURVEY.md §8(f)-2: encode every DISTINCT item of the batch once (the reference re-encodes duplicates: Zipf-popular
         # items fill many of the B (S + 1) slots) and gather the vectors back to the slots; the slot gradients are
@@ -224,14 +228,26 @@ class TrainStep:
         # loss scaling (their range ends at 6e-8); the other dtypes run it on request only.
         self.sp = None
         self._param_ready = {}      # deferred update: key -> event recorded behind that slice's AdamW on the side stream
-        if self.dtype == torch.float16 or loss_scale is not None or os.environ.get("MOREC_STEP_PARAMS", "0") == "1":
+        if graph is None:
+            graph = os.environ.get("MOREC_GRAPH", "0") == "1"
+        self.graph = bool(graph) and self.device.type == "cuda" and not self.collectives and not self.dedup_items
+        if self.dtype == torch.float16 or loss_scale is not None or self.graph or os.environ.get("MOREC_STEP_PARAMS", "0") == "1":
             init = float(loss_scale) if loss_scale is not None else (65536.0 if self.dtype == torch.float16 else 1.0)
             self.sp = ops.StepParams(self.device, init_scale=init, step=0, growth_interval=growth_interval,
                                      dynamic=bool(dynamic_loss_scale) and (self.dtype == torch.float16 or loss_scale is not None))
+        # A step block WITHOUT loss scaling (bf16 / fp32 under graph capture): nothing can veto the update, so the decision (step count,
+        # bias corrections, next dropout seed word) is taken at the START of the step and AdamW may run bucket by bucket under the
+        # backward pass as it does without a block.  With scaling the decision needs the whole step's gradients and comes last.
+        self._decide_first = self.sp is not None and not self.sp.dynamic and init == 1.0
+        self._decided = False
+        self._graphs, self._graph_pool = {}, None
+        if self.graph:
+            self.sp.use_as_seed_source(True)
         self.buckets = self._bucket_plan()
         if defer_update is None:
             defer_update = os.environ.get("MOREC_DEFER_UPDATE", "0") == "1"
-        self.defer_update = bool(defer_update) and self.sp is not None and model.use_modal and not self.vision and self.device.type == "cuda"
+        self.defer_update = (bool(defer_update) and self.sp is not None and not self._decide_first and model.use_modal and not self.vision
+                             and self.device.type == "cuda")
         self._pending, self._reduced, self._stepped = [], [], []
         self._fused_update = False
         self._in_step = False
@@ -373,6 +389,7 @@ class TrainStep:
         ``reduce_gradients`` must follow to reduce the rest and join them before the arenas are read."""
         m, p, g = self.model, self.p, self.g
         D, S = m.args.embedding_dim, m.max_seq_len
+        self._begin_step()
         # Nothing in the FORWARD pass reads the gradient arenas or the W^T copies (dX = dY W): zero / refresh them on the side stream,
         # under the forward GEMMs (HBM-bound fills next to MFMA-bound kernels), and let the main stream wait for them right before
         # the backward pass starts.
@@ -456,6 +473,12 @@ class TrainStep:
         ops.x3_cache_clear()
         return loss_sum[0] / n_valid
 
+    def _begin_step(self):
+        """Static step block: step count + 1, bias corrections and the dropout seed word of THIS step, once per step (a no-op otherwise)."""
+        if self._decide_first and not self._decided:
+            self.sp.decide_(self.betas[0], self.betas[1])
+            self._decided = True
+
     def _gscale(self, n_valid):
         """Device scalar the loss gradient starts from: 1 / n_valid, times the loss scale of the step block when there is one."""
         if self.sp is None:
@@ -528,7 +551,7 @@ class TrainStep:
         bucket's weight-gradient GEMMs, UNDER the rest of the backward pass (28 B / parameter of HBM traffic next to MFMA-bound
         GEMMs) instead of after it.  Safe: nothing later in this step reads these weights again -- the backward walks the layers
         downwards -- and the bf16 shadow / W^T copies are only read by the next step."""
-        if not self._fused_update or self.sp is not None:      # with a step block the update waits for the overflow verdict of the WHOLE step
+        if not self._fused_update or (self.sp is not None and not self._decide_first):      # with loss scaling the update waits for the overflow verdict of the WHOLE step
             return
         side = engine.WgradStream.get(self.device)
         if side is None:
@@ -549,8 +572,13 @@ class TrainStep:
     def _adamw_slice(self, gi, lo, hi, step):
         grp = self.groups[gi]
         a = grp["arena"]
-        ops.adamw_(a.data[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], None if a.shadow is None else a.shadow[lo:hi],
-                   grp["lr"], self.betas[0], self.betas[1], self.eps, grp["wd"], step)
+        sh = None if a.shadow is None else a.shadow[lo:hi]
+        if self.sp is not None:      # step count / bias corrections from the device block (decided at the start of this step)
+            ops.adamw_sp_(a.data[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], sh, grp["lr"], self.betas[0], self.betas[1], self.eps,
+                          grp["wd"], self.sp)
+            return
+        ops.adamw_(a.data[lo:hi], a.grad[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], sh, grp["lr"], self.betas[0], self.betas[1], self.eps,
+                   grp["wd"], step)
 
     def _issue_ready(self, key):
         if key == "head":      # the recommender group (SASRec, fc, id table) is complete once the tower's backward is under way
@@ -734,7 +762,10 @@ class TrainStep:
         With a step block (fp16 mode): GradScaler.step + update on the device -- overflow check of every gradient arena, the decision,
         then the update (or nothing); ``step_count`` then counts the calls, ``applied_steps()`` the updates that happened."""
         self.step_count += 1
-        if self.sp is not None:
+        if self._decide_first:
+            self._begin_step()      # (a direct call without forward_backward: the block still has to move on)
+            self._decided = False
+        elif self.sp is not None:
             self.flush()      # (a deferred update of the previous step that nothing has waited for yet)
             for grp in self.groups:
                 self.sp.check_finite_(grp["arena"].grad)
@@ -767,6 +798,67 @@ class TrainStep:
                 pos = hi
         self._stepped = []
 
+    def _step_body(self, sample_items_id, sample_items, log_mask, token_packing, defer: bool):
+        self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
+        try:
+            loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
+        finally:
+            self._fused_update = False
+        self.reduce_gradients()
+        self._in_step = defer
+        try:
+            self.optimizer_step()
+        finally:
+            self._in_step = False
+        return loss
+
+    def _throttle(self):
+        """Two steps in flight keep the device queue full; the host waits for the step before the previous one (see ``step``)."""
+        ev = torch.cuda.Event()
+        self._inflight.append(ev)
+        if len(self._inflight) > 2:
+            self._inflight.pop(0).synchronize()
+        return ev
+
+    def step_graphed(self, sample_items_id, sample_items, log_mask, token_packing=None):
+        """``step`` as ONE graph launch per input shape (``TrainStep(graph=True)``; otherwise plain ``step``).  The first step of a shape
+        runs eagerly (allocator warm-up, first-call set-up of the kernels), the second is captured -- forward, backward, gradient
+        zeroing, W^T refresh, AdamW, on both streams -- and from then on a step is: copy the batch into the graph's static input
+        buffers, ``replay()``.  Per-step state the kernels need (step count, AdamW bias corrections, loss scale, dropout seed word) is
+        read from the device block, so nothing of it is frozen into the graph.  Text tower: pass ``token_packing`` (host-prepared index
+        vectors) or run the padded layout -- the device-side packing synchronises with the host and cannot be captured."""
+        tp = token_packing
+        if (not self.graph or (self.model.use_modal and not self.vision and tp is None and engine.UNPAD_DEFAULT)):
+            return self.step(sample_items_id, sample_items, log_mask, token_packing)
+        ins = [sample_items_id, sample_items, log_mask] + (list(tp) if tp is not None else [])
+        key = tuple((tuple(t.shape), t.dtype) for t in ins)
+        ent = self._graphs.get(key)
+        if ent is None:            # first sight of this shape: eager
+            self._graphs[key] = "seen"
+            return self.step(sample_items_id, sample_items, log_mask, token_packing)
+        if ent == "seen":
+            self.flush()
+            static = [torch.empty_like(t) for t in ins]
+            for d_, s_ in zip(static, ins):
+                d_.copy_(s_)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(self.device)
+            # thread_local: only THIS thread's calls are policed during capture (a collate thread may be page-locking the next batch)
+            with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+                loss = self._step_body(static[0], static[1], static[2], tuple(static[3:]) if tp is not None else None, defer=False)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            self.step_count -= 1           # (the capture pass counted a step that has not run)
+            ent = self._graphs[key] = (g, static, loss)
+        g, static, loss = ent
+        for d_, s_ in zip(static, ins):
+            d_.copy_(s_, non_blocking=True)
+        ev = self._throttle()
+        g.replay()
+        self.step_count += 1
+        ev.record(torch.cuda.current_stream(self.device))
+        return loss.clone()
+
     def step(self, sample_items_id, sample_items, log_mask, token_packing=None):
         """The whole optimisation step of ``T/run.py:241-247`` (no GradScaler: bf16 needs no loss scaling).  Returns the loss
         of this rank's rows (device scalar); under pooled negatives that is a SHARE of the global loss -- ``global_loss``.
@@ -775,22 +867,8 @@ class TrainStep:
         # No synchronisation happens inside a step, so the host could issue steps far ahead of the device; every step in flight holds its
         # host batch, its events and (until its kernels are queued) its share of the allocator's attention.  Two steps in flight keep the
         # device queue full; the host waits for the step before the previous one.
-        if self.device.type == "cuda":
-            ev = torch.cuda.Event()
-            self._inflight.append(ev)
-            if len(self._inflight) > 2:
-                self._inflight.pop(0).synchronize()
-        self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
-        try:
-            loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
-        finally:
-            self._fused_update = False
-        self.reduce_gradients()
-        self._in_step = True
-        try:
-            self.optimizer_step()
-        finally:
-            self._in_step = False
-        if self.device.type == "cuda":
-            self._inflight[-1].record(torch.cuda.current_stream(self.device))
+        ev = self._throttle() if self.device.type == "cuda" else None
+        loss = self._step_body(sample_items_id, sample_items, log_mask, token_packing, defer=True)
+        if ev is not None:
+            ev.record(torch.cuda.current_stream(self.device))
         return loss

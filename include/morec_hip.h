@@ -32,7 +32,8 @@
  *      last-bit rounding pattern of bf16 outputs), which is why it is off unless asked for.  Set knobs before the first
  *      launch or between steps, not concurrently with launches;
  *   2. with "gemm8p_tail_split" = 1 only: one device scratch allocation per stream (the only memory the library ever allocates);
- *   3. morec_comm handles (below): created and destroyed by the caller.
+ *   3. morec_comm handles (below): created and destroyed by the caller;
+ *   4. the dropout seed source (morec_dropout_seed_source): one device pointer, NULL by default.
  */
 #ifndef MOREC_HIP_H
 #define MOREC_HIP_H
@@ -195,6 +196,11 @@ typedef struct {
     const int32_t* cu_seqlens;   /* NULL: every sequence owns T rows.  Otherwise int32[n_seq + 1] (device): sequence s owns rows
                                     cu_seqlens[s] .. cu_seqlens[s+1]-1 (<= T of them) -- the unpadded ("varlen") token layout in
                                     which [PAD] positions are not materialised at all; key_keep is then indexed by packed row */
+    int total_rows;              /* with cu_seqlens: rows of qkv / ctx / dqkv (>= cu_seqlens[n_seq]), or 0.  The packed buffers may carry SPARE
+                                    rows behind the last sequence (a token count padded up to a bucket size, so that one captured graph
+                                    serves every batch of the bucket); */
+    int spare_rows_max;          /* ... upper bound of their number: the launch appends ceil(spare_rows_max / 16) blocks that write zeros into
+                                    the rows cu_seqlens[n_seq] .. total_rows-1 of ctx (forward) / dqkv (backward).  0 = no spare rows. */
 } morec_attn_desc;
 
 int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx, void* stream);
@@ -362,8 +368,18 @@ typedef struct {
     float inv_scale;        /* 1 / S of the step being applied: what morec_adamw_sp multiplies the gradients with */
     float bc1, bc2;         /* 1 - beta1^step, 1 - beta2^step of the step being applied */
     int32_t apply;          /* decision of the last morec_step_decide: 1 = update, 0 = skip */
-    int32_t reserved[7];
+    int32_t pad0;
+    uint64_t drop_seed;       /* splitmix64 state, advanced by every morec_step_decide */
+    uint64_t drop_seed_mixed; /* its output: the word morec_dropout_seed_source(&sp->drop_seed_mixed) feeds to the dropout kernels */
+    int32_t reserved[2];
 } morec_step_params;
+/* Process-wide dropout seed source (state item 4 of the list at the top of this file): dev_u64 = a DEVICE uint64 (8-byte aligned) that every
+ * dropout / DropPath kernel XORs into the two halves of its seed argument at kernel entry, NULL = none (the default).  The mask of a launch
+ * is then a function of (seed argument, *dev_u64): a captured graph of the step -- whose seed arguments are frozen at capture -- draws
+ * fresh masks at every replay when the word changes between replays (morec_step_decide advances sp->drop_seed_mixed).  The word must not
+ * change between the forward and the backward launch that regenerate the same mask.  Stands where torch's global CUDA RNG state stands in
+ * the reference (nn.Dropout under T/run.py:307-314 `setup_seed`). */
+int morec_dropout_seed_source(const void* dev_u64);
 /* *sp = {step, loss_scale = init_scale, everything else clear} (init_scale = 1: no scaling, bf16 / fp32 modes) */
 int morec_step_params_init(morec_step_params* sp, float init_scale, int step, void* stream);
 /* sp->found_inf |= any element of grad[0 .. n) is inf or NaN   (GradScaler.unscale_'s found_inf; the division by S is left to AdamW) */

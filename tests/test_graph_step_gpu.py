@@ -1,0 +1,201 @@
+"""-m gpu: ``TrainStep.step_graphed`` -- the optimisation step of ``T/run.py:231-247`` captured ONCE per input shape into a hipGraph
+(forward, backward, gradient zeroing, W^T refresh, AdamW, both streams) and replayed.  What makes it replayable: the per-step state the
+kernels need (step count, AdamW bias corrections, loss scale, dropout seed word) lives in the device block ``morec_step_params``, and
+the unpadded text layout is padded up to a bucket of spare rows that every kernel treats as exact zeros.  Checked here:
+
+* replay == eager: the graphed trajectory of the ID tower (bf16), the padded and the bucketed-unpadded text tower (fp16, loss scaling and
+  the overflow protocol inside the graph) and the Swin tower against plain ``step`` on the same batches -- equal up to the run-to-run
+  noise of the step (fp32 atomics), orders of magnitude below one optimizer step;
+* the dropout masks change from replay to replay although the seed ARGUMENTS are frozen in the graph (``morec_dropout_seed_source``);
+* spare rows: attention forward / backward write exact zeros there and leave every owned row bit-identical."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _pop(ids_all, item_num):
+    counts = np.bincount(ids_all.reshape(-1), minlength=item_num + 1).astype(np.float64) + 1.0
+    pop = counts / counts[1:].sum()
+    pop[0] = 1.0
+    return pop
+
+
+def _text_model(dtype, bert, D, S, T, item_num, pop, drop=0.0, seed=7):
+    from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    shape = BertShape.named(bert)
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=drop, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_" + bert, word_embedding_dim=shape.hidden_size, compute_dtype=dtype)
+    torch.manual_seed(seed)
+    return Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop), pop).to(DEV).train()
+
+
+def _dist(a, b):
+    dl = max(abs(x - y) for x, y in zip(a[0], b[0]))
+    dp = max(float((x.double() - y.double()).norm() / y.double().norm()) for x, y in zip(a[1], b[1]))
+    return dl, dp
+
+
+def test_id_tower_replay_equals_eager_and_draws_new_masks():
+    import bench
+    from idvs.morec_amd.model import Model
+    from idvs.morec_amd.train_step import TrainStep
+    B, S, D, item_num, steps = 64, 20, 128, 3000, 8
+    ids_all = bench.synth_batches(steps, B, S, item_num, np.random.default_rng(3))
+    pop = _pop(ids_all, item_num)
+    res = {}
+    for mode in ("eager", "eager2", "graph"):
+        args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2, compute_dtype="bf16")
+        torch.manual_seed(11)
+        m = Model(args, item_num, False, None, pop).to(DEV).train()
+        ts = TrainStep(m, lr=3e-3, fine_tune_lr=3e-3, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, graph=(mode == "graph"))
+        assert ts.graph == (mode == "graph") and (ts.sp is not None) == (mode == "graph")
+        losses = []
+        for i in range(steps):
+            ids = torch.from_numpy(ids_all[i]).to(DEV)
+            losses.append(float(ts.step_graphed(ids.view(-1), ids.view(-1).clone(), torch.ones(B, S, device=DEV))))
+        if mode == "graph":
+            caps = [v for v in ts._graphs.values() if v != "seen"]
+            assert len(caps) == 1 and ts.applied_steps() == steps and ts.step_count == steps
+        torch.cuda.synchronize()
+        res[mode] = (losses, [g["arena"].data.clone() for g in ts.groups])
+        if mode == "graph":
+            ts.sp.use_as_seed_source(False)
+    noise = _dist(res["eager"], res["eager2"])
+    d = _dist(res["graph"], res["eager"])
+    print(f"ID tower, graph vs eager over {steps} steps: max |d loss| {d[0]:.2e} (eager run-to-run {noise[0]:.2e}), parameter distance {d[1]:.2e} ({noise[1]:.2e})")
+    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
+    assert res["graph"][0][-1] < res["graph"][0][0] - 0.2
+    # dropout on, learning rates 0: the same batch replayed three times must see three different masks (the seed word moves on the device)
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.3, transformer_block=2, compute_dtype="bf16")
+    torch.manual_seed(11)
+    m = Model(args, item_num, False, None, pop).to(DEV).train()
+    ts = TrainStep(m, lr=0.0, fine_tune_lr=0.0, l2_weight=0.0, fine_tune_l2_weight=0.0, pool_negatives=False, graph=True)
+    ids = torch.from_numpy(ids_all[0]).to(DEV)
+    ls = [float(ts.step_graphed(ids.view(-1), ids.view(-1).clone(), torch.ones(B, S, device=DEV))) for _ in range(6)]
+    ts.sp.use_as_seed_source(False)
+    print("same batch, lr 0, dropout 0.3, losses:", ["%.5f" % x for x in ls])
+    assert len({round(x, 5) for x in ls[2:]}) == 4, ls          # (steps 0 / 1 are the eager and the capture pass)
+    assert max(ls) - min(ls) < 0.5
+
+
+@pytest.mark.parametrize("layout", ["padded", "bucketed"])
+def test_text_tower_fp16_replay_equals_eager(layout):
+    """fp16: loss scaling, the overflow check, the skip decision and AdamW are all INSIDE the graph.  ``bucketed``: unpadded token layout
+    whose row count is padded to a multiple of 128 spare rows -- batches with different token counts share one graph."""
+    import bench
+    from idvs.morec_amd import engine
+    from idvs.morec_amd.train_step import TrainStep
+    B, S, T, D, item_num, steps = 24, 20, 30, 128, 3000, 8
+    content = bench.synth_catalog(item_num, T, np.random.default_rng(1))
+    ids_all = bench.synth_batches(steps, B, S, item_num, np.random.default_rng(2))
+    pop = _pop(ids_all, item_num)
+    saved = engine.UNPAD_DEFAULT
+    res, n_graphs, n_tok = {}, 0, set()
+    try:
+        engine.UNPAD_DEFAULT = layout != "padded"
+        for mode in ("eager", "eager2", "graph"):
+            m = _text_model("fp16", "tiny", D, S, T, item_num, pop)
+            ts = TrainStep(m, lr=3e-3, fine_tune_lr=3e-3, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, loss_scale=1024.0,
+                           graph=(mode == "graph"))
+            losses = []
+            for i in range(steps):
+                ids = torch.from_numpy(ids_all[i]).to(DEV)
+                rows = content[ids_all[i].reshape(-1)]
+                items = torch.from_numpy(rows).to(DEV)
+                pack = None
+                if layout == "bucketed":
+                    hp = engine.token_packing_host(rows[:, T:], rows[:, :T], pad_to=128 if mode == "graph" else 0)
+                    n_tok.add(int(hp[0][-1]))
+                    pack = tuple(t.to(DEV) for t in hp)
+                fn = ts.step_graphed if mode == "graph" else ts.step
+                losses.append(float(fn(ids.view(-1), items, torch.ones(B, S, device=DEV), token_packing=pack)))
+            if mode == "graph":
+                n_graphs = len([v for v in ts._graphs.values() if v != "seen"])
+                h = ts.sp.host()
+                assert h.step == steps and h.skipped == 0
+            torch.cuda.synchronize()
+            res[mode] = (losses, [g["arena"].data.clone() for g in ts.groups])
+            if mode == "graph":
+                ts.sp.use_as_seed_source(False)
+    finally:
+        engine.UNPAD_DEFAULT = saved
+    noise = _dist(res["eager"], res["eager2"])
+    d = _dist(res["graph"], res["eager"])
+    print(f"text fp16 {layout}: graph vs eager over {steps} steps: max |d loss| {d[0]:.2e} (eager run-to-run {noise[0]:.2e}), parameter distance "
+          f"{d[1]:.2e} ({noise[1]:.2e}); {n_graphs} graph(s) for {len(n_tok)} distinct token counts")
+    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
+    assert res["graph"][0][-1] < res["graph"][0][0] - 0.2
+    assert 1 <= n_graphs <= 4
+    if layout == "bucketed":
+        assert len(n_tok) > n_graphs          # several token counts per captured graph: the point of the buckets
+
+
+def test_spare_rows_are_exact_zeros_and_owned_rows_unchanged():
+    from idvs.morec_amd import ops
+    n_seq, T, heads, dh = 37, 30, 4, 64
+    H = heads * dh
+    g = torch.Generator(device="cpu").manual_seed(5)
+    lens = torch.randint(1, T + 1, (n_seq,), generator=g)
+    cu = torch.zeros(n_seq + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    n = int(cu[-1])
+    total = (n + 127) // 128 * 128 + 128
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        qkv = torch.randn(total, 3 * H, generator=g).to(DEV).to(dt)
+        dctx = torch.randn(total, H, generator=g).to(DEV).to(dt)
+        keep = torch.ones(total, device=DEV)
+        cud = cu.to(DEV)
+        outs = []
+        for rows in (n, total):
+            desc = ops.attn_desc(n_seq, T, heads, dh, False, dh ** -0.5, ops.FLT_MIN_MASK, dt, 0.0, 0, cud, total_rows=rows)
+            ctx = ops.attn_fwd(desc, qkv[:rows].contiguous(), keep[:rows])
+            dq = ops.attn_bwd(desc, qkv[:rows].contiguous(), keep[:rows], dctx[:rows].contiguous())
+            outs.append((ctx, dq))
+        (c0, d0), (c1, d1) = outs
+        assert torch.equal(c1[:n], c0) and torch.equal(d1[:n], d0)
+        assert float(c1[n:].abs().max()) == 0.0 and float(d1[n:].abs().max()) == 0.0
+
+
+def test_vision_micro_replay_equals_eager():
+    from idvs.morec_amd.model import Model
+    from idvs.morec_amd.model.swin import HipSwinForImageClassification
+    from idvs.morec_amd.swin_engine import SwinShape
+    from idvs.morec_amd.train_step import TrainStep
+    import bench
+    B, S, D, item_num, steps = 4, 6, 64, 60, 6
+    vshape = SwinShape.named("swin_micro")
+    ids_all = bench.synth_batches(steps, B, S, item_num, np.random.default_rng(9))
+    pop = _pop(ids_all, item_num)
+    gen = torch.Generator(device=DEV).manual_seed(4321)
+    catalog = torch.randn((item_num + 1, 3, vshape.image_size, vshape.image_size), device=DEV, generator=gen)
+    res = {}
+    for mode in ("eager", "eager2", "graph"):
+        args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                     CV_model_load="swin_micro", compute_dtype="bf16")
+        torch.manual_seed(5)
+        m = Model(args, item_num, True, HipSwinForImageClassification(vshape, D), pop).to(DEV).eval()      # eval: DropPath off (a deterministic comparison)
+        ts = TrainStep(m, lr=1e-3, fine_tune_lr=1e-3, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, graph=(mode == "graph"))
+        losses = []
+        for i in range(steps):
+            ids = torch.from_numpy(ids_all[i]).to(DEV)
+            losses.append(float(ts.step_graphed(ids.view(-1), catalog[ids.view(-1)], torch.ones(B, S, device=DEV))))
+        torch.cuda.synchronize()
+        res[mode] = (losses, [g["arena"].data.clone() for g in ts.groups])
+        if mode == "graph":
+            assert len([v for v in ts._graphs.values() if v != "seen"]) == 1
+            ts.sp.use_as_seed_source(False)
+    noise = _dist(res["eager"], res["eager2"])
+    d = _dist(res["graph"], res["eager"])
+    print(f"Swin micro, graph vs eager: max |d loss| {d[0]:.2e} (noise {noise[0]:.2e}), parameter distance {d[1]:.2e} ({noise[1]:.2e})")
+    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
