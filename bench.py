@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--no-graph", action="store_true", help="one rank: launch every kernel of the step from the host instead of replaying the "
+                    "step's captured hipGraph (TrainStep.step_graphed; one graph per input shape, the unpadded token layout padded to buckets of 512 rows)")
     ap.add_argument("--sweep", action="store_true", help="N > 1: after the headline region, time the data-parallel knobs -- collectives through "
                     "torch.distributed vs the library's own RCCL communicators, 0 / 8 / 16 CUs reserved for the ring kernel, reduction overlapped "
                     "with the backward or after it -- and print each configuration's bucket trace under `sweep` (schema: INTEGRATION.md)")
@@ -206,7 +208,10 @@ def main():
     # defer_update: with a step block (fp16) the AdamW launches of step t run under the forward pass of step t + 1 (TrainStep docstring);
     # the timed region ends with a device synchronisation, so every update it issued is inside it
     ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool,
-                   dedup_items=a.dedup, defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0")
+                   dedup_items=a.dedup, defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0",
+                   graph=(world == 1 and not a.no_graph and not a.dedup))
+    PAD_TO = 512 if ts.graph else 0        # spare-row bucket of the unpadded token layout (one captured graph per bucket)
+    use_graph = {"v": bool(ts.graph)}
 
     # host batches in pinned memory: what the reference's DataLoader hands to T/run.py:232-234
     host = []
@@ -218,7 +223,8 @@ def main():
         # the collate's share of the unpadded token layout: row offsets / packed-row indices from the attention masks (+ the rows in
         # token-id order for the word-embedding gradient), on the host,
         # uploaded with the batch (no device-side bookkeeping, no host synchronisation inside the step)
-        pack = None if (vision or id_tower or a.padded) else _engine.token_packing_host(content[ids_all[i].reshape(-1), T:], content[ids_all[i].reshape(-1), :T])
+        pack = None if (vision or id_tower or a.padded) else _engine.token_packing_host(content[ids_all[i].reshape(-1), T:], content[ids_all[i].reshape(-1), :T],
+                                                                                        pad_to=PAD_TO)
         host.append((ids, items, lm, pack))
     # Warm-up batch 0 = a copy of the TIMED batch with the most real tokens (the timed set itself is untouched): activation buffers
     # are sized by the batch's token count and the caching allocator cannot reuse a smaller block for a larger request, so the first
@@ -330,6 +336,8 @@ def main():
             items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
         lm_d = lm.to(dev, non_blocking=True)
         pack_d = None if pack is None else tuple(t.to(dev, non_blocking=True) for t in pack)
+        if use_graph["v"]:
+            return ts.step_graphed(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
         return ts.step(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
 
     def start_feed(order):
@@ -342,6 +350,16 @@ def main():
         feeder = BatchPrefetcher(lambda i: make_u8(i), list(order), depth=2)
         u8_feed = {"feeder": feeder, "it": iter(feeder), "order": list(order), "pos": 0}
 
+    # graph mode: every input shape of the timed batches is seen twice before the clock starts (first sight runs eagerly, the second
+    # is the capture) -- the per-shape analogue of priming the allocator with the largest batch
+    if use_graph["v"] and u8_stats is None:
+        shapes = {}
+        for i in range(a.warmup, n_batches):
+            shapes.setdefault(None if host[i][3] is None else int(host[i][3][1].numel()), i)
+        log(f"graph mode: {len(shapes)} input shape(s) among the timed batches; capturing")
+        for i in shapes.values():
+            run_step(i)
+            run_step(i)
     start_feed(list(range(a.warmup)) + list(range(a.warmup, n_batches)))
     log("warm-up")
     for i in range(a.warmup):
@@ -479,6 +497,7 @@ def main():
     # durations of both stretch over each other (they would add up to more than the step).  The pass therefore measures each GEMM
     # launch with the chip to itself, i.e. the kernels' own rate; the headline region above runs with the overlap.
     n_inst = min(a.steps, 8)
+    graph_was, use_graph["v"] = use_graph["v"], False      # the per-launch events need the launches: every pass from here on is eager
     wgrad_was = _engine.WgradStream.enabled
     _engine.WgradStream.enabled = False
     run_step(a.warmup)
@@ -493,6 +512,7 @@ def main():
     # the K-step headline region is < 1 s)
     sustained = None
     if not a.no_secondary and world == 1:
+        use_graph["v"] = graph_was
         n_sus, t1 = 0, time.perf_counter()
         while True:
             for i in range(a.warmup, n_batches):
@@ -505,6 +525,7 @@ def main():
         sustained = {"ms_per_step": round(dts / n_sus * 1e3, 3), "user_seq_per_s": round(a.batch * n_sus / dts, 2), "steps": n_sus,
                      "seconds": round(dts, 2), "note": "the K batches of the headline region cycled back to back for >= 3 s"}
         log(f"sustained: {sustained['ms_per_step']} ms/step over {n_sus} steps")
+    use_graph["v"] = False
     # secondary measurement (never `value`): the same steps with distinct-item dedup on, and the duplicate rate of the batches
     def timed_again():
         for i in range(min(2, a.warmup)):
@@ -710,6 +731,9 @@ def main():
         out["metric"] = "user-sequences/sec end-to-end train step, IDRec SASRec (embedding table)"
         out["config"]["workload"] = (f"SASRec(2 blocks, 2 heads, D=512) + ID embedding table ({a.item_num} items, dense AdamW over the table), "
                                      f"in-batch debiased CE, B={a.batch}/GPU, S=20")
+    out["config"]["launch"] = (f"hipGraph replay: one captured graph per input shape ({len([v for v in ts._graphs.values() if v != 'seen'])} captured"
+                               + (f", unpadded token rows padded to multiples of {PAD_TO}" if PAD_TO and not vision and not id_tower and not a.padded else "") + ")"
+                               if graph_was else "host launches (eager)")
     if not vision and not id_tower:
         out["config"]["token_layout"] = "padded (all T positions)" if (a.padded or not _engine.UNPAD_DEFAULT) else "unpadded (real tokens only; exact)"
     if padded_info is not None:

@@ -288,7 +288,7 @@ def pos_grad_(dz, dpos, period):
 # Upper bound of the SPARE rows a packed token layout may carry behind its last sequence (token counts padded up to a multiple of this by
 # ``engine.token_packing_host(pad_to=...)`` so that one captured graph serves every batch of the bucket): the attention launches append
 # ceil(SPARE_ROWS_MAX / 16) blocks that zero those rows of their outputs.
-SPARE_ROWS_MAX = 256
+SPARE_ROWS_MAX = 1024
 
 
 def attn_desc(n_seq, T, n_heads, dh, causal, scale, mask_value, dtype, p_drop=0.0, seed=0, cu_seqlens=None, total_rows=0):

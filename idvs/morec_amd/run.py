@@ -306,7 +306,8 @@ def train(args, use_modal, local_rank):
     if args.fused_step:
         stepper = TrainStep(model, lr=args.lr, fine_tune_lr=args.fine_tune_lr, l2_weight=args.l2_weight,
                             fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives,
-                            defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0")      # (the epoch ends with a device synchronisation before eval / save)
+                            defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0",      # (the epoch ends with a device synchronisation before eval / save)
+                            graph=(world == 1 and not getattr(args, "no_graph", False)))
         if ckpt is not None and ckpt.get("optimizer") is not None:     # T/run.py:193-195
             stepper.load_optimizer_state_dict(ckpt["optimizer"])
         wrapped = model
@@ -344,7 +345,7 @@ def train(args, use_modal, local_rank):
             pack = None
             if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
                 rows = items.view(-1, items.size(-1))
-                pack = engine.token_packing_host(rows[:, T:], rows[:, :T])
+                pack = engine.token_packing_host(rows[:, T:], rows[:, :T], pad_to=512 if (stepper is not None and stepper.graph) else 0)
             return ids, items, log_mask, pack
 
         on_device = hasattr(item_content, "device_batch")       # LMDB catalogue: the collate itself issues device work (decode -> H2D -> resize)
@@ -384,7 +385,7 @@ def train(args, use_modal, local_rank):
             else:
                 items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
             if args.fused_step:
-                loss = stepper.global_loss(stepper.step(ids.view(-1), items, log_mask, token_packing=pack))    # pooled negatives: a rank's step returns its SHARE
+                loss = stepper.global_loss(stepper.step_graphed(ids.view(-1), items, log_mask, token_packing=pack))    # pooled negatives: a rank's step returns its SHARE; one rank: hipGraph replay per input shape
             else:
                 optimizer.zero_grad()
                 loss = wrapped(ids.view(-1), items, log_mask, local_rank)

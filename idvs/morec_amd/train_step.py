@@ -828,7 +828,7 @@ class TrainStep:
         read from the device block, so nothing of it is frozen into the graph.  Text tower: pass ``token_packing`` (host-prepared index
         vectors) or run the padded layout -- the device-side packing synchronises with the host and cannot be captured."""
         tp = token_packing
-        if (not self.graph or (self.model.use_modal and not self.vision and tp is None and engine.UNPAD_DEFAULT)):
+        if (not self.graph or self.dedup_items or (self.model.use_modal and not self.vision and tp is None and engine.UNPAD_DEFAULT)):
             return self.step(sample_items_id, sample_items, log_mask, token_packing)
         ins = [sample_items_id, sample_items, log_mask] + (list(tp) if tp is not None else [])
         key = tuple((tuple(t.shape), t.dtype) for t in ins)

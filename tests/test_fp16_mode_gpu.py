@@ -190,7 +190,8 @@ def test_deferred_update_equals_the_inline_one():
     """``TrainStep(defer_update=True)``: the AdamW launches of step t run on the side stream under the forward pass of step t + 1, every
     layer of which waits for its own slice.  Same arithmetic per element, so the two trajectories may differ only by the run-to-run noise
     of the step itself (fp32 atomics in the LayerNorm / embedding / bias gradient sums: measured by running the inline form twice), while a
-    forward pass that read a slice BEFORE its update would be off by a whole optimizer step (lr 3e-3: orders of magnitude above that)."""
+    forward pass that read a slice BEFORE its update would be off by a whole optimizer step (the loss moves ~0.2 per step here: orders of
+    magnitude above that)."""
     import bench
     from idvs.morec_amd.model import BertShape, HipBertModel, Model
     from idvs.morec_amd.train_step import TrainStep
@@ -208,7 +209,7 @@ def test_deferred_update_equals_the_inline_one():
     for defer in (False, "again", True):
         torch.manual_seed(7)
         m = Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), pop).to(DEV).train()
-        ts = TrainStep(m, lr=3e-3, fine_tune_lr=3e-3, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, loss_scale=1024.0,
+        ts = TrainStep(m, lr=1e-3, fine_tune_lr=1e-4, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=False, loss_scale=1024.0,
                        defer_update=(defer is True))
         assert ts.defer_update == (defer is True)
         losses = []
@@ -236,7 +237,7 @@ def test_deferred_update_equals_the_inline_one():
           f"relative parameter distance {dp:.2e} (noise {noise_p:.2e}); loss {res[True][0][0]:.4f} -> {res[True][0][-1]:.4f}")
     assert res[False][0][0] == res[True][0][0]                 # step 0 sees the same parameters: identical
     assert dl <= 10 * noise_l + 2e-4 and dp <= 10 * noise_p + 1e-5
-    assert res[True][0][-1] < res[True][0][0] - 0.3            # eight steps at lr 3e-3 move the loss by far more than either bound
+    assert res[True][0][-1] < res[True][0][0] - 0.5            # eight steps move the loss by far more than either bound
 
 
 @pytest.mark.parametrize("mode", ["fp16", "bf16", "fp32x3"])
