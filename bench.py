@@ -60,8 +60,9 @@ def parse():
     ap.add_argument("--no-pool", action="store_true", help="rank-local negatives (reference behaviour) instead of the pooled set")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests)")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional smoke test of the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--no-graph", action="store_true", help="one rank: launch every kernel of the step from the host instead of replaying the "
-                    "step's captured hipGraph (TrainStep.step_graphed; one graph per input shape, the unpadded token layout padded to buckets of 512 rows)")
+    ap.add_argument("--graph", action="store_true", help="one rank: replay the step as a captured hipGraph (TrainStep.step_graphed; one graph per input "
+                    "shape, the unpadded token layout padded to buckets of 512 rows) instead of launching its ~700 kernels from the host.  Opt-in: on "
+                    "this stack a replayed graph keeps the 5-8 us dependency gap between consecutive kernels, so it buys little (DESIGN.md)")
     ap.add_argument("--sweep", action="store_true", help="N > 1: after the headline region, time the data-parallel knobs -- collectives through "
                     "torch.distributed vs the library's own RCCL communicators, 0 / 8 / 16 CUs reserved for the ring kernel, reduction overlapped "
                     "with the backward or after it -- and print each configuration's bucket trace under `sweep` (schema: INTEGRATION.md)")
@@ -209,7 +210,7 @@ def main():
     # the timed region ends with a device synchronisation, so every update it issued is inside it
     ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.01, fine_tune_l2_weight=0.01, pool_negatives=not a.no_pool,
                    dedup_items=a.dedup, defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0",
-                   graph=(world == 1 and not a.no_graph and not a.dedup))
+                   graph=(world == 1 and a.graph and not a.dedup))
     PAD_TO = 512 if ts.graph else 0        # spare-row bucket of the unpadded token layout (one captured graph per bucket)
     use_graph = {"v": bool(ts.graph)}
 

@@ -116,10 +116,7 @@ def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1):
     ws = None
     if split_m > 1:
         need = _lib.lib().morec_gemm_tn_workspace_bytes(N, K, split_m) // 4
-        ws = _TN_WS.get(dy3.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 20 * 1024 * 1024), device=dy3.device, dtype=torch.float32)
-            _TN_WS[dy3.device] = ws
+        ws = _scratch(_TN_WS, dy3.device, need, 20 * 1024 * 1024)
     py, px = dy3.data_ptr(), x3.data_ptr()
     for sy, sx in ((0, 0), (0, 2), (2, 0)):      # (hi, hi), (hi, lo), (lo, hi)
         check(_lib.lib().morec_gemm_tn(C.c_void_p(py + 2 * sy * N), C.c_void_p(px + 2 * sx * K), _p(out), M, N, K, 3 * N, 3 * K, out.stride(0),
@@ -128,6 +125,19 @@ def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1):
 
 
 _CS_WS = {}      # per-device fp32 scratch of the fused column sums (stream-ordered reuse, like _TN_WS)
+# Scratch buffers that have been outgrown are KEPT (never handed back to the allocator): a captured graph of the step
+# (TrainStep.step_graphed) has their addresses baked into its kernel arguments and keeps writing there at every replay.
+_WS_RETIRED = []
+
+
+def _scratch(cache, device, need, floor):
+    ws = cache.get(device)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _WS_RETIRED.append(ws)
+        ws = torch.empty(max(need, floor), device=device, dtype=torch.float32)
+        cache[device] = ws
+    return ws
 
 
 def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=None, dact=ACT_NONE, dact_in=None,
@@ -152,10 +162,7 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
     if colsum_out is not None:
         need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4
-        ws = _CS_WS.get(a.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 2 * 1024 * 1024), device=a.device, dtype=torch.float32)
-            _CS_WS[a.device] = ws
+        ws = _scratch(_CS_WS, a.device, need, 4 * 1024 * 1024)
         check(_lib.lib().morec_gemm_nt_colsum(C.byref(d), _p(a), _p(b), _p(out), _p(bias), _p(aux_out), _p(dact_in),
                                               _p(colsum_out), _p(ws), _stream()), "morec_gemm_nt_colsum")
         return out
@@ -176,10 +183,7 @@ def gemm_tn_(dy, x, out, split_m=1, accumulate=True, slabs=True):
     ws = None
     if slabs and split_m > 1:
         need = _lib.lib().morec_gemm_tn_workspace_bytes(N, K, split_m) // 4
-        ws = _TN_WS.get(dy.device)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 20 * 1024 * 1024), device=dy.device, dtype=torch.float32)
-            _TN_WS[dy.device] = ws
+        ws = _scratch(_TN_WS, dy.device, need, 20 * 1024 * 1024)
     check(_lib.lib().morec_gemm_tn(_p(dy), _p(x), _p(out), M, N, K, dy.stride(0), x.stride(0), out.stride(0), code(dy.dtype),
                                    split_m, int(accumulate), _p(ws), _stream()), "morec_gemm_tn")
     return out

@@ -68,8 +68,8 @@ def build_parser():
     p.add_argument("--max_steps", type=int, default=0)
     p.add_argument("--prefetch", type=int, default=4, help="batches built ahead of the device by the collate thread (run.BatchPrefetcher; "
                    "T/run.py:111-124 uses DataLoader(num_workers=12, pin_memory=True)); 0 = collate inline on the main thread")
-    p.add_argument("--no_graph", action="store_true", help="--fused_step on one rank replays the step as a captured hipGraph per input shape "
-                   "(TrainStep.step_graphed; unpadded token rows padded to buckets of 512); this switches back to host launches")
+    p.add_argument("--graph", action="store_true", help="--fused_step on one rank: replay the step as a captured hipGraph per input shape "
+                   "(TrainStep.step_graphed; unpadded token rows padded to buckets of 512) instead of host launches")
     p.add_argument("--steady_after", type=int, default=10, help="the epoch log also reports user-seq/s over the steps after this many (allocator "
                    "warm-up, first-call set-up and the loss scaler's initial back-off excluded)")
     p.add_argument("--checkpoint_root", type=str, default="./checkpoint", help="parent of checkpoint_<tower>.../cpt_<label>/ (T/run.py:326-331)")

@@ -307,7 +307,7 @@ def train(args, use_modal, local_rank):
         stepper = TrainStep(model, lr=args.lr, fine_tune_lr=args.fine_tune_lr, l2_weight=args.l2_weight,
                             fine_tune_l2_weight=args.fine_tune_l2_weight, pool_negatives=args.pool_negatives,
                             defer_update=os.environ.get("MOREC_DEFER_UPDATE", "1") != "0",      # (the epoch ends with a device synchronisation before eval / save)
-                            graph=(world == 1 and not getattr(args, "no_graph", False)))
+                            graph=(world == 1 and bool(getattr(args, "graph", False))))
         if ckpt is not None and ckpt.get("optimizer") is not None:     # T/run.py:193-195
             stepper.load_optimizer_state_dict(ckpt["optimizer"])
         wrapped = model

@@ -851,6 +851,7 @@ class TrainStep:
             self.step_count -= 1           # (the capture pass counted a step that has not run)
             ent = self._graphs[key] = (g, static, loss)
         g, static, loss = ent
+        self.flush()            # (an eager step's deferred update may still be running: the graph's forward carries no per-slice waits)
         for d_, s_ in zip(static, ins):
             d_.copy_(s_, non_blocking=True)
         ev = self._throttle()
