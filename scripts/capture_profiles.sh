@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): kernel trace + PMC passes of the bench command and of four GEMM shapes; everything lands in
 # gpurun_out/ (copy what is to be judged into profiles/).   bash scripts/capture_profiles.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 # Single-stream runs for the per-kernel numbers (with the weight-gradient stream on, dW launches overlap the dX chain and the traced
@@ -31,6 +31,17 @@ rm -f /tmp/prof/ks_results.db
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ks -- python $R/bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary > $O/${TAG}_prof_swin_line.json 2> /dev/null
 NS2=$(python -c "import json,sys; print(json.loads([l for l in open('$O/${TAG}_prof_swin_line.json') if l.startswith('{')][-1])['steps_executed'])")
 python $R/scripts/prof_summary.py /tmp/prof/ks_results.db $NS2 "$TAG swin_tiny B=64 (704 images/step): MOREC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- bench.py --tower swin_tiny --batch 64 --steps 4 --warmup 2 ($NS2 steps traced)" > $O/${TAG}_swin_tiny_kernel_stats.csv
+# Swin-T / Swin-B: HBM-side bytes of the GEMM launches (FETCH_SIZE / WRITE_SIZE, separate passes) -> <tag>_swin_{tiny,base}_gemm_pmc.json,
+# which bench.py matches by signature for the vision lines' roofline.traffic
+for spec in "swin_tiny 64" "swin_base 32"; do
+  set -- $spec
+  SB="python $R/bench.py --tower $1 --batch $2 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary"
+  MOREC_WGRAD_STREAM=0 timeout 200 $SB > $O/${TAG}_prof_$1_line.json 2> /dev/null
+  rm -f /tmp/prof/sf_results.db /tmp/prof/swr_results.db
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o sf -- $SB > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof -o swr -- $SB > /dev/null 2>&1
+  python $R/scripts/pmc_traffic.py /tmp/prof/sf_results.db /tmp/prof/swr_results.db $O/${TAG}_prof_$1_line.json $O/${TAG}_$1_gemm_pmc.json
+done
 # scoring kernels at the 8-rank pooled column count (Nr = 2560 rows x Nc = 21 504 columns, D = 512): HBM-side bytes per launch, then
 # the kernel trace of the same command
 {

@@ -6,7 +6,7 @@ from idvs.morec_amd import ops, _lib
 from idvs.morec_amd._lib import ACT_GELU, DACT_MUL
 M, N, K = (int(x) for x in sys.argv[1:4])
 kind = sys.argv[4] if len(sys.argv) > 4 else "nt"
-dev, dt = "cuda", torch.bfloat16
+dev, dt = "cuda", (torch.float16 if os.environ.get("MOREC_ONE_DTYPE", "fp16") == "fp16" else torch.bfloat16)
 if kind == "tn":
     from idvs.morec_amd.engine import _splitk
     dy = torch.randn(M, N, device=dev).to(dt); x = torch.randn(M, K, device=dev).to(dt); out = torch.zeros(N, K, device=dev)
