@@ -1,4 +1,4 @@
-// gemm_skinny.hip -- NT GEMM for NARROW outputs over very many rows:  C[M, N] = A[M, K] . B[N, K]^T  with N <= 128, K <= 384, M in the
+// gemm_skinny.hip -- NT GEMM for NARROW outputs over very many rows:  C[M, N] = A[M, K] . B[N, K]^T  with N <= 128 (N <= 288 when K <= 96), K <= 384, M in the
 // millions: the Swin stage-1 / stage-2 products whose output is C = 96 ... 128 wide (attention output projection, MLP fc2, the dX
 // products of fc1 / o_proj / qkv, the patch embedding: HF modeling_swin.py SwinSelfOutput / SwinOutput / SwinPatchEmbeddings via
 // V/model/encoders.py:30-31, and their autograd backward).  These are streaming problems -- 2 N K / ((K + N) 2) < 160 FLOP per byte,
@@ -25,6 +25,7 @@ struct SkArgs {
     const bf16* A;
     const bf16* B;
     bf16* C;
+    const float* bias;     // fp32 [N] added to every row (nn.Linear bias), or null
     int M, N, K, lda, ldb, ldc, tiles;
 };
 
@@ -77,6 +78,13 @@ __device__ __forceinline__ void skinny_body(const SkArgs& p, char* smem, const b
                 fb[cb][ks] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rB, off, 0, 0));
             }
     }
+    // bias of this lane's columns (cb: columns (half * NBH + cb) * 16 + 4 q .. + 3); zeros without one
+    float4 bv[NBH];
+#pragma unroll
+    for (int cb = 0; cb < NBH; ++cb) {
+        const int n = (half * NBH + cb) * 16 + 4 * q;
+        bv[cb] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // ---- DMA geometry of a tile: instruction j of this wave fills slots [(wave * IPW + j) * 64, + 64) of the stage image; slot i = row
     // i / SP, physical 16-byte slot i % SP, which holds logical slot (phys ^ (row & 7)) of its 8-slot group (XOR within the group:
     // the 16 rows of a fragment read then spread over the banks).  Slots past K read out of range -> zeros.
@@ -96,8 +104,9 @@ __device__ __forceinline__ void skinny_body(const SkArgs& p, char* smem, const b
 #pragma unroll
         for (int j = 0; j < IPW; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(dst + j * 1024), 16, aoff[j], 0, 0, 0);
     };
-    // output: vector v of the staged tile = row v / VPR, 16-byte column group v % VPR; this thread moves vectors tid and tid + 256
+    // output: vector v of the staged tile = row v / VPR, 16-byte column group v % VPR; this thread moves vectors tid, tid + 256, ...
     constexpr int VPR = NCOL / 8;
+    constexpr int NSTORE = (TR * VPR + THREADS - 1) / THREADS;      // store instructions per thread and tile
     const int vN = p.N / 8;                               // real 16-byte column groups per row
     auto store_tile = [&](int tile, int buf) {
         const int m0 = tile * TR;
@@ -105,7 +114,7 @@ __device__ __forceinline__ void skinny_body(const SkArgs& p, char* smem, const b
         const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(Cg + (size_t)m0 * p.ldc), 0, (int)cbts, 0x00020000);
         const char* src = stage_out + buf * OUT_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NSTORE; ++h) {
             const int v = tid + h * THREADS;
             const int row = v / VPR, cg = v % VPR;
             const bool in = v < TR * VPR && cg < vN;
@@ -134,7 +143,7 @@ __device__ __forceinline__ void skinny_body(const SkArgs& p, char* smem, const b
         const char* st = ring + (i % NST) * STAGE + frow * PITCH;
         f32x4_t acc[NBH];
 #pragma unroll
-        for (int cb = 0; cb < NBH; ++cb) acc[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < NBH; ++cb) acc[cb] = f32x4_t{bv[cb].x, bv[cb].y, bv[cb].z, bv[cb].w};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int lg = ks * 4 + q;
@@ -180,6 +189,11 @@ int launch_skinny(const SkArgs& a, hipStream_t s) {
 
 template <typename T16, int NBH>
 int dispatch_ks(const SkArgs& a, int ks, hipStream_t s) {
+    if constexpr (NBH > 4) {      // wide outputs (N <= 288: the stage-1 q|k|v projection) only with short K: 9 column blocks x 3 k-steps of B = 108 registers
+        if (ks <= 2) return launch_skinny<T16, 2, NBH>(a, s);
+        if (ks == 3) return launch_skinny<T16, 3, NBH>(a, s);
+        return G8_NOT_TAKEN;
+    }
     switch (ks) {
         case 1: case 2: return launch_skinny<T16, 2, NBH>(a, s);
         case 3: return launch_skinny<T16, 3, NBH>(a, s);
@@ -196,7 +210,7 @@ int dispatch_ks(const SkArgs& a, int ks, hipStream_t s) {
 // tuning key "gemm_skinny": 0 = automatic (default), 1 = never
 int g_skinny_mode = -1;
 
-// Plain products only (no bias / activation / accumulation / second output): what the Swin engine asks of its narrow GEMMs.
+// Plain products and products with a bias (no activation / accumulation / second output): what the Swin engine asks of its narrow GEMMs.
 int gemm_skinny_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     if (g_skinny_mode < 0) {
         const char* e = getenv("MOREC_GEMM_SKINNY");
@@ -204,17 +218,20 @@ int gemm_skinny_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s)
     }
     if (g_skinny_mode == 1) return G8_NOT_TAKEN;
     if (!is_h16(d->in_dtype) || d->out_dtype != d->in_dtype) return G8_NOT_TAKEN;
-    if (a.bias || a.aux_out || a.dact_in || a.colsum || d->act != MOREC_ACT_NONE || d->dact != MOREC_ACT_NONE || a.accumulate != 0 || d->split_k > 1 ||
+    if (a.aux_out || a.dact_in || a.colsum || d->act != MOREC_ACT_NONE || d->dact != MOREC_ACT_NONE || a.accumulate != 0 || d->split_k > 1 ||
         d->alpha != 1.0f)
         return G8_NOT_TAKEN;
-    if (d->N > 128 || d->N < 64 || d->N % 8 || d->K % 8 || d->K > 384 || d->M < 8192) return G8_NOT_TAKEN;
+    if (d->N > 288 || d->N < 64 || d->N % 8 || d->K % 8 || d->K > 384 || d->M < 8192) return G8_NOT_TAKEN;
+    if (d->N > 128 && d->K > 96) return G8_NOT_TAKEN;
+    if (a.bias && (d->N % 4 || (reinterpret_cast<uintptr_t>(a.bias) & 15u))) return G8_NOT_TAKEN;
     if (d->lda % 8 || d->ldb % 8 || d->ldc % 8) return G8_NOT_TAKEN;
     if ((long)TR * d->lda * 2 >= 0x7fffffffL) return G8_NOT_TAKEN;
     SkArgs k;
     k.A = reinterpret_cast<const bf16*>(a.A); k.B = reinterpret_cast<const bf16*>(a.B); k.C = reinterpret_cast<bf16*>(a.C);
+    k.bias = a.bias;
     k.M = d->M; k.N = d->N; k.K = d->K; k.lda = d->lda; k.ldb = d->ldb; k.ldc = d->ldc; k.tiles = (d->M + TR - 1) / TR;
     const int ks = (d->K + 31) / 32;
-    const bool wide = d->N > 96;
-    if (d->in_dtype == MOREC_F16) return wide ? dispatch_ks<f16, 4>(k, ks, s) : dispatch_ks<f16, 3>(k, ks, s);
-    return wide ? dispatch_ks<bf16, 4>(k, ks, s) : dispatch_ks<bf16, 3>(k, ks, s);
+    const int nbh = d->N <= 96 ? 3 : (d->N <= 128 ? 4 : 9);
+    if (d->in_dtype == MOREC_F16) return nbh == 3 ? dispatch_ks<f16, 3>(k, ks, s) : nbh == 4 ? dispatch_ks<f16, 4>(k, ks, s) : dispatch_ks<f16, 9>(k, ks, s);
+    return nbh == 3 ? dispatch_ks<bf16, 3>(k, ks, s) : nbh == 4 ? dispatch_ks<bf16, 4>(k, ks, s) : dispatch_ks<bf16, 9>(k, ks, s);
 }

@@ -5,7 +5,7 @@ import torch
 from idvs.morec_amd import ops, _lib
 L = _lib.lib()
 dev, dt = "cuda", torch.bfloat16
-shapes = [(2207744, 96, 48, "patch embed"), (2207744, 96, 96, "o_proj / its dX"), (2207744, 96, 384, "fc2 / dX of fc1"), (2207744, 96, 288, "dX of qkv"),
+shapes = [(2207744, 288, 96, "stage 1 q|k|v projection (N = 288)"), (2207744, 96, 48, "patch embed"), (2207744, 96, 96, "o_proj / its dX"), (2207744, 96, 384, "fc2 / dX of fc1"), (2207744, 96, 288, "dX of qkv"),
           (551936, 192, 192, "stage 2 o_proj (N = 192: tile kernels)"), (1126400, 128, 128, "Swin-B stage 1 o_proj (352 images)"), (1126400, 128, 384, "Swin-B dX of qkv")]
 for M, N, K, what in shapes:
     a = torch.randn(M, K, device=dev).to(dt); b = torch.randn(N, K, device=dev).to(dt); out = torch.empty(M, N, device=dev, dtype=dt)

@@ -11,15 +11,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(M, N, K, dt, lda=None, ldc=None, seed=0):
+def _run(M, N, K, dt, lda=None, ldc=None, seed=0, bias=False):
     from idvs.morec_amd import ops
     g = torch.Generator(device="cpu").manual_seed(seed + M + N + K)
     lda, ldc = lda or K, ldc or N
     a_full = (torch.randn(M, lda, generator=g) * 0.5).to(DEV).to(dt)
     b = (torch.randn(N, K, generator=g) * 0.5).to(DEV).to(dt)
     out = torch.full((M, ldc), 7.0, device=DEV, dtype=dt)
-    ops.gemm_nt(a_full, b, out=out, M=M, N=N, K=K, lda=lda, ldc=ldc)
-    ref = a_full[:, :K].double() @ b.double().t()
+    bv = torch.randn(N, generator=g).to(DEV) if bias else None
+    ops.gemm_nt(a_full, b, out=out, M=M, N=N, K=K, lda=lda, ldc=ldc, bias=bv)
+    ref = a_full[:, :K].double() @ b.double().t() + (bv.double() if bias else 0.0)
     got = out[:, :N].double()
     ulp = 2.0 ** (-8 if dt == torch.bfloat16 else -11)
     bound = ulp * ref.abs() + 3e-6 * np.sqrt(K) + 1e-30
@@ -34,6 +35,13 @@ def _run(M, N, K, dt, lda=None, ldc=None, seed=0):
                                    (9000, 96, 192), (8192, 64, 64), (33333, 104, 200)])
 def test_skinny_products(dt, M, N, K):
     _run(M, N, K, dt)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(300001, 288, 96), (70001, 96, 48), (20000, 192, 64), (50017, 128, 384), (9000, 256, 96)])
+def test_skinny_products_with_bias(dt, M, N, K):
+    """nn.Linear with its bias: the stage-1 q|k|v projection of Swin-T (N = 288, K = 96) and the patch embedding (K = 48)."""
+    _run(M, N, K, dt, bias=True)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
