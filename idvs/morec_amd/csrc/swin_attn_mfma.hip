@@ -62,6 +62,19 @@ __device__ __forceinline__ uint4 frag_tr(const char* tile, int row_bytes, int co
     return __builtin_bit_cast(uint4, v);
 }
 
+// The same read with the 16 head columns of block pair td spread as 4 groups of 4: lane c receives column 4 td + 8 (c >> 2) + (c & 3).
+// As the A operand of an MFMA this makes output row 4 g + r of block td the head column 8 g + 4 td + r, i.e. the two blocks td = 0, 1 of a
+// lane are 8 CONSECUTIVE head columns of its token row: one 16-byte store per (token, tensor) instead of two 8-byte ones (the 8-byte
+// pieces made these kernels store-issue bound: 2.4 - 3.3 TB/s, profiles/r03_swin_tiny_kernel_stats.csv).
+__device__ __forceinline__ uint4 frag_tr_spread(const char* tile, int row_bytes, int td, int s) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const char* p0 = tile + (32 * s + 4 * g + (c >> 2)) * row_bytes + (4 * td + 8 * (c & 3)) * 2;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * row_bytes));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(uint4, v);
+}
+
 struct LaneGeom {
     int row[4];        // natural row of token t = (lane & 15) + 16 k (clamped for padded tokens)
     bool valid[4];
@@ -199,6 +212,15 @@ __device__ __forceinline__ void store4_bf16(bf16* p, const f32x4_t& v, float mul
     *reinterpret_cast<uint2*>(p) = o;
 }
 
+__device__ __forceinline__ void store8_bf16(bf16* p, const f32x4_t& lo, const f32x4_t& hi) {
+    uint4 o;
+    o.x = pack_bf16x2(lo[0], lo[1]);
+    o.y = pack_bf16x2(lo[2], lo[3]);
+    o.z = pack_bf16x2(hi[0], hi[1]);
+    o.w = pack_bf16x2(hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(p) = o;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wavefront execute in order; this only stops the compiler from moving LDS accesses across
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
             for (int ti = 0; ti < 4; ++ti) pf[ti] = pack_frag(s, ti, sk);
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
-                const uint4 vt = frag_tr(sV, TROW, 16 * td, sk);
+                const uint4 vt = frag_tr_spread(sV, TROW, td, sk);      // o[td][ti][r] = head column 8 g + 4 td + r of token 16 ti + c
 #pragma unroll
                 for (int ti = 0; ti < 4; ++ti) o[td][ti] = mfma(vt, pf[ti], o[td][ti]);
             }
@@ -272,9 +294,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
             if (G.valid[ti]) {
-#pragma unroll
-                for (int td = 0; td < 2; ++td)
-                    store4_bf16(a.ctx + (size_t)G.row[ti] * C + head * DH + 16 * td + 4 * g4, o[td][ti], 1.0f);
+                store8_bf16(a.ctx + (size_t)G.row[ti] * C + head * DH + 8 * g4, o[0][ti], o[1][ti]);
             }
     }
 }
@@ -374,6 +394,16 @@ __device__ __forceinline__ void store4_buf(const __amdgpu_buffer_rsrc_t& rs, uin
     o[0] = pack_bf16x2(v[0] * mul, v[1] * mul);
     o[1] = pack_bf16x2(v[2] * mul, v[3] * mul);
     __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff, 0);
+}
+
+// the lane's 8 consecutive head columns of one token row (blocks td = 0 | 1 of the spread fragments): one 16-byte store
+__device__ __forceinline__ void store8_buf(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, int soff, const f32x4_t& lo, const f32x4_t& hi, float mul) {
+    u32x4_t o;
+    o[0] = pack_bf16x2(lo[0] * mul, lo[1] * mul);
+    o[1] = pack_bf16x2(lo[2] * mul, lo[3] * mul);
+    o[2] = pack_bf16x2(hi[0] * mul, hi[1] * mul);
+    o[3] = pack_bf16x2(hi[2] * mul, hi[3] * mul);
+    __builtin_amdgcn_raw_buffer_store_b128(o, rs, voff, soff, 0);
 }
 
 // dbias accumulates in registers (LDS float atomics cost 2x the rest of the kernel) and is reduced once per workgroup.
@@ -492,16 +522,14 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
             for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
                 for (int td = 0; td < 2; ++td) {
-                    const uint4 kt = frag_tr(sK, TROW, 16 * td, sk);
+                    const uint4 kt = frag_tr_spread(sK, TROW, td, sk);
 #pragma unroll
                     for (int ti = 0; ti < 4; ++ti) acc[td][ti] = mfma(kt, dsf[ti][sk], acc[td][ti]);
                 }
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti)
                 if (G.valid[ti]) {
-#pragma unroll
-                    for (int td = 0; td < 2; ++td)
-                        store4_buf(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), 32 * td, acc[td][ti], a.scale);
+                    store8_buf(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), 0, acc[0][ti], acc[1][ti], a.scale);
                 }
             if (a.csum) {
 #pragma unroll
@@ -524,7 +552,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
                 for (int tj = 0; tj < 4; ++tj) pt[tj] = frag_tr(sP, PROW, 16 * tj, sk);
 #pragma unroll
                 for (int td = 0; td < 2; ++td) {
-                    const uint4 ot = frag_tr(sX, TROW, 16 * td, sk);
+                    const uint4 ot = frag_tr_spread(sX, TROW, td, sk);
 #pragma unroll
                     for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(ot, pt[tj], acc[td][tj]);
                 }
@@ -532,9 +560,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
                 if (G.valid[tj]) {
-#pragma unroll
-                    for (int td = 0; td < 2; ++td)
-                        store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 4 + 32 * td, acc[td][tj], 1.0f);
+                    store8_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 4, acc[0][tj], acc[1][tj], 1.0f);
                 }
             if (a.csum) {
 #pragma unroll
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
                 for (int tj = 0; tj < 4; ++tj) st[tj] = frag_tr(sP, PROW, 16 * tj, sk);
 #pragma unroll
                 for (int td = 0; td < 2; ++td) {
-                    const uint4 qt = frag_tr(sX, TROW, 16 * td, sk);
+                    const uint4 qt = frag_tr_spread(sX, TROW, td, sk);
 #pragma unroll
                     for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(qt, st[tj], acc[td][tj]);
                 }
@@ -585,9 +611,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
                 if (G.valid[tj]) {
-#pragma unroll
-                    for (int td = 0; td < 2; ++td)
-                        store4_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 4 * g4) * 2), C * 2 + 32 * td, acc[td][tj], a.scale);
+                    store8_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 2, acc[0][tj], acc[1][tj], a.scale);
                 }
             if (a.csum) {
 #pragma unroll
@@ -598,15 +622,15 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
         }
         wave_lds_fence();
     }
-    if (a.csum) {   // one row per wavefront slot: [slot][tensor * C + head * 32 + 16 td + 4 g + e]; empty slots write zeros
-        float* wrow = a.csum + (size_t)(wm.bx * 4 + wave) * (3 * C) + head * DH + 4 * g4;
+    if (a.csum) {   // one row per wavefront slot: [slot][tensor * C + head * 32 + 8 g + 4 td + e] (the spread column order); empty slots write zeros
+        float* wrow = a.csum + (size_t)(wm.bx * 4 + wave) * (3 * C) + head * DH + 8 * g4;
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
                 float4 v;
                 v.x = row16_sum(cs[t][td][0]); v.y = row16_sum(cs[t][td][1]); v.z = row16_sum(cs[t][td][2]); v.w = row16_sum(cs[t][td][3]);
-                if (c == 0) *reinterpret_cast<float4*>(wrow + t * C + 16 * td) = v;
+                if (c == 0) *reinterpret_cast<float4*>(wrow + t * C + 4 * td) = v;
             }
     }
     if (a.dbias_t) {
