@@ -129,6 +129,7 @@ __device__ __forceinline__ void store_row_d(bf16* dst, size_t row, int pitch, in
         v.z = h16<T16>::pack2(o[2 * h + 1][0], o[2 * h + 1][1]);
         v.w = h16<T16>::pack2(o[2 * h + 1][2], o[2 * h + 1][3]);
         *reinterpret_cast<uint4*>(p + 8 * h) = v;
+        store_b128_guard();      // (MFMAs of the next block follow: see common.hpp)
     }
 }
 

@@ -344,6 +344,17 @@ __device__ __forceinline__ void drop_keep_vec(const DropRng& d, uint64_t idx0, b
     }
 }
 
+// ---- hazard guard behind a 16-byte global / buffer STORE in a kernel that keeps issuing MFMAs around it.  hipcc separates such a store from the
+// next VALU write of its data registers by the two wait states the ISA asks for, and counts an interleaved v_mfma as one of them; measured on
+// gfx950 (scripts/race_probe2.py, profiles/r04_store_hazard_probe.txt): with the memory pipe backed up by a second stream's kernel, dword 0 of
+// the store data of 16 lanes was occasionally the NEXT value of that register -- 4 token rows of Swin attention gradients replaced by raw fp32
+// bit patterns, a NaN in the weight gradient every few steps.  Three idle issue slots behind the store (nothing the compiler may move) close it.
+__device__ __forceinline__ void store_b128_guard() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 2" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- packed ("varlen") token layouts with SPARE rows: the blocks a launcher appends behind its (sequence, head) grid zero the rows
 // [cu[n_seq], total_rows) of a row-major output, 16 rows per block -- rows no sequence owns (a layout padded up to a bucket size so that
 // one captured graph serves every batch of the bucket) then hold exact zeros instead of whatever the allocator left there, and the

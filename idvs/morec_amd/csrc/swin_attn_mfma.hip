@@ -219,6 +219,7 @@ __device__ __forceinline__ void store8_bf16(bf16* p, const f32x4_t& lo, const f3
     o.z = pack_bf16x2(hi[0], hi[1]);
     o.w = pack_bf16x2(hi[2], hi[3]);
     *reinterpret_cast<uint4*>(p) = o;
+    store_b128_guard();
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -404,6 +405,7 @@ __device__ __forceinline__ void store8_buf(const __amdgpu_buffer_rsrc_t& rs, uin
     o[2] = pack_bf16x2(hi[0] * mul, hi[1] * mul);
     o[3] = pack_bf16x2(hi[2] * mul, hi[3] * mul);
     __builtin_amdgcn_raw_buffer_store_b128(o, rs, voff, soff, 0);
+    store_b128_guard();
 }
 
 // dbias accumulates in registers (LDS float atomics cost 2x the rest of the kernel) and is reduced once per workgroup.
