@@ -390,7 +390,7 @@ def token_packing(mask: torch.Tensor):
     return cu, tok_idx
 
 
-def token_packing_host(mask, token_ids=None, pad_to: int = 0):
+def token_packing_host(mask, token_ids=None, pad_to: int = 0, pin: bool | None = None):
     """The same bookkeeping on the HOST (numpy / CPU tensor ``mask`` int [Nc, T], what the data loader's collate holds before the H2D
     copy, ``T/run.py:232-239``): returns pinned int32 CPU tensors ``(cu_seqlens [Nc + 1], tok_idx [n_tokens])`` or ``None`` when the
     rows are not a run of ones followed by zeros (the padded layout is kept then).  Uploading the two vectors with the batch spares
@@ -424,7 +424,8 @@ def token_packing_host(mask, token_ids=None, pad_to: int = 0):
         if n + extra == Nc * T:      # (a packed row count of exactly Nc T means "nothing dropped" to bert_forward: stay clear of it)
             extra += pad_to
         tok = np.concatenate((tok, np.full(extra, -1, dtype=np.int32)))
-    pin = torch.cuda.is_available()
+    if pin is None:      # (False from a DataLoader worker process: it must not touch the HIP runtime; the loader's pin thread page-locks)
+        pin = torch.cuda.is_available()
     out = [torch.from_numpy(cu), torch.from_numpy(tok)]
     if token_ids is not None:
         ids = token_ids.numpy() if isinstance(token_ids, torch.Tensor) else np.asarray(token_ids)

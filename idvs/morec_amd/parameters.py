@@ -66,6 +66,9 @@ def build_parser():
     p.add_argument("--synthetic_full_len", action="store_true", help="synthetic users all have raw history max_seq_len + 3 (train sequences "
                    "of exactly S + 1 items, no padding): the shape bench.py times (SURVEY.md §8d)")
     p.add_argument("--max_steps", type=int, default=0)
+    p.add_argument("--collate_workers", type=int, default=2, help="worker PROCESSES that build the batches (collate + unpadded-layout index vectors) "
+                   "through torch's DataLoader with pin_memory, as T/run.py:111-124 does with num_workers=12 -- no GIL shared with the thread that "
+                   "launches ~700 kernels per step; 0 = the in-process collate thread (--prefetch)")
     p.add_argument("--prefetch", type=int, default=4, help="batches built ahead of the device by the collate thread (run.BatchPrefetcher; "
                    "T/run.py:111-124 uses DataLoader(num_workers=12, pin_memory=True)); 0 = collate inline on the main thread")
     p.add_argument("--graph", action="store_true", help="--fused_step on one rank: replay the step as a captured hipGraph per input shape "

@@ -73,6 +73,19 @@ def synthetic_dataset(n_users, n_items, S, T, seed=12345, full_len=False):
     return n_items, content, users_train, users_valid, users_test, hist_valid, hist_test, pop
 
 
+class _BatchSet(torch.utils.data.Dataset):
+    """One DataLoader "sample" = one collated batch (``batch_size=None``): the loader's worker processes run ``make(batch_idx)``."""
+
+    def __init__(self, make, batches):
+        self.make, self.batches = make, batches
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, i):
+        return self.make(self.batches[i])
+
+
 class BatchPrefetcher:
     """Batches built AHEAD of the device by a worker thread: collate (numpy gathers out of the item table), the unpadded token layout's
     index vectors and page-locking -- what the reference gets from ``DataLoader(num_workers=12, pin_memory=True)`` (``T/run.py:111-124``;
@@ -335,6 +348,7 @@ def train(args, use_modal, local_rank):
         # T/run.py:114,123-124,230: DistributedSampler(seed 0 + epoch, padded to a multiple of the world size) + a loader
         # without drop_last -- the last batch of an epoch is short
         batches = epoch_batches(len(users), args.batch_size, world, rank, now_epoch)
+        n_workers = 0 if (bce or hasattr(item_content, "device_batch")) else max(0, int(getattr(args, "collate_workers", 0)))
 
         def make_batch(batch_idx):      # host side of a batch (collate thread): T/run.py:111-124's DataLoader work
             batch_users = [users[i] for i in batch_idx]
@@ -345,13 +359,21 @@ def train(args, use_modal, local_rank):
             pack = None
             if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
                 rows = items.view(-1, items.size(-1))
-                pack = engine.token_packing_host(rows[:, T:], rows[:, :T], pad_to=512 if (stepper is not None and stepper.graph) else 0)
+                pack = engine.token_packing_host(rows[:, T:], rows[:, :T], pad_to=512 if (stepper is not None and stepper.graph) else 0,
+                                                 pin=False if n_workers > 0 else None)
             return ids, items, log_mask, pack
 
         on_device = hasattr(item_content, "device_batch")       # LMDB catalogue: the collate itself issues device work (decode -> H2D -> resize)
         depth = 0 if on_device else int(getattr(args, "prefetch", 2))
-        feeder = BatchPrefetcher(make_batch, batches, depth) if depth > 0 else None
-        source = feeder if feeder is not None else ((b_, make_batch(idx_)) for b_, idx_ in enumerate(batches))
+        feeder = None
+        if n_workers > 0 and not on_device:
+            # T/run.py:111-124: DataLoader worker processes + its pin-memory thread; one "sample" = one whole collated batch
+            loader = torch.utils.data.DataLoader(_BatchSet(make_batch, batches), batch_size=None, shuffle=False, num_workers=n_workers,
+                                                 pin_memory=True, prefetch_factor=max(2, depth // max(1, n_workers)))
+            source = enumerate(loader)
+        else:
+            feeder = BatchPrefetcher(make_batch, batches, depth) if depth > 0 else None
+            source = feeder if feeder is not None else ((b_, make_batch(idx_)) for b_, idx_ in enumerate(batches))
         t0, loss_acc, t_mark, n_mark = time.time(), None, None, 0
         b = -1
         for b, (ids, items, log_mask, pack) in source:
@@ -414,7 +436,8 @@ def train(args, use_modal, local_rank):
         if t_mark is not None and n_mark > 0:
             steady = n_mark * world / max(t_end - t_mark, 1e-9)
             train.last_steady_rate = steady          # (read by bench.py's run.py-vs-bench comparison)
-            Log.info("epoch %d: steady state (after step %d): %.1f user-seq/s, prefetch depth %d" % (now_epoch, int(getattr(args, "steady_after", 10)), steady, depth))
+            Log.info("epoch %d: steady state (after step %d): %.1f user-seq/s, %s" % (now_epoch, int(getattr(args, "steady_after", 10)), steady,
+                                                                                    ("%d collate worker processes" % n_workers) if n_workers > 0 else ("collate thread, depth %d" % depth)))
             if feeder is not None and feeder.n:
                 Log.info("collate thread: %.2f ms per batch; the training loop waited %.1f ms in total for batches" % (feeder.make_s / feeder.n * 1e3, feeder.wait_s * 1e3))
         if stepper is not None and stepper.sp is not None:
