@@ -69,6 +69,9 @@ _SIGS = {
     "morec_gemm_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "morec_gemm_tn": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "morec_gemm_tn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "morec_mlp_dact_recompute_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "morec_mlp_dact_recompute_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "morec_mlp_dact_recompute": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_transpose_batch": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),

@@ -50,6 +50,8 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
     {   // narrow outputs over very many rows (Swin stage 1 / 2): the streaming kernel (gemm_skinny.hip)
         const int rs = gemm_skinny_try_launch(d, a, s);
         if (rs != G8_NOT_TAKEN) return rs;
+        const int rw = gemm_skinny_wide_try_launch(d, a, s);      // 288 < N <= 512, K <= 128 (stage-1 fc1 + GELU without a second output)
+        if (rw != G8_NOT_TAKEN) return rw;
     }
     {   // bf16, large: the 256 x 256 eight-phase kernel (gemm8p.hip)
         const int r8 = gemm8p_try_launch(d, a, s);

@@ -34,6 +34,7 @@ struct GemmArgs {
 #define G8_NOT_TAKEN 0x7fff0001
 int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);
 int gemm_skinny_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm_skinny.hip: N <= 128, K <= 384, plain product
+int gemm_skinny_wide_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s); // gemm_skinny_wide.hip: 288 < N <= 512, K <= 128, bias / GELU
 extern int g_skinny_mode;
 int gemm_nt_f16_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm_f16.hip
 int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);

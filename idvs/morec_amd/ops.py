@@ -171,6 +171,33 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
     return out
 
 
+_DR_WS = {}
+
+
+def mlp_dact_recompute_supported(M, N, K, dtype):
+    """Does ``mlp_dact_recompute`` take this shape (Swin stage-1 MLP: 288 < N <= 512, K <= 128, M >= 8192, 16-bit)?  The forward then
+    runs fc1 + GELU WITHOUT the act'(pre) output."""
+    return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().morec_mlp_dact_recompute_supported(M, N, K, code(dtype)))
+
+
+def mlp_dact_recompute(dy, w2t, x, w1, b1, colsum_out=None):
+    """dU = (dy @ w2t^T) * GELU'(x @ w1^T + b1), ``colsum_out += dU.sum(0)``: the backward of ``GELU(fc1(x)) -> fc2`` down to the
+    pre-activation gradient, with the pre-activation recomputed from ``x`` instead of read from a saved tensor
+    (``morec_mlp_dact_recompute``)."""
+    _dev(dy), _dev(x)
+    M, K = dy.shape
+    N = w2t.shape[0]
+    assert dy.is_contiguous() and x.is_contiguous() and w2t.is_contiguous() and w1.is_contiguous()
+    assert x.shape == (M, K) and w1.shape == (N, K) and w2t.shape == (N, K)
+    out = torch.empty((M, N), device=dy.device, dtype=dy.dtype)
+    ws = None
+    if colsum_out is not None:
+        ws = _scratch(_DR_WS, dy.device, _lib.lib().morec_mlp_dact_recompute_workspace_bytes(N) // 4, 1024 * 1024)
+    check(_lib.lib().morec_mlp_dact_recompute(_p(dy), _p(w2t), _p(x), _p(w1), _p(b1), _p(out), _p(colsum_out), _p(ws), M, N, K,
+                                              code(dy.dtype), _stream()), "morec_mlp_dact_recompute")
+    return out
+
+
 _TN_WS = {}
 
 

@@ -174,8 +174,11 @@ def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, n
             hn, h, mean2, rstd2 = ops.layernorm_fwd(a, p[L + "layernorm_after.weight"], p[L + "layernorm_after.bias"], eps,
                                                     bias=p[L + "attention.o_proj.bias"], res=x, z_inplace=True,
                                                     rowscale=scale, rows_per_scale=tokens)
-            pre = torch.empty((x.shape[0], w["f1"].w.shape[0]), device=x.device, dtype=dtype) if need_grad else None
-            g = ops.gemm_nt(hn, w["f1"].w, bias=p[L + "mlp.fc1.bias"], act=ACT_GELU, aux_out=pre, aux_deriv=need_grad)   # pre = GELU'(fc1)
+            # stage-1 widths (C <= 128): no act'(pre) tensor -- the backward recomputes the pre-activation from hn (ops.mlp_dact_recompute)
+            b1 = p[L + "mlp.fc1.bias"]
+            keep_pre = need_grad and not (b1.data_ptr() % 16 == 0 and ops.mlp_dact_recompute_supported(x.shape[0], w["f1"].w.shape[0], C, dtype))
+            pre = torch.empty((x.shape[0], w["f1"].w.shape[0]), device=x.device, dtype=dtype) if keep_pre else None
+            g = ops.gemm_nt(hn, w["f1"].w, bias=b1, act=ACT_GELU, aux_out=pre, aux_deriv=keep_pre)   # pre = GELU'(fc1)
             f = ops.gemm_nt(g, w["f2"].w)
             pending = (f, p[L + "mlp.fc2.bias"], h)
             saved_blocks.append((desc, bias_t, x, xn, mean1, rstd1, qkv, ctx, h, hn, mean2, rstd2, pre, g, scale, tokens))
@@ -239,8 +242,11 @@ def swin_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
             desc, bias_t, x, xn, mean1, rstd1, qkv, ctx, h, hn, mean2, rstd2, pre, g, scale, tokens = saved_stages[s][b]
             # MLP branch: out = h + fc2(gelu(fc1(LN2(h)))) + b2
             linear_wgrad_(dout, g, grads[L + "mlp.fc2.weight"])
-            du = ops.gemm_nt(dout, w["f2"].wt, dact=DACT_MUL, dact_in=pre, K=dout.shape[1], N=pre.shape[1],
-                             colsum_out=grads[L + "mlp.fc1.bias"])
+            if pre is None:
+                du = ops.mlp_dact_recompute(dout, w["f2"].wt, hn, w["f1"].w, p[L + "mlp.fc1.bias"], colsum_out=grads[L + "mlp.fc1.bias"])
+            else:
+                du = ops.gemm_nt(dout, w["f2"].wt, dact=DACT_MUL, dact_in=pre, K=dout.shape[1], N=pre.shape[1],
+                                 colsum_out=grads[L + "mlp.fc1.bias"])
             linear_wgrad_(du, hn, grads[L + "mlp.fc1.weight"])
             dhn = ops.gemm_nt(du, w["f1"].wt, K=du.shape[1], N=C)
             # h = x + droppath * (o_proj(ctx) + bo): dh = LN2'(dhn) + dout; da = droppath * dh
