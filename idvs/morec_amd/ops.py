@@ -175,7 +175,7 @@ _DR_WS = {}
 
 
 def mlp_dact_recompute_supported(M, N, K, dtype):
-    """Does ``mlp_dact_recompute`` take this shape (Swin stage-1 MLP: 288 < N <= 512, K <= 128, M >= 8192, 16-bit)?  The forward then
+    """Does ``mlp_dact_recompute`` take this shape (Swin stage-1 / stage-2 MLP: 288 < N <= 768, K <= 192, M >= 8192, 16-bit)?  The forward then
     runs fc1 + GELU WITHOUT the act'(pre) output."""
     return dtype in (torch.bfloat16, torch.float16) and bool(_lib.lib().morec_mlp_dact_recompute_supported(M, N, K, code(dtype)))
 

@@ -174,7 +174,7 @@ def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, n
             hn, h, mean2, rstd2 = ops.layernorm_fwd(a, p[L + "layernorm_after.weight"], p[L + "layernorm_after.bias"], eps,
                                                     bias=p[L + "attention.o_proj.bias"], res=x, z_inplace=True,
                                                     rowscale=scale, rows_per_scale=tokens)
-            # stage-1 widths (C <= 128): no act'(pre) tensor -- the backward recomputes the pre-activation from hn (ops.mlp_dact_recompute)
+            # stage-1 / stage-2 widths (C <= 192): no act'(pre) tensor -- the backward recomputes the pre-activation from hn (ops.mlp_dact_recompute)
             b1 = p[L + "mlp.fc1.bias"]
             keep_pre = need_grad and not (b1.data_ptr() % 16 == 0 and ops.mlp_dact_recompute_supported(x.shape[0], w["f1"].w.shape[0], C, dtype))
             pre = torch.empty((x.shape[0], w["f1"].w.shape[0]), device=x.device, dtype=dtype) if keep_pre else None

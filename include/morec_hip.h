@@ -69,8 +69,8 @@ int morec_version(void);
  *   "gemm8p_tail_bias"   share of K the first part takes in that split;
  *   "gemm8p_ngroup"      tile order: -1 = automatic column groups (default), 0 = row-major, n = column groups of n N-tiles;
  *   "gemm8p_reserve_cus" CUs (multiple of 8) left out of the persistent grid for a concurrent RCCL kernel;
- *   "gemm_skinny"        0 = automatic, 1 = never use the streaming kernels for narrow outputs (gemm_skinny: N <= 288, K <= 384; gemm_skinny_wide:
- *                        N <= 512, K <= 128; M >= 8192; product + bias [+ GELU]) -- morec_mlp_dact_recompute_supported() then answers 0;
+ *   "gemm_skinny"        0 = automatic, 2 = gemm_skinny only (no gemm_skinny_wide / recompute), 1 = never use the streaming kernels for narrow outputs (gemm_skinny: N <= 288, K <= 384; gemm_skinny_wide:
+ *                        N <= 768, K <= 192, GELU(product + bias); M >= 8192) -- morec_mlp_dact_recompute_supported() then answers 0;
  *   "ce8p"               scoring kernels: 0 = automatic, 1 = always the 128 x 128 kernels, 2 = the 256 x 256 eight-phase kernels
  *                        wherever the shape rules allow (bf16, D > 64, D % 8 == Nc % 8 == (B S) % 8 == 0);
  *   "gemm8p_debug", "gemm8p_stamps_lo/hi"  ablation bits / device address of a cycle-stamp buffer (diagnostics).
@@ -115,9 +115,10 @@ int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, const void* B,
  *   dU[M, N] = (dY[M, K] . W2t[N, K]^T) * act'(X[M, K] . W1[N, K]^T + b1[N]),   colsum_out[n] += sum_m dU[m, n]  (= d b1)
  * The pre-activation is recomputed from X (K = C wide) instead of being read back 4 C wide; the matching forward is morec_gemm_nt
  * with act = MOREC_ACT_GELU and aux_out == NULL.  All operands contiguous (pitches K, K, K, K, N), 16-bit (bf16 / f16), 16-byte aligned.
- * Written for the Swin stage-1 MLP (HF modeling_swin.py SwinIntermediate / SwinOutput: 288 < N <= 512, K <= 128, M >= 8192);
- * morec_mlp_dact_recompute_supported() says whether a shape is taken (the caller then skips the aux output of the forward GEMM),
- * anything else returns MOREC_E_UNSUPPORTED.  workspace: morec_mlp_dact_recompute_workspace_bytes(N) bytes of fp32 (per-workgroup
+ * Written for the Swin stage-1 / stage-2 MLP (HF modeling_swin.py SwinIntermediate / SwinOutput: 288 < N <= 768, K <= 192 --
+ * N <= 384 for K <= 96, N <= 512 for K <= 128 --, M >= 8192);
+ * morec_mlp_dact_recompute_supported() says for which of those shapes dropping act' pays (K <= 128: the caller then skips the aux
+ * output of the forward GEMM); the call itself also takes the K <= 192 class; anything else returns MOREC_E_UNSUPPORTED.  workspace: morec_mlp_dact_recompute_workspace_bytes(N) bytes of fp32 (per-workgroup
  * column sums, folded in a fixed order), needed when colsum_out != NULL.  autograd reference: torch.nn.functional.gelu backward +
  * nn.Linear backward (db = dY.sum(0)). */
 int morec_mlp_dact_recompute_supported(int M, int N, int K, int dtype);

@@ -18,7 +18,7 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-for M, N, K, what in [(2207744, 384, 96, "Swin-T stage 1 (704 images)"), (1103872, 512, 128, "Swin-B stage 1 (352 images)")]:
+for M, N, K, what in [(2207744, 384, 96, "Swin-T stage 1 (704 images)"), (1103872, 512, 128, "Swin-B stage 1 (352 images)"), (551936, 768, 192, "Swin-T stage 2 (704 images)")]:
     x = torch.randn(M, K, device=dev).to(dt); dy = torch.randn(M, K, device=dev).to(dt)
     w1 = (torch.randn(N, K, device=dev) * 0.1).to(dt); w2t = (torch.randn(N, K, device=dev) * 0.1).to(dt)
     b1 = torch.randn(N, device=dev); cs = torch.zeros(N, device=dev)
@@ -38,11 +38,3 @@ for M, N, K, what in [(2207744, 384, 96, "Swin-T stage 1 (704 images)"), (110387
     print(f"  dU:  x act' read back (tile kernel) {t_b_old:7.1f} us ({byt(K + N, N) / t_b_old / 1e6:5.2f} TB/s)   pre-activation recomputed {t_b_new:7.1f} us "
           f"({byt(2 * K, N) / t_b_new / 1e6:5.2f} TB/s)")
 
-# Swin-B stage-1 q|k|v projection (N = 384, K = 128, bias): falls into the wide kernel's shape class too
-M, N, K = 1103872, 384, 128
-x = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * 0.1).to(dt); b = torch.randn(N, device=dev); o = torch.empty(M, N, device=dev, dtype=dt)
-t_new = timed(lambda: ops.gemm_nt(x, w, bias=b, out=o))
-L.morec_tuning_set(b"gemm_skinny", 1)
-t_old = timed(lambda: ops.gemm_nt(x, w, bias=b, out=o))
-L.morec_tuning_set(b"gemm_skinny", 0)
-print(f"Swin-B stage-1 q|k|v (M = {M}, N = {N}, K = {K}, bias): tile kernel {t_old:7.1f} us   streaming {t_new:7.1f} us ({(M * K + M * N) * 2 / t_new / 1e6:5.2f} TB/s)")

@@ -71,9 +71,11 @@ def _dgelu64(u):
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,gelu", [(300001, 384, 96, True), (100003, 512, 128, True), (8192, 384, 96, True), (20001, 320, 64, True),
+                                        (138001, 768, 192, True), (50000, 640, 160, True),
                                         (50000, 448, 128, False), (70001, 384, 96, False)])
 def test_wide_bias_gelu(dt, M, N, K, gelu):
-    """fc1 + bias (+ GELU) without a second output; ragged M, N below the padded tile width, a pitch wider than N."""
+    """fc1 + bias + GELU without a second output (streaming kernel; the bias-only cases take the tile kernels); ragged M, N below the padded
+    tile width, a pitch wider than N."""
     from idvs.morec_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     a = (torch.randn(M, K, generator=g) * 0.5).to(DEV).to(dt)
@@ -92,11 +94,12 @@ def test_wide_bias_gelu(dt, M, N, K, gelu):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K", [(300001, 384, 96), (100003, 512, 128), (8192, 384, 96), (33333, 320, 64)])
+@pytest.mark.parametrize("M,N,K", [(300001, 384, 96), (100003, 512, 128), (8192, 384, 96), (33333, 320, 64),
+                                   (138001, 768, 192), (40000, 576, 192), (30003, 320, 192), (8200, 768, 160)])      # K > 128: two column slices
 def test_mlp_dact_recompute(dt, M, N, K):
     """dU = (dY W2) * GELU'(x W1^T + b1) with the pre-activation recomputed in the kernel, + its column sums (d b1) ADDED to what is there."""
     from idvs.morec_amd import _lib, ops
-    assert ops.mlp_dact_recompute_supported(M, N, K, dt)
+    assert ops.mlp_dact_recompute_supported(M, N, K, dt) == (K <= 128)      # K = 192: the call works, the engine keeps act' there (slower)
     g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
     dy = (torch.randn(M, K, generator=g) * 0.5).to(DEV).to(dt)
     w2t = (torch.randn(N, K, generator=g) * 0.3).to(DEV).to(dt)
@@ -126,7 +129,9 @@ def test_mlp_dact_recompute_shape_rules():
     from idvs.morec_amd import _lib, ops
     bf = torch.bfloat16
     assert ops.mlp_dact_recompute_supported(2207744, 384, 96, bf) and ops.mlp_dact_recompute_supported(1103872, 512, 128, torch.float16)
-    assert not ops.mlp_dact_recompute_supported(551936, 768, 192, bf)          # stage 2: the fragments of two [768, 192] weights do not fit the registers
+    assert not ops.mlp_dact_recompute_supported(551936, 768, 192, bf)          # stage 2 of Swin-T: accepted by the call (two column slices) but slower than reading act'
+    assert not ops.mlp_dact_recompute_supported(275968, 1024, 256, bf)         # stage 2 of Swin-B: the fragments of two [1024, 256] weights do not fit the registers
+    assert not ops.mlp_dact_recompute_supported(137984, 1536, 384, bf)
     assert not ops.mlp_dact_recompute_supported(4096, 384, 96, bf) and not ops.mlp_dact_recompute_supported(300000, 384, 96, torch.float32)
     L = _lib.lib()
     assert L.morec_tuning_set(b"gemm_skinny", 1) == 0
@@ -134,7 +139,7 @@ def test_mlp_dact_recompute_shape_rules():
         assert not ops.mlp_dact_recompute_supported(2207744, 384, 96, bf)
     finally:
         L.morec_tuning_set(b"gemm_skinny", 0)
-    t = torch.zeros(9000, 192, device=DEV, dtype=bf)
-    w = torch.zeros(768, 192, device=DEV, dtype=bf)
+    t = torch.zeros(9000, 256, device=DEV, dtype=bf)
+    w = torch.zeros(1024, 256, device=DEV, dtype=bf)
     with pytest.raises(RuntimeError):
         ops.mlp_dact_recompute(t, w, t, w, None)
