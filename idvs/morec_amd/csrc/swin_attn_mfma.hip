@@ -205,13 +205,6 @@ __device__ __forceinline__ uint4 pack_frag(const f32x4_t (&p)[4][4], int ti, int
     return f;
 }
 
-__device__ __forceinline__ void store4_bf16(bf16* p, const f32x4_t& v, float mul) {
-    uint2 o;
-    o.x = pack_bf16x2(v[0] * mul, v[1] * mul);
-    o.y = pack_bf16x2(v[2] * mul, v[3] * mul);
-    *reinterpret_cast<uint2*>(p) = o;
-}
-
 __device__ __forceinline__ void store8_bf16(bf16* p, const f32x4_t& lo, const f32x4_t& hi) {
     uint4 o;
     o.x = pack_bf16x2(lo[0], lo[1]);
@@ -388,16 +381,8 @@ __device__ __forceinline__ void load_bwd_frags(const BwdBufs& B, const LaneGeom&
         f.o[k] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(B.dctx, (uint32_t)G.row[k] * (uint32_t)(C * 2) + (uint32_t)((head * DH + 8 * g4) * 2), 0, 0));
     }
 }
-// out[row][col .. col + 3] = v * mul (bf16), row / col in elements of a [rows][pitch] matrix; soff = wave-uniform byte offset
-__device__ __forceinline__ void store4_buf(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, int soff, const f32x4_t& v, float mul) {
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
-    u32x2_t o;
-    o[0] = pack_bf16x2(v[0] * mul, v[1] * mul);
-    o[1] = pack_bf16x2(v[2] * mul, v[3] * mul);
-    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff, 0);
-}
-
-// the lane's 8 consecutive head columns of one token row (blocks td = 0 | 1 of the spread fragments): one 16-byte store
+// the lane's 8 consecutive head columns of one token row (blocks td = 0 | 1 of the spread fragments): one 16-byte store at byte offset
+// voff (per lane) + soff (wave-uniform) of a [rows][pitch] bf16 matrix, values scaled by mul
 __device__ __forceinline__ void store8_buf(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, int soff, const f32x4_t& lo, const f32x4_t& hi, float mul) {
     u32x4_t o;
     o[0] = pack_bf16x2(lo[0] * mul, lo[1] * mul);
