@@ -69,6 +69,7 @@ struct Ctx {
     int tok[2];                           // token (within the stage) of this lane in piece j: rows past the end are poisoned per stage
     int dpiece;                           // LDS offset of the wave's first piece within a half
     int ay[2], ax;                        // per-lane fragment base offsets: DY column group 0 / 1 of this wave, X column group
+    uint32_t vmask;                       // SKIP kernels: the wave's output blocks inside the matrix (mfma_quadrant)
 };
 
 // two pieces (4 token rows each) of one half-tile; `left` = tokens that exist from the stage's first row on
@@ -87,8 +88,28 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* smem, int addr, int ks) 
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <typename T16, int N0, int KQ>
-__device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const bf16x8_t (&fy)[2][4], const bf16x8_t (&fx)[4]) {
+// SKIP (outputs narrower than the tile: Swin's 96 ... 576-wide weights): vm = wave-uniform mask of the wave's 32 x 32 output blocks that lie
+// inside the matrix (bits 0-3: n-blocks, bits 4-5: k-blocks); a block outside it costs no MFMA.  A [96, 384] weight gradient fills 36 of
+// the 128 blocks of its two 256 x 256 tiles: unskipped, the launch was bound by MFMAs on padding (578 GFLOP for 163), not by its 2.1 GB.
+template <typename T16, int N0, int KQ, bool SKIP>
+__device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const bf16x8_t (&fy)[2][4], const bf16x8_t (&fx)[4], uint32_t vm) {
+    if constexpr (SKIP) {
+        if (!(vm & (16u << KQ))) return;
+        const bool a = (vm >> N0) & 1u, b = (vm >> (N0 + 1)) & 1u;
+        if (!(a && b)) {
+            if (!(a || b)) return;
+            __builtin_amdgcn_s_setprio(1);
+            if (a) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc[N0][KQ] = h16<T16>::mma32(fx[ks], fy[0][ks], acc[N0][KQ]);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc[N0 + 1][KQ] = h16<T16>::mma32(fx[ks], fy[1][ks], acc[N0 + 1][KQ]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -100,7 +121,7 @@ __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const bf16x
 
 // One stage (64 tokens) out of the buffer at byte offset cb.  mo = byte offset (rows x pitch) of this stage's first token in DY
 // (mo * ldx / ldy for X is passed separately); left = tokens of the chunk from this stage's first row on.
-template <typename T16, int REM>
+template <typename T16, int REM, bool SKIP>
 __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy, int sox, int dy_step, int dx_step, int left,
                                       f32x16_t (&acc)[4][2]) {
     char* cur = smem + cb;
@@ -119,7 +140,7 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 8, 2>();
     bar();
-    mfma_quadrant<T16, 0, 0>(acc, fy, fx0);
+    mfma_quadrant<T16, 0, 0, SKIP>(acc, fy, fx0, c.vmask);
     bar();
     // ---- phase 1: X-second fragments; refill DY-second of t+1
 #pragma unroll
@@ -128,7 +149,7 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 8, 0>();
     bar();
-    mfma_quadrant<T16, 0, 1>(acc, fy, fx1);
+    mfma_quadrant<T16, 0, 1, SKIP>(acc, fy, fx1, c.vmask);
     bar();
     // ---- phase 2: DY-second fragments; refill DY-first of t+2 (this buffer)
 #pragma unroll
@@ -140,21 +161,21 @@ __device__ __forceinline__ void stage(char* smem, const Ctx& c, int cb, int soy,
     pin();
     vm_wait_tail<REM, 6, 0>();
     bar();
-    mfma_quadrant<T16, 2, 1>(acc, fy, fx1);
+    mfma_quadrant<T16, 2, 1, SKIP>(acc, fy, fx1, c.vmask);
     bar();
     // ---- phase 3: nothing to read (X-first is still in registers); refill X-first of t+2
     if constexpr (REM >= 2) dma2(c.rx, c.x1, c.tok, left - 2 * TT, sox + 2 * dx_step, cur + OP_BYTES + c.dpiece);
     pin();
     vm_wait_tail<REM, 4, 0>();
     bar();
-    mfma_quadrant<T16, 2, 0>(acc, fy, fx0);
+    mfma_quadrant<T16, 2, 0, SKIP>(acc, fy, fx0, c.vmask);
     bar();
 }
 
 // The panel pointers are __restrict__ for hipcc's s_waitcnt insertion (see gemm8p.hip::tile_body): it tags the LDS-DMA
 // instructions with alias scopes and every ds_read with "does not alias them"; untagged, each ds_read after an LDS-DMA gets
 // a full `s_waitcnt vmcnt(0)`.
-template <typename T16>
+template <typename T16, bool SKIP>
 __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16* __restrict__ DYt, const bf16* __restrict__ Xt, int n0, int k0,
                                         int mbeg, int mend, float* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
@@ -188,6 +209,12 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg) c.ay[cg] = rowoff + (((wr * 4 + cg * 2 + cgrp) ^ (2 * rr)) << 5);
         c.ax = rowoff + (((wc * 2 + cgrp) ^ (2 * rr)) << 5);
+        uint32_t vm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vm |= (n0 + wr * 128 + i * 32 < p.N) ? (1u << i) : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vm |= (k0 + wc * 64 + j * 32 < p.K) ? (16u << j) : 0u;
+        c.vmask = __builtin_amdgcn_readfirstlane(vm);
     }
     const int dy_step = TT * p.ldy * 2, dx_step = TT * p.ldx * 2;
     const int left0 = mend - mbeg;
@@ -212,11 +239,11 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
     if (wr == 1) bar();
     int cb = 0, t = 0;
     for (; t < nt - 2; ++t) {
-        stage<T16, 2>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
+        stage<T16, 2, SKIP>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
         cb ^= BUF_BYTES;
     }
-    stage<T16, 1>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
-    stage<T16, 0>(smem, c, cb ^ BUF_BYTES, (t + 1) * dy_step, (t + 1) * dx_step, dy_step, dx_step, left0 - (t + 1) * TT, acc);
+    stage<T16, 1, SKIP>(smem, c, cb, t * dy_step, t * dx_step, dy_step, dx_step, left0 - t * TT, acc);
+    stage<T16, 0, SKIP>(smem, c, cb ^ BUF_BYTES, (t + 1) * dy_step, (t + 1) * dx_step, dy_step, dx_step, left0 - (t + 1) * TT, acc);
     if (wr == 0) bar();
 
     // ---- epilogue: acc[Ni][Ki][4 g + r] = C[n0 + wr*128 + Ni*32 + (lane & 31)][k0 + wc*64 + Ki*32 + 8 g + 4 (lane >> 5) + r], fp32.
@@ -259,7 +286,7 @@ __device__ __forceinline__ void tn_body(const TnArgs8& p, char* smem, const bf16
     }
 }
 
-template <typename T16>
+template <typename T16, bool SKIP>
 __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // Work items in (token chunk, n-tile, k-tile) order, k fastest, dealt to the XCDs in CONTIGUOUS runs (xcd_remap over the whole
@@ -272,8 +299,13 @@ __global__ __launch_bounds__(THREADS) void gemm_tn8p_kernel(TnArgs8 p) {
     const int z = item / tiles, wg = item - z * tiles;
     const int n0 = (wg / p.tiles_k) * 256, k0 = (wg % p.tiles_k) * 256;
     const int mbeg = z * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
-    tn_body<T16>(p, smem, p.DY + (size_t)mbeg * p.ldy + n0, p.X + (size_t)mbeg * p.ldx + k0, n0, k0, mbeg, mend,
+    tn_body<T16, SKIP>(p, smem, p.DY + (size_t)mbeg * p.ldy + n0, p.X + (size_t)mbeg * p.ldx + k0, n0, k0, mbeg, mend,
             p.out + (size_t)z * p.slab_stride);
+}
+// MOREC_TN8P_SKIP=0: never use the block-skipping variant (A/B aid)
+bool skip_env() {
+    static const bool on = [] { const char* e = getenv("MOREC_TN8P_SKIP"); return !e || atoi(e) != 0; }();
+    return on;
 }
 }  // namespace
 
@@ -300,9 +332,14 @@ int gemm_tn8p_try_launch(const bf16* DY, const bf16* X, float* out, size_t slab_
     a.tiles_n = tiles_n; a.tiles_k = tiles_k; a.zs = zs; a.slab_stride = slab_stride;
     if (!by_h16(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // thread-safe one-time set-up
-            (void)attr_rc;
-            hipLaunchKernelGGL(gemm_tn8p_kernel<T>, dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
+            static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);   // thread-safe one-time set-up
+            static const hipError_t attr_rc2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn8p_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+            (void)attr_rc; (void)attr_rc2;
+            // a 32-wide block row or column of some tile lies outside the matrix: the variant that skips those blocks' MFMAs
+            if (skip_env() && ((N % 256 != 0 && N % 256 <= 224) || (K % 256 != 0 && K % 256 <= 224)))
+                hipLaunchKernelGGL((gemm_tn8p_kernel<T, true>), dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
+            else
+                hipLaunchKernelGGL((gemm_tn8p_kernel<T, false>), dim3(tiles_n * tiles_k * zs), dim3(THREADS), LDS_TOTAL, s, a);
         }))
         return G8_NOT_TAKEN;
     MOREC_CHECK_LAUNCH();

@@ -40,6 +40,14 @@ def _text_model(dtype, bert, D, S, T, item_num, pop, drop=0.0, seed=7):
     return Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=drop, attention_probs_dropout_prob=drop), pop).to(DEV).train()
 
 
+# Two EAGER runs of the same steps differ -- fp32 atomic sums in a different order move a near-zero gradient by its last bits and Adam's
+# g / sqrt(v) turns that into a full-size update of that parameter -- by an amount that itself varies from box to box and pair to pair
+# (ID tower: relative parameter distance 1.6e-9 on one box, 3.4e-4 ... 7.8e-4 on another; text fp16: 5.2e-3 ... 6.4e-3, loss 0.6e-3 ... 3.4e-3;
+# Swin micro: 3.7e-4 ... 5.7e-4), so ONE eager pair does not bound the noise: each test adds a floor of ~4 x the largest value measured
+# (gpurun r4v, three rounds).  A replay that skipped or repeated an update, or read a stale batch, is off by 1e-1 ... 1.
+FLOOR = {"id": (2e-3, 4e-3), "text": (1.5e-2, 3e-2), "swin": (2e-3, 3e-3)}      # (max |d loss|, relative parameter distance)
+
+
 def _dist(a, b):
     dl = max(abs(x - y) for x, y in zip(a[0], b[0]))
     dp = max(float((x.double() - y.double()).norm() / y.double().norm()) for x, y in zip(a[1], b[1]))
@@ -74,7 +82,7 @@ def test_id_tower_replay_equals_eager_and_draws_new_masks():
     noise = _dist(res["eager"], res["eager2"])
     d = _dist(res["graph"], res["eager"])
     print(f"ID tower, graph vs eager over {steps} steps: max |d loss| {d[0]:.2e} (eager run-to-run {noise[0]:.2e}), parameter distance {d[1]:.2e} ({noise[1]:.2e})")
-    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
+    assert d[0] <= 10 * noise[0] + FLOOR["id"][0] and d[1] <= 10 * noise[1] + FLOOR["id"][1]
     assert res["graph"][0][-1] < res["graph"][0][0] - 0.2
     # dropout on, learning rates 0: the same batch replayed three times must see three different masks (the seed word moves on the device)
     args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.3, transformer_block=2, compute_dtype="bf16")
@@ -134,7 +142,7 @@ def test_text_tower_fp16_replay_equals_eager(layout):
     d = _dist(res["graph"], res["eager"])
     print(f"text fp16 {layout}: graph vs eager over {steps} steps: max |d loss| {d[0]:.2e} (eager run-to-run {noise[0]:.2e}), parameter distance "
           f"{d[1]:.2e} ({noise[1]:.2e}); {n_graphs} graph(s) for {len(n_tok)} distinct token counts")
-    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
+    assert d[0] <= 10 * noise[0] + FLOOR["text"][0] and d[1] <= 10 * noise[1] + FLOOR["text"][1]
     assert res["graph"][0][-1] < res["graph"][0][0] - 0.2
     assert 1 <= n_graphs <= 4
     if layout == "bucketed":
@@ -198,4 +206,4 @@ def test_vision_micro_replay_equals_eager():
     noise = _dist(res["eager"], res["eager2"])
     d = _dist(res["graph"], res["eager"])
     print(f"Swin micro, graph vs eager: max |d loss| {d[0]:.2e} (noise {noise[0]:.2e}), parameter distance {d[1]:.2e} ({noise[1]:.2e})")
-    assert d[0] <= 10 * noise[0] + 2e-3 and d[1] <= 10 * noise[1] + 1e-4
+    assert d[0] <= 10 * noise[0] + FLOOR["swin"][0] and d[1] <= 10 * noise[1] + FLOOR["swin"][1]

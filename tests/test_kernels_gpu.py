@@ -180,6 +180,26 @@ def test_gemm_tn(shape, dt16):
         assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(120000, 96, 384), (120000, 384, 96), (90001, 288, 96), (90000, 96, 96), (70000, 192, 768), (70000, 576, 192),
+                                   (60000, 96, 48), (50000, 128, 512), (50000, 1152, 384)])
+def test_gemm_tn_outputs_narrower_than_the_tile(M, N, K, dt16):
+    """Swin's weight-gradient shapes (C = 96 ... 384): 256 x 256 tiles of which whole 32 x 32 blocks lie outside the matrix -- the
+    eight-phase kernel's block-skipping variant (gemm_tn8p.hip, SKIP) must leave the blocks inside untouched and write nothing outside."""
+    from idvs.morec_amd import engine
+    dy, x = rnd(M, N, dt=dt16, scale=0.2), rnd(M, K, dt=dt16, scale=0.2, seed=1)
+    split = engine._splitk(N, K, M)
+    guard = torch.full((N + 8, K + 8), 3.0, device=DEV)
+    out = guard[:N, :K]
+    ops.gemm_tn_(dy, x, out, split_m=split, accumulate=False)
+    ref = dy.double().t() @ x.double()
+    assert rel(out, ref) < 2e-5 * math.sqrt(M) + 1e-6
+    assert bool((guard[N:] == 3.0).all()) and bool((guard[:, K:] == 3.0).all())
+    out2 = torch.ones(N, K, device=DEV)
+    ops.gemm_tn_(dy, x, out2, split_m=split)                 # accumulate into what is there
+    assert rel(out2 - 1, ref) < 2e-5 * math.sqrt(M) + 1e-5
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_transpose_cast_colsum(dt):
     x = rnd(300, 170, dt=dt)

@@ -4,6 +4,7 @@ consumer; closing early does not hang."""
 import threading
 import time
 
+import numpy as np
 import pytest
 import torch
 
@@ -50,3 +51,21 @@ def test_close_with_a_full_queue_does_not_hang():
     f.close()
     assert time.time() - t0 < 3 and not f.t.is_alive()
     assert threading.active_count() < 50
+
+
+def _make_for_workers(idx):
+    a = torch.from_numpy(np.asarray(idx, dtype=np.int64))
+    return a, a.float() * 2.0, torch.ones(len(idx), 3), (a.int(), None)       # nested tuple with a None entry, as the token packing has
+
+
+def test_batches_from_worker_processes_arrive_in_order():
+    """``run.py --collate_workers N``: one DataLoader "sample" is one whole collated batch (``batch_size=None``), built in worker processes
+    (T/run.py:111-124 uses ``DataLoader(num_workers=12)``); order, ragged last batch and ``None`` entries survive the trip."""
+    from idvs.morec_amd.run import _BatchSet
+    batches = [list(range(i * 4, i * 4 + 4)) for i in range(9)] + [[100, 101]]
+    loader = torch.utils.data.DataLoader(_BatchSet(_make_for_workers, batches), batch_size=None, shuffle=False, num_workers=2, prefetch_factor=2)
+    got = list(loader)
+    assert len(got) == len(batches)
+    for idx, (a, b, c, pack) in zip(batches, got):
+        assert a.tolist() == idx and b.tolist() == [2.0 * v for v in idx] and c.shape == (len(idx), 3)
+        assert pack[0].dtype == torch.int32 and pack[0].tolist() == idx and pack[1] is None
