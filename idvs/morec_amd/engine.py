@@ -80,7 +80,7 @@ def _splitk(N: int, K: int, Mp: int) -> int:
     """Split factor over the token dimension for dW[N, K] = dY^T X so that the launch fills the 256 CUs once with
     256 x 256 tiles (1 workgroup of 8 waves per CU) or, for small weights, twice with 128 x 128 tiles."""
     big = _cdiv(N, 256) * _cdiv(K, 256)
-    s = max(1, min(round(256 / big), Mp // 1024)) if big <= 256 else 1
+    s = max(1, min(256 // big, Mp // 1024)) if big <= 256 else 1      # floor: 10 tiles x 26 chunks = 260 workgroups would be TWO rounds on 256 CUs
     if big * s >= 192:
         return s
     small = _cdiv(N, 128) * _cdiv(K, 128)
