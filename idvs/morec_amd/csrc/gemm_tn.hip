@@ -146,7 +146,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_tn_kernel(TnArgs p) {
                 continue;
             }
             float* dst = p.C + (size_t)n * p.ldc + k;
-            if (p.atomic) {
+            if (p.atomic && gridDim.z == 1) {      // one token chunk: this lane is the only writer of its four elements -- read-modify-write, no atomics
+                float4 cur = *reinterpret_cast<const float4*>(dst);   // (SASRec weights at D = 2048, 640 rows: 16.8 M scalar atomics took 150 us per launch)
+                cur.x += acc[i][j][0]; cur.y += acc[i][j][1]; cur.z += acc[i][j][2]; cur.w += acc[i][j][3];
+                *reinterpret_cast<float4*>(dst) = cur;
+            } else if (p.atomic) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
             } else {
