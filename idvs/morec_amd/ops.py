@@ -5,6 +5,7 @@ streams); all arithmetic happens in ``libmorec_hip.so``.  Every wrapper raises o
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -97,11 +98,24 @@ def x3_cache_clear():
     _X3_CACHE.clear()
 
 
+X3_VERIFY = os.environ.get("MOREC_X3_VERIFY", "0") == "1"
+X3_HITS = 0
+
+
 def split_cached(t):
-    """``split_bf16x3(t, 2)`` ([hi | hi | lo], bf16 [R, 3 C]) of a whole contiguous fp32 tensor, computed once per step."""
+    """``split_bf16x3(t, 2)`` ([hi | hi | lo], bf16 [R, 3 C]) of a whole contiguous fp32 tensor, computed once per step.
+    The entry is keyed by the tensor object; ``t._version`` only sees torch's own in-place writes -- the library's kernels write through raw
+    pointers -- so the contract is: no morec op overwrites a tensor between two GEMMs that read it (the engines keep it: the one in-place
+    form, ``layernorm_fwd(z_inplace=True)``, overwrites a GEMM OUTPUT that was never an operand).  ``ops.X3_VERIFY`` (env ``MOREC_X3_VERIFY=1``)
+    re-splits on every hit and compares: ``tests/test_fp32x3_gpu.py`` runs whole training steps under it."""
+    global X3_HITS
     key = id(t)
     hit = _X3_CACHE.get(key)
     if hit is not None and hit[0] is t and hit[1] == t._version:
+        if X3_VERIFY:
+            X3_HITS += 1
+            if not torch.equal(split_bf16x3(t, 2), hit[2]):
+                raise RuntimeError("split_cached: the tensor changed since its [hi | hi | lo] split was cached (stale operand)")
         return hit[2]
     s = split_bf16x3(t, 2)
     _X3_CACHE[key] = (t, t._version, s)

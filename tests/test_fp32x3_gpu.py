@@ -89,6 +89,7 @@ def test_fp32x3_step_tracks_the_exact_fp32_parity_mode():
         return ids.view(-1), items, torch.ones(B, S, device=DEV)
 
     curves, gnorms = {}, {}
+    ops.X3_VERIFY, ops.X3_HITS = True, 0      # every reuse of a cached [hi | hi | lo] split is re-derived and compared (stale-split guard)
     for name, model in (("fp32", m32), ("fp32x3", mx3)):
         ts = TrainStep(model, **kw)
         curves[name] = []
@@ -101,6 +102,8 @@ def test_fp32x3_step_tracks_the_exact_fp32_parity_mode():
             curves[name].append(float(loss))
         del ts
     assert ops.FP32_GEMM == "exact"        # the mode is scoped to the step
+    hits, ops.X3_VERIFY = ops.X3_HITS, False
+    assert hits > 100, hits                 # the cache is exercised (dX and dW products share their operands' splits), and never stale
     c32, cx3 = np.array(curves["fp32"]), np.array(curves["fp32x3"])
     d0 = abs(cx3[0] - c32[0]) / c32[0]
     dc = float((np.abs(cx3 - c32) / c32).max())
