@@ -457,7 +457,7 @@ int check_attn(const morec_swin_attn_desc* d) {
     if (d->window != 7) return MOREC_E_UNSUPPORTED;           // 7 x 7 = 49 tokens <= one wavefront of query rows
     if (d->H % d->window || d->W % d->window) return MOREC_E_UNSUPPORTED;   // (HF pads; no hot-path config needs it)
     if (d->shift < 0 || d->shift >= d->window) return MOREC_E_ARG;
-    if (d->dtype != MOREC_F32 && d->dtype != MOREC_BF16) return MOREC_E_DTYPE;
+    if (d->dtype != MOREC_F32 && !is_h16(d->dtype)) return MOREC_E_DTYPE;
     return MOREC_OK;
 }
 
@@ -474,7 +474,7 @@ SwinAttnArgs make_args(const morec_swin_attn_desc* d, int& gx) {
 }
 }  // namespace
 
-// bf16 fast path on the matrix cores (swin_attn_mfma.hip); MOREC_E_UNSUPPORTED = shape / dtype outside it
+// 16-bit fast path on the matrix cores (swin_attn_mfma.hip); MOREC_E_UNSUPPORTED = shape / dtype outside it
 int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
                                 void* dqkv, float* dbias_t, bool backward, hipStream_t s, float* csum = nullptr, long csum_rows = 0,
                                 int* csum_rows_needed = nullptr);
@@ -493,6 +493,7 @@ extern "C" int morec_swin_attn_fwd(const morec_swin_attn_desc* d, const void* qk
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     dim3 grid(gx, d->heads), block(64);
     if (d->dtype == MOREC_F32) hipLaunchKernelGGL((swin_attn_fwd_kernel<float, 7>), grid, block, 0, s, a);
+    else if (d->dtype == MOREC_F16) hipLaunchKernelGGL((swin_attn_fwd_kernel<f16, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((swin_attn_fwd_kernel<bf16, 7>), grid, block, 0, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -511,6 +512,7 @@ extern "C" int morec_swin_attn_bwd(const morec_swin_attn_desc* d, const void* qk
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     dim3 grid(gx, d->heads), block(64);
     if (d->dtype == MOREC_F32) hipLaunchKernelGGL((swin_attn_bwd_kernel<float, 7>), grid, block, 0, s, a);
+    else if (d->dtype == MOREC_F16) hipLaunchKernelGGL((swin_attn_bwd_kernel<f16, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((swin_attn_bwd_kernel<bf16, 7>), grid, block, 0, s, a);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -546,6 +548,8 @@ extern "C" int morec_swin_patchify(const float* pixels, void* out, int n_img, in
         hipLaunchKernelGGL((swin_patchify_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, pixels, (float*)out, n_img, channels, R, patch, ld_out);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_patchify_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, pixels, (bf16*)out, n_img, channels, R, patch, ld_out);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((swin_patchify_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, pixels, (f16*)out, n_img, channels, R, patch, ld_out);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
@@ -563,6 +567,8 @@ extern "C" int morec_swin_patchify_u8(const uint8_t* pixels_hwc, void* out, int 
         hipLaunchKernelGGL((swin_patchify_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, pixels_hwc, (float*)out, n_img, channels, R, patch, ld_out, mean, std);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_patchify_u8_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, pixels_hwc, (bf16*)out, n_img, channels, R, patch, ld_out, mean, std);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((swin_patchify_u8_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, pixels_hwc, (f16*)out, n_img, channels, R, patch, ld_out, mean, std);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
@@ -573,12 +579,14 @@ extern "C" int morec_swin_merge(const void* in, void* out, int n_img, int H, int
     if (!in || !out || n_img <= 0 || H <= 0 || W <= 0 || C <= 0) return MOREC_E_ARG;
     if (H % 2 || W % 2) return MOREC_E_UNSUPPORTED;           // (HF pads odd maps; no hot-path config needs it)
     if (C % 8) return MOREC_E_ALIGN;
-    const size_t total = (size_t)n_img * (H / 2) * (W / 2) * (4 * C / (dtype == MOREC_BF16 ? 8 : 4));
+    const size_t total = (size_t)n_img * (H / 2) * (W / 2) * (4 * C / (dtype == MOREC_F32 ? 4 : 8));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
         hipLaunchKernelGGL((swin_merge_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)in, (float*)out, n_img, H, W, C, reverse);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_merge_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)in, (bf16*)out, n_img, H, W, C, reverse);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((swin_merge_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, (const f16*)in, (f16*)out, n_img, H, W, C, reverse);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
@@ -588,12 +596,14 @@ extern "C" int morec_swin_merge(const void* in, void* out, int n_img, int H, int
 extern "C" int morec_swin_pool_fwd(const void* x, void* out, int n_img, int tokens, int C, int dtype, void* stream) {
     if (!x || !out || n_img <= 0 || tokens <= 0 || C <= 0) return MOREC_E_ARG;
     if (C % 8) return MOREC_E_ALIGN;
-    const int n = n_img * (C / (dtype == MOREC_BF16 ? 8 : 4));
+    const int n = n_img * (C / (dtype == MOREC_F32 ? 4 : 8));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
         hipLaunchKernelGGL((swin_pool_fwd_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)x, (float*)out, n_img, tokens, C);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_pool_fwd_kernel<bf16>), dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)x, (bf16*)out, n_img, tokens, C);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((swin_pool_fwd_kernel<f16>), dim3((n + 255) / 256), dim3(256), 0, s, (const f16*)x, (f16*)out, n_img, tokens, C);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
@@ -603,12 +613,14 @@ extern "C" int morec_swin_pool_fwd(const void* x, void* out, int n_img, int toke
 extern "C" int morec_swin_pool_bwd(const void* dout, void* dx, int n_img, int tokens, int C, int dtype, void* stream) {
     if (!dout || !dx || n_img <= 0 || tokens <= 0 || C <= 0) return MOREC_E_ARG;
     if (C % 8) return MOREC_E_ALIGN;
-    const size_t total = (size_t)n_img * tokens * (C / (dtype == MOREC_BF16 ? 8 : 4));
+    const size_t total = (size_t)n_img * tokens * (C / (dtype == MOREC_F32 ? 4 : 8));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
         hipLaunchKernelGGL((swin_pool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)dout, (float*)dx, n_img, tokens, C);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((swin_pool_bwd_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)dout, (bf16*)dx, n_img, tokens, C);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((swin_pool_bwd_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, (const f16*)dout, (f16*)dx, n_img, tokens, C);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
@@ -620,12 +632,14 @@ extern "C" int morec_bias_residual(const void* a, const float* bias, const void*
     if (!a || !res || !out || M <= 0 || N <= 0) return MOREC_E_ARG;
     if (rowscale && rows_per_scale <= 0) return MOREC_E_ARG;
     if (N % 8) return MOREC_E_ALIGN;
-    const size_t total = (size_t)M * (N / (dtype == MOREC_BF16 ? 8 : 4));
+    const size_t total = (size_t)M * (N / (dtype == MOREC_F32 ? 4 : 8));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MOREC_F32)
         hipLaunchKernelGGL((bias_residual_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)a, bias, (const float*)res, rowscale, rows_per_scale, (float*)out, (size_t)M, N);
     else if (dtype == MOREC_BF16)
         hipLaunchKernelGGL((bias_residual_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, s, (const bf16*)a, bias, (const bf16*)res, rowscale, rows_per_scale, (bf16*)out, (size_t)M, N);
+    else if (dtype == MOREC_F16)
+        hipLaunchKernelGGL((bias_residual_kernel<f16>), dim3(grid_for(total)), dim3(256), 0, s, (const f16*)a, bias, (const f16*)res, rowscale, rows_per_scale, (f16*)out, (size_t)M, N);
     else
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();

@@ -1,4 +1,4 @@
-// swin_attn_mfma.hip -- bf16 Swin window attention (7 x 7 = 49 tokens, 32-wide heads) on the matrix cores.
+// swin_attn_mfma.hip -- 16-bit (bf16 / f16) Swin window attention (7 x 7 = 49 tokens, 32-wide heads) on the matrix cores.
 //
 // Same contract as the exact-fp32 / generic kernels in swin.hip (SwinAttention, modeling_swin.py:401-468; window
 // partition / cyclic shift / reverse folded into row addressing).  One wavefront per (window, head), four wavefronts
@@ -46,9 +46,12 @@ struct SwinMArgs {
     float* csum;           // bwd, optional: [gx * 4 wavefronts][3 C] fp32 column sums of the wavefront's dq / dk / dv rows
 };
 
+// T16 = bf16 | f16: the storage type of q / k / v / ctx and their gradients (the operand bits go to the MFMA as they are; only the
+// instruction and the fp32 -> 16-bit packs differ)
+template <typename T16>
 __device__ __forceinline__ f32x4_t mfma(const uint4& a_rows, const uint4& b_rows, f32x4_t acc) {
     // acc[r] += sum_k A[4 (lane >> 4) + r][k] * B[lane & 15][k]; both operands given as "row (lane & 15), 8 k of chunk lane >> 4"
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_rows), __builtin_bit_cast(bf16x8_t, b_rows), acc, 0, 0, 0);
+    return h16<T16>::mma16(__builtin_bit_cast(bf16x8_t, a_rows), __builtin_bit_cast(bf16x8_t, b_rows), acc);
 }
 
 // transposed fragment of a row-major LDS tile: lane (c, g) receives column col0 + c of rows {32 s + 4 g + e} (e = 0..3) and
@@ -196,21 +199,23 @@ __device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, Bi
 }
 
 // B-operand fragment (k-step sk over keys) of row block ti from the register tile
+template <typename T16>
 __device__ __forceinline__ uint4 pack_frag(const f32x4_t (&p)[4][4], int ti, int sk) {
     uint4 f;
-    f.x = pack_bf16x2(p[2 * sk][ti][0], p[2 * sk][ti][1]);
-    f.y = pack_bf16x2(p[2 * sk][ti][2], p[2 * sk][ti][3]);
-    f.z = pack_bf16x2(p[2 * sk + 1][ti][0], p[2 * sk + 1][ti][1]);
-    f.w = pack_bf16x2(p[2 * sk + 1][ti][2], p[2 * sk + 1][ti][3]);
+    f.x = h16<T16>::pack2(p[2 * sk][ti][0], p[2 * sk][ti][1]);
+    f.y = h16<T16>::pack2(p[2 * sk][ti][2], p[2 * sk][ti][3]);
+    f.z = h16<T16>::pack2(p[2 * sk + 1][ti][0], p[2 * sk + 1][ti][1]);
+    f.w = h16<T16>::pack2(p[2 * sk + 1][ti][2], p[2 * sk + 1][ti][3]);
     return f;
 }
 
+template <typename T16>
 __device__ __forceinline__ void store8_bf16(bf16* p, const f32x4_t& lo, const f32x4_t& hi) {
     uint4 o;
-    o.x = pack_bf16x2(lo[0], lo[1]);
-    o.y = pack_bf16x2(lo[2], lo[3]);
-    o.z = pack_bf16x2(hi[0], hi[1]);
-    o.w = pack_bf16x2(hi[2], hi[3]);
+    o.x = h16<T16>::pack2(lo[0], lo[1]);
+    o.y = h16<T16>::pack2(lo[2], lo[3]);
+    o.z = h16<T16>::pack2(hi[0], hi[1]);
+    o.w = h16<T16>::pack2(hi[2], hi[3]);
     *reinterpret_cast<uint4*>(p) = o;
     store_b128_guard();
 }
@@ -222,6 +227,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <typename T16>
 __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     __shared__ __attribute__((aligned(16))) char sVall[4 * TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g4 = lane >> 4;
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
+            for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma<T16>(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
         softmax_rows(s, a.scale, [&](int tj, int ti) { return f32x4_t{bias[tj][ti][0], bias[tj][ti][1], bias[tj][ti][2], bias[tj][ti][3]}; }, G, mb);
         wave_lds_fence();
         f32x4_t o[2][4];
@@ -276,19 +282,19 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
         for (int sk = 0; sk < 2; ++sk) {
             uint4 pf[4];
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) pf[ti] = pack_frag(s, ti, sk);
+            for (int ti = 0; ti < 4; ++ti) pf[ti] = pack_frag<T16>(s, ti, sk);
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
                 const uint4 vt = frag_tr_spread(sV, TROW, td, sk);      // o[td][ti][r] = head column 8 g + 4 td + r of token 16 ti + c
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) o[td][ti] = mfma(vt, pf[ti], o[td][ti]);
+                for (int ti = 0; ti < 4; ++ti) o[td][ti] = mfma<T16>(vt, pf[ti], o[td][ti]);
             }
         }
         wave_lds_fence();   // the transposed reads are done before the next window overwrites the tile
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
             if (G.valid[ti]) {
-                store8_bf16(a.ctx + (size_t)G.row[ti] * C + head * DH + 8 * g4, o[0][ti], o[1][ti]);
+                store8_bf16<T16>(a.ctx + (size_t)G.row[ti] * C + head * DH + 8 * g4, o[0][ti], o[1][ti]);
             }
     }
 }
@@ -344,13 +350,13 @@ __device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, 
     }
 }
 
-template <int NTI>
+template <typename T16, int NTI>
 __device__ __forceinline__ uint4 pack_part(const f32x4_t (&p)[4][NTI], int t, int sk) {
     uint4 f;
-    f.x = pack_bf16x2(p[2 * sk][t][0], p[2 * sk][t][1]);
-    f.y = pack_bf16x2(p[2 * sk][t][2], p[2 * sk][t][3]);
-    f.z = pack_bf16x2(p[2 * sk + 1][t][0], p[2 * sk + 1][t][1]);
-    f.w = pack_bf16x2(p[2 * sk + 1][t][2], p[2 * sk + 1][t][3]);
+    f.x = h16<T16>::pack2(p[2 * sk][t][0], p[2 * sk][t][1]);
+    f.y = h16<T16>::pack2(p[2 * sk][t][2], p[2 * sk][t][3]);
+    f.z = h16<T16>::pack2(p[2 * sk + 1][t][0], p[2 * sk + 1][t][1]);
+    f.w = h16<T16>::pack2(p[2 * sk + 1][t][2], p[2 * sk + 1][t][3]);
     return f;
 }
 
@@ -383,12 +389,13 @@ __device__ __forceinline__ void load_bwd_frags(const BwdBufs& B, const LaneGeom&
 }
 // the lane's 8 consecutive head columns of one token row (blocks td = 0 | 1 of the spread fragments): one 16-byte store at byte offset
 // voff (per lane) + soff (wave-uniform) of a [rows][pitch] bf16 matrix, values scaled by mul
+template <typename T16>
 __device__ __forceinline__ void store8_buf(const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, int soff, const f32x4_t& lo, const f32x4_t& hi, float mul) {
     u32x4_t o;
-    o[0] = pack_bf16x2(lo[0] * mul, lo[1] * mul);
-    o[1] = pack_bf16x2(lo[2] * mul, lo[3] * mul);
-    o[2] = pack_bf16x2(hi[0] * mul, hi[1] * mul);
-    o[3] = pack_bf16x2(hi[2] * mul, hi[3] * mul);
+    o[0] = h16<T16>::pack2(lo[0] * mul, lo[1] * mul);
+    o[1] = h16<T16>::pack2(lo[2] * mul, lo[3] * mul);
+    o[2] = h16<T16>::pack2(hi[0] * mul, hi[1] * mul);
+    o[3] = h16<T16>::pack2(hi[2] * mul, hi[3] * mul);
     __builtin_amdgcn_raw_buffer_store_b128(o, rs, voff, soff, 0);
     store_b128_guard();
 }
@@ -398,7 +405,7 @@ __device__ __forceinline__ void store8_buf(const __amdgpu_buffer_rsrc_t& rs, uin
 // dK product (the last phase, when the softmax registers are dead) runs -- and q stays in registers for the dK product instead
 // of being re-read.  (Three dependent round trips per window -- q/k, then v/dO, then q again -- with two wavefronts per SIMD
 // to hide them left the kernel at 2 TB/s whatever the stage: profiles/r02_swin_attn.txt.)
-template <bool WIDE>
+template <typename T16, bool WIDE>
 __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(SwinMArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sBias = reinterpret_cast<float*>(smem);                 // [NT (query i)][BP] shared by the block's 4 wavefronts
@@ -459,8 +466,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
             const uint4 ob = *reinterpret_cast<const uint4*>(sX + (c + 16 * TB) * TROW + 16 * g4);
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
-                s[tj][0] = mfma(fr.k[tj], fr.q[TB], f32x4_t{0.f, 0.f, 0.f, 0.f});
-                dp[tj][0] = mfma(fr.v[tj], ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
+                s[tj][0] = mfma<T16>(fr.k[tj], fr.q[TB], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                dp[tj][0] = mfma<T16>(fr.v[tj], ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
             }
             // padded query rows (i >= NT) read the last real bias row; softmax_part zeroes their probabilities
             softmax_part<TB, 1>(s, a.scale, [&](int tj, int ti) {
@@ -486,8 +493,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
             char* prow = sP + (16 * TB + c) * PROW;
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
-                dsf[TB][sk] = pack_part<1>(dp, 0, sk);
-                const uint4 pfr = pack_part<1>(s, 0, sk);
+                dsf[TB][sk] = pack_part<T16, 1>(dp, 0, sk);
+                const uint4 pfr = pack_part<T16, 1>(s, 0, sk);
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
                 *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
             }
@@ -511,12 +518,12 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
                 for (int td = 0; td < 2; ++td) {
                     const uint4 kt = frag_tr_spread(sK, TROW, td, sk);
 #pragma unroll
-                    for (int ti = 0; ti < 4; ++ti) acc[td][ti] = mfma(kt, dsf[ti][sk], acc[td][ti]);
+                    for (int ti = 0; ti < 4; ++ti) acc[td][ti] = mfma<T16>(kt, dsf[ti][sk], acc[td][ti]);
                 }
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti)
                 if (G.valid[ti]) {
-                    store8_buf(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), 0, acc[0][ti], acc[1][ti], a.scale);
+                    store8_buf<T16>(bufs.dqkv, (uint32_t)G.row[ti] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), 0, acc[0][ti], acc[1][ti], a.scale);
                 }
             if (a.csum) {
 #pragma unroll
@@ -541,13 +548,13 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
                 for (int td = 0; td < 2; ++td) {
                     const uint4 ot = frag_tr_spread(sX, TROW, td, sk);
 #pragma unroll
-                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(ot, pt[tj], acc[td][tj]);
+                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma<T16>(ot, pt[tj], acc[td][tj]);
                 }
             }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
                 if (G.valid[tj]) {
-                    store8_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 4, acc[0][tj], acc[1][tj], 1.0f);
+                    store8_buf<T16>(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 4, acc[0][tj], acc[1][tj], 1.0f);
                 }
             if (a.csum) {
 #pragma unroll
@@ -592,13 +599,13 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
                 for (int td = 0; td < 2; ++td) {
                     const uint4 qt = frag_tr_spread(sX, TROW, td, sk);
 #pragma unroll
-                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma(qt, st[tj], acc[td][tj]);
+                    for (int tj = 0; tj < 4; ++tj) acc[td][tj] = mfma<T16>(qt, st[tj], acc[td][tj]);
                 }
             }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
                 if (G.valid[tj]) {
-                    store8_buf(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 2, acc[0][tj], acc[1][tj], a.scale);
+                    store8_buf<T16>(bufs.dqkv, (uint32_t)G.row[tj] * (uint32_t)(pitch * 2) + (uint32_t)((head * DH + 8 * g4) * 2), C * 2, acc[0][tj], acc[1][tj], a.scale);
                 }
             if (a.csum) {
 #pragma unroll
@@ -647,12 +654,12 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
 }
 }  // namespace
 
-// bf16, window 7, head width 32 only; anything else returns MOREC_E_UNSUPPORTED and the caller falls back to swin.hip's kernels
+// bf16 / f16, window 7, head width 32 only; anything else returns MOREC_E_UNSUPPORTED and the caller falls back to swin.hip's kernels
 // csum / csum_rows (backward, optional): scratch for the per-wavefront column sums of dqkv and the number of rows it holds;
 // *csum_rows_needed reports how many the launch geometry needs (the caller folds that many rows)
 int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, const float* bias_t, void* ctx, const void* dctx,
                                 void* dqkv, float* dbias_t, bool backward, hipStream_t s, float* csum, long csum_rows, int* csum_rows_needed) {
-    if (d->dtype != MOREC_BF16 || d->window != WS || d->dh != DH) return MOREC_E_UNSUPPORTED;
+    if (!is_h16(d->dtype) || d->window != WS || d->dh != DH) return MOREC_E_UNSUPPORTED;
     if ((d->heads * DH) % 8) return MOREC_E_UNSUPPORTED;
     SwinMArgs a{};
     a.qkv = reinterpret_cast<const bf16*>(qkv); a.bias_t = bias_t; a.ctx = reinterpret_cast<bf16*>(ctx);
@@ -669,20 +676,23 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     const unsigned long long qkv_bytes = (unsigned long long)d->n_img * d->H * d->W * 3 * d->heads * DH * 2;
     if (backward && qkv_bytes >= 0xffffffffull) return MOREC_E_UNSUPPORTED;     // 32-bit buffer offsets in the backward kernel
     a.qkv_bytes = (unsigned)qkv_bytes;
-    if (!backward) {
-        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, grid, block, 0, s, a);
-    } else {
-        const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
-        static const bool attr_set = [&] {      // thread-safe one-time set-up (the LDS size is a compile-time function of the tile constants)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
+    static const int wide = [] { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); return e ? atoi(e) : 1; }();
+    by_h16(d->dtype, [&](auto* t) {
+        using T = MOREC_TAG_T(t);
+        if (!backward) {
+            hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<T>, grid, block, 0, s, a);
+            return;
+        }
+        static const bool attr_set = [&] {      // thread-safe one-time set-up per storage type (the LDS size is a compile-time function of the tile constants)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_bwd_mfma_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             return true;
         }();
         (void)attr_set;
-        static const int wide = [] { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); return e ? atoi(e) : 1; }();
-        if (wide) hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, grid, block, lds, s, a);
-        else hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<false>, grid, block, lds, s, a);
-    }
+        if (wide) hipLaunchKernelGGL((swin_attn_bwd_mfma_kernel<T, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((swin_attn_bwd_mfma_kernel<T, false>), grid, block, lds, s, a);
+    });
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

@@ -17,7 +17,8 @@
  *     small-problem GEMMs), MOREC_F16 = 2 (IEEE fp16 operands, fp32 accumulate: v_mfma_f32_32x32x16_f16 / 16x16x32_f16 in the same
  *     kernels -- the arithmetic of the reference's `torch.cuda.amp.autocast()` step, T/run.py:242-247, three more significand bits
  *     than bf16 at the same MFMA rate; gradients need the loss scaling of morec_step_params below).  "bf16" in an entry point's
- *     description means either 16-bit type unless it says otherwise; the Swin kernels and morec_split_bf16x3 take MOREC_BF16 only;
+ *     description means either 16-bit type unless it says otherwise (the Swin kernels too, V/run.py's autocast step); morec_split_bf16x3
+ *     takes MOREC_BF16 only;
  *   - row-major matrices with explicit leading dimensions in ELEMENTS; every base pointer and
  *     every row pitch must be 16-byte aligned (MOREC_E_ALIGN otherwise);
  *   - item ids are int32 on the device (the host narrows the int64 ids PyTorch provides).
@@ -126,7 +127,7 @@ size_t morec_mlp_dact_recompute_workspace_bytes(int N);
 int morec_mlp_dact_recompute(const void* dY, const void* W2t, const void* X, const void* W1, const float* b1, void* dU,
                              float* colsum_out, float* workspace, int M, int N, int K, int dtype, void* stream);
 
-/* Weight-gradient GEMM without transposed copies (bf16 only; MOREC_E_UNSUPPORTED otherwise):
+/* Weight-gradient GEMM without transposed copies (16-bit operands only; MOREC_E_UNSUPPORTED otherwise):
  * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z; without a workspace that
  * requires accumulate != 0 (fp32 atomicAdd into a caller-zeroed C), with one the partial tiles are folded by a second kernel and
  * accumulate == 0 overwrites C.  Autograd backward of nn.Linear: dW = dY^T X. */
