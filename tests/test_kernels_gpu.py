@@ -181,6 +181,26 @@ def test_gemm_tn(shape, dt16):
 
 
 @pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,bias", [(2560, 512, 512, False), (2560, 512, 2048, True), (640, 2048, 2048, True), (2688, 512, 512, False), (77, 72, 64, True),
+                                        (1000, 260, 520, False), (64, 64, 4096, True), (3000, 1024, 136, True), (130, 4, 128, False)])
+def test_gemm_nt_small_problems(M, N, K, bias, dt16):
+    """The SASRec-sized products (2 560 ... 640 rows, D = 512 ... 2048: the two-buffer tile kernel): ragged M / N / K, a strided A and C, bias,
+    against the exact product of the same 16-bit operands; nothing written outside the M x N block."""
+    a_full = rnd(M, K + 24, dt=dt16, scale=0.3)
+    a = a_full[:, :K]
+    b = rnd(N, K, dt=dt16, scale=0.3, seed=1)
+    bv = rnd(N, seed=2) if bias else None
+    guard = torch.full((M + 3, N + 8), 5.0, device=DEV, dtype=dt16)
+    out = guard[:M, :N]
+    ops.gemm_nt(a_full, b, out=guard, bias=bv, M=M, N=N, K=K, lda=a_full.stride(0), ldc=guard.stride(0))      # (whole tensors + explicit extents)
+    ref = a.double() @ b.double().t() + (bv.double() if bias else 0.0)
+    ulp = 2.0 ** (-8 if dt16 == torch.bfloat16 else -11)
+    bound = ulp * ref.abs() + 3e-6 * math.sqrt(K) + 1e-30
+    assert bool(((out.double() - ref).abs() <= bound).all()), float(((out.double() - ref).abs() / bound).max())
+    assert bool((guard[M:] == 5.0).all()) and bool((guard[:, N:] == 5.0).all())
+
+
+@pytest.mark.parametrize("dt16", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(120000, 96, 384), (120000, 384, 96), (90001, 288, 96), (90000, 96, 96), (70000, 192, 768), (70000, 576, 192),
                                    (60000, 96, 48), (50000, 128, 512), (50000, 1152, 384)])
 def test_gemm_tn_outputs_narrower_than_the_tile(M, N, K, dt16):
