@@ -1,9 +1,9 @@
 // attention.hip -- small-tile multi-head attention, forward and backward, one wavefront per
 // (sequence, head).  The sequences on this path are tiny and fixed (user history S = 20 / 10, titles
-// T = 30): the problem is "many independent 32 x 32 score tiles", not long context, so the design is
+// T = 30; abstracts / bodies 50 at most): the problem is "many independent 32 x 32 (64 x 64) score tiles", not long context, so the design is
 //   * Q / K / V (and dO) d-chunks staged in LDS as fp32 (chunking makes any head width work:
 //     BERT dh = 64, SASRec d_k = 256 ... 2048),
-//   * each lane owns a 4 x 4 block of the 32 x 32 score tile in registers (8 x 8 lanes),
+//   * each lane owns a 4 x 4 block of the 32 x 32 score tile in registers (8 x 8 lanes); 8 x 8 blocks of a 64 x 64 tile for 32 < T <= 64,
 //   * softmax row statistics by wave64 shuffles across the 8 lanes that share a row,
 //   * P (and dS) parked in LDS for the second product.
 // HBM traffic is exactly one read of qkv (+ dctx) and one write of ctx (dqkv): the kernel is
@@ -16,8 +16,14 @@
 #include "common.hpp"
 
 namespace {
-constexpr int TP = 32;   // padded tile edge
-constexpr int PP = 36;   // pitch (floats) of the 32 x 32 probability tiles
+// Tile edge TP = 8 TB: the 8 x 8 lanes of the wavefront own TB x TB blocks of the TP x TP score tile.  TB = 4 (T <= 32: titles of 30 tokens,
+// histories of 20 / 10) is the shape everything on the benchmarked path has; TB = 8 (T <= 64) serves the reference's longer inputs --
+// abstracts / bodies of 50 tokens (T/parameters.py:43-44), longer behaviour sequences -- on the same code.
+template <int TB>
+struct Tile {
+    static constexpr int TP = 8 * TB;      // padded tile edge
+    static constexpr int PP = TP + 4;      // pitch (floats) of the TP x TP probability tiles
+};
 
 struct AttnArgs {
     const void* qkv;
@@ -32,12 +38,12 @@ struct AttnArgs {
     int total_rows;    // rows of the packed buffers (>= cu[n_seq]); the spare ones are zero-filled by the blocks behind the grid
 };
 
-// stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to 32 rows
-template <typename T, int DC>
+// stage a [T x DC] chunk (columns col0 + d0 .. of the packed row) into LDS as fp32, zero-padded to TP rows
+template <typename T, int DC, int TB>
 __device__ __forceinline__ void stage_chunk(const T* __restrict__ src, size_t row0, int pitch, int col0, int d0, int dh,
                                             int Tlen, float* __restrict__ dst) {
     constexpr int P = DC + 4;
-    constexpr int VEC = TP * DC / 4;  // float4 slots
+    constexpr int VEC = Tile<TB>::TP * DC / 4;  // float4 slots
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < VEC / 64; ++i) {
@@ -50,37 +56,38 @@ __device__ __forceinline__ void stage_chunk(const T* __restrict__ src, size_t ro
 }
 
 // s[r][c] += sum_d X[i0 + r][d] * Y[j0 + c][d] over one staged chunk
-template <int DC>
+template <int DC, int TB>
 __device__ __forceinline__ void block_dot(const float* __restrict__ X, const float* __restrict__ Y, int i0, int j0,
-                                          float (&s)[4][4]) {
+                                          float (&s)[TB][TB]) {
     constexpr int P = DC + 4;
 #pragma unroll 4
     for (int d = 0; d < DC; d += 4) {
-        float4 x[4], y[4];
+        float4 x[TB], y[TB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const float4*>(X + (i0 + r) * P + d);
+        for (int r = 0; r < TB; ++r) x[r] = *reinterpret_cast<const float4*>(X + (i0 + r) * P + d);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const float4*>(Y + (j0 + c) * P + d);
+        for (int c = 0; c < TB; ++c) y[c] = *reinterpret_cast<const float4*>(Y + (j0 + c) * P + d);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < TB; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < TB; ++c)
                 s[r][c] += x[r].x * y[c].x + x[r].y * y[c].y + x[r].z * y[c].z + x[r].w * y[c].w;
     }
 }
 
-// masked, scaled softmax of the lane's 4 x 4 block; rows are shared by the 8 lanes with equal (lane >> 3)
-__device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, int Tlen, int causal, float scale,
+// masked, scaled softmax of the lane's TB x TB block; rows are shared by the 8 lanes with equal (lane >> 3)
+template <int TB>
+__device__ __forceinline__ void block_softmax(float (&s)[TB][TB], int i0, int j0, int Tlen, int causal, float scale,
                                               float mask_value, const float* __restrict__ keep_row) {
-    float keep[4];
+    float keep[TB];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) keep[c] = (j0 + c < Tlen) ? keep_row[j0 + c] : 0.f;
+    for (int c = 0; c < TB; ++c) keep[c] = (j0 + c < Tlen) ? keep_row[j0 + c] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TB; ++r) {
         const int i = i0 + r;
         float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < TB; ++c) {
             const int j = j0 + c;
             const bool kept = (keep[c] != 0.f) && (!causal || j <= i);
             // reference arithmetic: score * scale + additive mask (the large-magnitude mask absorbs the score)
@@ -93,7 +100,7 @@ __device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, 
         m = fmaxf(m, __shfl_xor(m, 4, 64));
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < TB; ++c) {
             const float e = (j0 + c < Tlen) ? expf(s[r][c] - m) : 0.f;
             s[r][c] = e;
             sum += e;
@@ -103,39 +110,48 @@ __device__ __forceinline__ void block_softmax(float (&s)[4][4], int i0, int j0, 
         sum += __shfl_xor(sum, 4, 64);
         const float inv = (i < Tlen) ? 1.0f / sum : 0.f;   // padded query rows contribute nothing downstream
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[r][c] *= inv;
+        for (int c = 0; c < TB; ++c) s[r][c] *= inv;
     }
 }
 
-// dropout keep-mask of the lane's 4 x 4 block: element index ((tile * 32 + i) * 32 + j)
-__device__ __forceinline__ void block_drop_mask(const DropRng& d, uint64_t tile, int i0, int j0, float (&m)[4][4]) {
+// dropout keep-mask of the lane's TB x TB block: element index ((tile * TP + i) * TP + j)  (TP = 32 for T <= 32: the same stream as
+// the MFMA kernels of attention_mfma.hip draw)
+template <int TB>
+__device__ __forceinline__ void block_drop_mask(const DropRng& d, uint64_t tile, int i0, int j0, float (&m)[TB][TB]) {
+    constexpr uint64_t TP = Tile<TB>::TP;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bool kp[4];
-        drop_keep_vec<4>(d, (tile * 32 + (uint64_t)(i0 + r)) * 32 + (uint64_t)j0, kp);   // j0 is a multiple of 4: even start
+    for (int r = 0; r < TB; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) m[r][c] = kp[c] ? d.inv_keep : 0.f;
-    }
+        for (int c4 = 0; c4 < TB; c4 += 4) {
+            bool kp[4];
+            drop_keep_vec<4>(d, (tile * TP + (uint64_t)(i0 + r)) * TP + (uint64_t)(j0 + c4), kp);   // j0 + c4 is a multiple of 4: even start
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[r][c4 + c] = kp[c] ? d.inv_keep : 0.f;
+        }
 }
 
-// o[r][0..CW-1] = sum_k W[k][w0 + r] * V[k][c0 .. c0+CW-1]   (W stored [k][32 + pad]: "weights by row k");
-// CW = DC / 8 columns per lane so that the 8 x 8 lane grid covers a [32 x DC] output chunk exactly.
-template <int DC>
+// o[r][0..CW-1] = sum_k W[k][w0 + r] * V[k][c0 .. c0+CW-1]   (W stored [k][TP + pad]: "weights by row k");
+// CW = DC / 8 columns per lane so that the 8 x 8 lane grid covers a [TP x DC] output chunk exactly.
+template <int DC, int TB>
 __device__ __forceinline__ void block_pv(const float* __restrict__ W, const float* __restrict__ V, int w0, int c0,
-                                         int klen, float (&o)[4][DC / 8]) {
-    constexpr int P = DC + 4, CW = DC / 8;
+                                         int klen, float (&o)[TB][DC / 8]) {
+    constexpr int P = DC + 4, CW = DC / 8, PP = Tile<TB>::PP;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < TB; ++r)
 #pragma unroll
         for (int c = 0; c < CW; ++c) o[r][c] = 0.f;
     for (int k = 0; k < klen; ++k) {
-        const float4 w = *reinterpret_cast<const float4*>(W + k * PP + w0);
-        const float wr[4] = {w.x, w.y, w.z, w.w};
+        float wr[TB];
+#pragma unroll
+        for (int r4 = 0; r4 < TB; r4 += 4) {
+            const float4 w = *reinterpret_cast<const float4*>(W + k * PP + w0 + r4);
+            wr[r4] = w.x; wr[r4 + 1] = w.y; wr[r4 + 2] = w.z; wr[r4 + 3] = w.w;
+        }
 #pragma unroll
         for (int q = 0; q < CW / 4; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(V + k * P + c0 + 4 * q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < TB; ++r) {
                 o[r][4 * q + 0] += wr[r] * v.x; o[r][4 * q + 1] += wr[r] * v.y;
                 o[r][4 * q + 2] += wr[r] * v.z; o[r][4 * q + 3] += wr[r] * v.w;
             }
@@ -143,11 +159,11 @@ __device__ __forceinline__ void block_pv(const float* __restrict__ W, const floa
     }
 }
 
-template <typename T, int CW>
+template <typename T, int CW, int TB>
 __device__ __forceinline__ void store_rows(T* __restrict__ dst, size_t row0, int pitch, int col, int r0, int Tlen,
-                                           int dcol, int dh, const float (&o)[4][CW]) {
+                                           int dcol, int dh, const float (&o)[TB][CW]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TB; ++r) {
         if (r0 + r < Tlen) {
             T* p = dst + (row0 + r0 + r) * (size_t)pitch + col;
 #pragma unroll
@@ -159,162 +175,215 @@ __device__ __forceinline__ void store_rows(T* __restrict__ dst, size_t row0, int
     }
 }
 
-template <typename T, int DC>
+// row r of a TB-wide register block -> TB consecutive floats of an LDS row
+template <int TB>
+__device__ __forceinline__ void put_row(float* __restrict__ dst, const float (&v)[TB]) {
+#pragma unroll
+    for (int c = 0; c < TB; c += 4) *reinterpret_cast<float4*>(dst + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+}
+
+template <int DC, int TB>
+constexpr size_t attn_fwd_lds() { return (size_t)(2 * Tile<TB>::TP * (DC + 4) + Tile<TB>::TP * Tile<TB>::PP) * sizeof(float); }
+template <int DC, int TB>
+constexpr size_t attn_bwd_lds() { return (size_t)(4 * Tile<TB>::TP * (DC + 4) + 3 * Tile<TB>::TP * Tile<TB>::PP) * sizeof(float); }
+
+template <typename T, int DC, int TB>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a) {
     if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows of a bucket-padded packed layout: ctx = 0 there
         zero_dead_rows(a.ctx, a.cu, a.n_seq, a.total_rows, (size_t)a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
         return;
     }
     a.drop = drop_resolve(a.drop);
-    constexpr int P = DC + 4;
+    constexpr int P = DC + 4, TP = Tile<TB>::TP, PP = Tile<TB>::PP;
     const int seq_ = blockIdx.x / a.n_heads;
     const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
     if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
-    __shared__ __attribute__((aligned(16))) float sA[TP * P];
-    __shared__ __attribute__((aligned(16))) float sB[TP * P];
-    __shared__ __attribute__((aligned(16))) float sPt[TP * PP];   // P transposed: [key j][query i]
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* sA = smem_f;
+    float* sB = sA + TP * P;
+    float* sPt = sB + TP * P;          // P transposed: [key j][query i]
     const int lane = threadIdx.x;
-    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
-    const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+    const int i0 = (lane >> 3) * TB, j0 = (lane & 7) * TB;
 
-    float s[4][4];
+    float s[TB][TB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < TB; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[r][c] = 0.f;
+        for (int c = 0; c < TB; ++c) s[r][c] = 0.f;
     for (int d0 = 0; d0 < a.dh; d0 += DC) {
-        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sA);
-        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sB);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sA);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sB);
         __syncthreads();
-        block_dot<DC>(sA, sB, i0, j0, s);
+        block_dot<DC, TB>(sA, sB, i0, j0, s);
         __syncthreads();
     }
-    block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+    block_softmax<TB>(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
     if (a.drop.thresh) {
-        float m[4][4];
-        block_drop_mask(a.drop, blockIdx.x, i0, j0, m);
+        float m[TB][TB];
+        block_drop_mask<TB>(a.drop, blockIdx.x, i0, j0, m);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < TB; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s[r][c] *= m[r][c];
+            for (int c = 0; c < TB; ++c) s[r][c] *= m[r][c];
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        *reinterpret_cast<float4*>(sPt + (j0 + c) * PP + i0) = make_float4(s[0][c], s[1][c], s[2][c], s[3][c]);
+    for (int c = 0; c < TB; ++c) {
+        float col[TB];
+#pragma unroll
+        for (int r = 0; r < TB; ++r) col[r] = s[r][c];
+        put_row<TB>(sPt + (j0 + c) * PP + i0, col);
+    }
     __syncthreads();
     T* ctx = reinterpret_cast<T*>(a.ctx);
     constexpr int CW = DC / 8;
     const int c0 = (lane & 7) * CW;
     for (int d0 = 0; d0 < a.dh; d0 += DC) {
-        stage_chunk<T, DC>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sA);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sA);
         __syncthreads();
-        float o[4][CW];
-        block_pv<DC>(sPt, sA, i0, c0, a.T, o);
-        store_rows<T, CW>(ctx, row0, H, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        float o[TB][CW];
+        block_pv<DC, TB>(sPt, sA, i0, c0, a.T, o);
+        store_rows<T, CW, TB>(ctx, row0, H, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
         __syncthreads();
     }
 }
 
 // Backward: recomputes P from Q, K (no forward state kept), then
 //   dV = P^T dO, dP = dO V^T, dS = P o (dP - rowsum(P o dP)) * scale, dQ = dS K, dK = dS^T Q.
-template <typename T, int DC>
+template <typename T, int DC, int TB>
 __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
     if ((int)blockIdx.x >= a.n_seq * a.n_heads) {      // spare rows: dqkv = 0 there
         zero_dead_rows(a.dqkv, a.cu, a.n_seq, a.total_rows, (size_t)3 * a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
         return;
     }
     a.drop = drop_resolve(a.drop);
-    constexpr int P = DC + 4;
+    constexpr int P = DC + 4, TP = Tile<TB>::TP, PP = Tile<TB>::PP;
     const int seq_ = blockIdx.x / a.n_heads;
     const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
     if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
-    __shared__ __attribute__((aligned(16))) float sQ[TP * P];
-    __shared__ __attribute__((aligned(16))) float sK[TP * P];
-    __shared__ __attribute__((aligned(16))) float sV[TP * P];
-    __shared__ __attribute__((aligned(16))) float sO[TP * P];
-    __shared__ __attribute__((aligned(16))) float sP[TP * PP];    // P   [query i][key j]
-    __shared__ __attribute__((aligned(16))) float sS[TP * PP];    // dS  [query i][key j]
-    __shared__ __attribute__((aligned(16))) float sSt[TP * PP];   // dS^T [key j][query i]
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* sQ = smem_f;
+    float* sK = sQ + TP * P;
+    float* sV = sK + TP * P;
+    float* sO = sV + TP * P;
+    float* sP = sO + TP * P;           // P   [query i][key j]
+    float* sS = sP + TP * PP;          // dS  [query i][key j]
+    float* sSt = sS + TP * PP;         // dS^T [key j][query i]
     const int lane = threadIdx.x;
-    const int seq = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const int head = blockIdx.x % a.n_heads;
     const int H = a.n_heads * a.dh, pitch = 3 * H;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* dctx = reinterpret_cast<const T*>(a.ctx);
     T* dqkv = reinterpret_cast<T*>(a.dqkv);
-    const int i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+    const int i0 = (lane >> 3) * TB, j0 = (lane & 7) * TB;
 
-    float s[4][4], dp[4][4];
+    float s[TB][TB], dp[TB][TB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < TB; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s[r][c] = 0.f; dp[r][c] = 0.f; }
+        for (int c = 0; c < TB; ++c) { s[r][c] = 0.f; dp[r][c] = 0.f; }
     for (int d0 = 0; d0 < a.dh; d0 += DC) {
-        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
-        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
-        stage_chunk<T, DC>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sV);
-        stage_chunk<T, DC>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, 2 * H + head * a.dh, d0, a.dh, a.T, sV);
+        stage_chunk<T, DC, TB>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
         __syncthreads();
-        block_dot<DC>(sQ, sK, i0, j0, s);
-        block_dot<DC>(sO, sV, i0, j0, dp);
+        block_dot<DC, TB>(sQ, sK, i0, j0, s);
+        block_dot<DC, TB>(sO, sV, i0, j0, dp);
         __syncthreads();
     }
-    block_softmax(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
-    float msk[4][4];
+    block_softmax<TB>(s, i0, j0, a.T, a.causal, a.scale, a.mask_value, a.key_keep + row0);
+    float msk[TB][TB];
     if (a.drop.thresh) {
-        block_drop_mask(a.drop, blockIdx.x, i0, j0, msk);
+        block_drop_mask<TB>(a.drop, blockIdx.x, i0, j0, msk);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < TB; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dp[r][c] *= msk[r][c];   // dP = dP_dropped o mask / (1 - p)
+            for (int c = 0; c < TB; ++c) dp[r][c] *= msk[r][c];   // dP = dP_dropped o mask / (1 - p)
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < TB; ++r) {
         float delta = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) delta += s[r][c] * dp[r][c];
+        for (int c = 0; c < TB; ++c) delta += s[r][c] * dp[r][c];
         delta += __shfl_xor(delta, 1, 64);
         delta += __shfl_xor(delta, 2, 64);
         delta += __shfl_xor(delta, 4, 64);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dp[r][c] = s[r][c] * (dp[r][c] - delta) * a.scale;   // dp now holds dS
+        for (int c = 0; c < TB; ++c) dp[r][c] = s[r][c] * (dp[r][c] - delta) * a.scale;   // dp now holds dS
         if (a.drop.thresh) {   // dV uses the DROPPED probabilities
 #pragma unroll
-            for (int c = 0; c < 4; ++c) s[r][c] *= msk[r][c];
+            for (int c = 0; c < TB; ++c) s[r][c] *= msk[r][c];
         }
-        *reinterpret_cast<float4*>(sP + (i0 + r) * PP + j0) = make_float4(s[r][0], s[r][1], s[r][2], s[r][3]);
-        *reinterpret_cast<float4*>(sS + (i0 + r) * PP + j0) = make_float4(dp[r][0], dp[r][1], dp[r][2], dp[r][3]);
+        put_row<TB>(sP + (i0 + r) * PP + j0, s[r]);
+        put_row<TB>(sS + (i0 + r) * PP + j0, dp[r]);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        *reinterpret_cast<float4*>(sSt + (j0 + c) * PP + i0) = make_float4(dp[0][c], dp[1][c], dp[2][c], dp[3][c]);
+    for (int c = 0; c < TB; ++c) {
+        float col[TB];
+#pragma unroll
+        for (int r = 0; r < TB; ++r) col[r] = dp[r][c];
+        put_row<TB>(sSt + (j0 + c) * PP + i0, col);
+    }
     __syncthreads();
     constexpr int CW = DC / 8;
     const int c0 = (lane & 7) * CW;
     for (int d0 = 0; d0 < a.dh; d0 += DC) {
-        stage_chunk<T, DC>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
-        stage_chunk<T, DC>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
-        stage_chunk<T, DC>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, head * a.dh, d0, a.dh, a.T, sQ);
+        stage_chunk<T, DC, TB>(qkv, row0, pitch, H + head * a.dh, d0, a.dh, a.T, sK);
+        stage_chunk<T, DC, TB>(dctx, row0, H, head * a.dh, d0, a.dh, a.T, sO);
         __syncthreads();
-        float o[4][CW];
+        float o[TB][CW];
         // dQ[i0..][cols] = sum_j dS^T[j][i0..] * K[j][cols]
-        block_pv<DC>(sSt, sK, i0, c0, a.T, o);
-        store_rows<T, CW>(dqkv, row0, pitch, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        block_pv<DC, TB>(sSt, sK, i0, c0, a.T, o);
+        store_rows<T, CW, TB>(dqkv, row0, pitch, head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
         // dK[j..][cols] = sum_i dS[i][j..] * Q[i][cols]   (the lane's row block i0 doubles as its key block)
-        block_pv<DC>(sS, sQ, i0, c0, a.T, o);
-        store_rows<T, CW>(dqkv, row0, pitch, H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        block_pv<DC, TB>(sS, sQ, i0, c0, a.T, o);
+        store_rows<T, CW, TB>(dqkv, row0, pitch, H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
         // dV[j..][cols] = sum_i P[i][j..] * dO[i][cols]
-        block_pv<DC>(sP, sO, i0, c0, a.T, o);
-        store_rows<T, CW>(dqkv, row0, pitch, 2 * H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
+        block_pv<DC, TB>(sP, sO, i0, c0, a.T, o);
+        store_rows<T, CW, TB>(dqkv, row0, pitch, 2 * H + head * a.dh + d0 + c0, i0, a.T, d0 + c0, a.dh, o);
         __syncthreads();
     }
+}
+
+constexpr int T_MAX = Tile<8>::TP;     // 64
+
+// one launch of the VALU kernels (forward: d-chunks of 64; backward: of 32), tile edge by sequence length
+template <bool BWD>
+int launch_valu(const morec_attn_desc* d, const AttnArgs& a, dim3 grid, hipStream_t s) {
+    const bool big = d->T > Tile<4>::TP;
+    if (!by_dtype(d->dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            if constexpr (!BWD) {
+                if (big) {
+                    static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<T, 64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_fwd_lds<64, 8>());
+                    (void)rc;
+                    hipLaunchKernelGGL((attn_fwd_kernel<T, 64, 8>), grid, dim3(64), (attn_fwd_lds<64, 8>()), s, a);
+                } else {
+                    hipLaunchKernelGGL((attn_fwd_kernel<T, 64, 4>), grid, dim3(64), (attn_fwd_lds<64, 4>()), s, a);
+                }
+            } else {
+                if (big) {
+                    static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<T, 32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_bwd_lds<32, 8>());
+                    (void)rc;
+                    hipLaunchKernelGGL((attn_bwd_kernel<T, 32, 8>), grid, dim3(64), (attn_bwd_lds<32, 8>()), s, a);
+                } else {
+                    hipLaunchKernelGGL((attn_bwd_kernel<T, 32, 4>), grid, dim3(64), (attn_bwd_lds<32, 4>()), s, a);
+                }
+            }
+        }))
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
 }
 
 int check_desc(const morec_attn_desc* d) {
     if (!d) return MOREC_E_ARG;
     if (d->n_seq <= 0 || d->T <= 0 || d->n_heads <= 0 || d->dh <= 0) return MOREC_E_ARG;
-    if (d->T > TP) return MOREC_E_UNSUPPORTED;
+    if (d->T > T_MAX) return MOREC_E_UNSUPPORTED;      // 64: the larger of the two tile edges
     if (d->dh % 8) return MOREC_E_ALIGN;
     if (d->p_drop < 0.f || d->p_drop >= 1.f) return MOREC_E_ARG;
     if (d->total_rows < 0 || d->spare_rows_max < 0 || (d->spare_rows_max > 0 && (!d->cu_seqlens || d->total_rows <= 0))) return MOREC_E_ARG;
@@ -356,13 +425,8 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
-    if (!by_dtype(d->dtype, [&](auto* t) {
-            using T = MOREC_TAG_T(t);
-            hipLaunchKernelGGL((attn_fwd_kernel<T, 64>), grid, block, 0, s, a);
-        }))
-        return MOREC_E_DTYPE;
-    MOREC_CHECK_LAUNCH();
-    return MOREC_OK;
+    (void)block;
+    return launch_valu<false>(d, a, grid, s);
 }
 
 extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const float* key_keep, const void* dctx,
@@ -377,13 +441,8 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
-    if (!by_dtype(d->dtype, [&](auto* t) {
-            using T = MOREC_TAG_T(t);
-            hipLaunchKernelGGL((attn_bwd_kernel<T, 32>), grid, block, 0, s, a);
-        }))
-        return MOREC_E_DTYPE;
-    MOREC_CHECK_LAUNCH();
-    return MOREC_OK;
+    (void)block;
+    return launch_valu<true>(d, a, grid, s);
 }
 
 // morec_attn_bwd + the bias gradient of the fused q|k|v projection: dbias[3 H] += column sums of the dqkv rows (MFMA path: fp32

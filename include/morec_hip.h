@@ -198,7 +198,9 @@ int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dt
 
 /* ------------------------------------------------------------------------------------------
  * Small-tile multi-head attention on packed projections qkv[M, 3*H] = [Q | K | V], M = n_seq*T,
- * H = n_heads*dh, T <= 32.  scores = (q.k) * scale + (key masked ? mask_value : 0), causal option,
+ * H = n_heads*dh, T <= 64 (T <= 32 with head width % 32 == 0 and 16-bit storage: the matrix-core kernels; otherwise -- fp32, other
+ * head widths, 32 < T <= 64: abstracts / bodies of 50 tokens, longer behaviour sequences -- the exact-fp32 VALU kernels; T > 64:
+ * MOREC_E_UNSUPPORTED).  scores = (q.k) * scale + (key masked ? mask_value : 0), causal option,
  * softmax, ctx = P.V.   SASRec: T/model/encoders.py:24-27 + T/model/modules.py:27-31 (causal,
  * mask_value -1e9, scale 1/sqrt(d_k)).  BERT: HF BertSelfAttention eager (mask_value finfo.min).
  * key_keep: float [n_seq, T], nonzero = attend.  One wavefront per (sequence, head).
@@ -209,7 +211,7 @@ typedef struct {
     float scale, mask_value;
     int dtype;
     float p_drop;      /* dropout on the attention probabilities (0 = off) */
-    uint64_t seed;     /* element index = ((seq * n_heads + head) * 32 + i) * 32 + j */
+    uint64_t seed;     /* element index = ((seq * n_heads + head) * TP + i) * TP + j, TP = 32 for T <= 32, 64 above */
     const int32_t* cu_seqlens;   /* NULL: every sequence owns T rows.  Otherwise int32[n_seq + 1] (device): sequence s owns rows
                                     cu_seqlens[s] .. cu_seqlens[s+1]-1 (<= T of them) -- the unpadded ("varlen") token layout in
                                     which [PAD] positions are not materialised at all; key_keep is then indexed by packed row */

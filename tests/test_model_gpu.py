@@ -199,17 +199,22 @@ def test_g6_full_size_golden(golden_dir, name, dtype):
     print(f"g6 {name} {dtype}: worst grad-norm rel err {worst:.2e}")
 
 
-def test_oracle_midsize_all_grads():
-    """Every parameter gradient of a mid-size modal model against the CPU oracle (autograd over the restatement)."""
+@pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16")])
+def test_oracle_midsize_all_grads(S, T, dt):
+    """Every parameter gradient of a mid-size modal model against the CPU oracle (autograd over the restatement).  (40, 50): behaviour
+    sequences and texts longer than the 32-row attention tile -- abstracts / bodies of 50 tokens (T/parameters.py:43-44) -- run on the
+    64 x 64 form of the VALU attention kernels (16-bit modes included: they fall back to it)."""
     import morec_oracle as orc
-    S, D, T, item_num, B = 10, 128, 30, 300, 12
+    D, item_num, B = 128, 300, 12
     shape = BertShape(vocab_size=2000, hidden_size=128, num_hidden_layers=3, num_attention_heads=4,
                       intermediate_size=512, max_position_embeddings=64)
-    rng = np.random.default_rng(7)
+    # (seed: with 7 the (40, 50) data puts one SASRec FFN pre-activation within rounding of 0, where ReLU' of the GPU and of the CPU oracle
+    # legitimately disagree -- w_1's gradient, and only it, was off by one element's worth: scripts/longseq_probe.py)
+    rng = np.random.default_rng(7 if S == 10 else 11)
     pop = rng.random(item_num + 1) + 0.05
     pop[1:] /= pop[1:].sum()
     pop[0] = 1
-    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=128, compute_dtype="fp32")
+    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=128, compute_dtype=dt, num_words_title=T)
     m = load_det(Model(args, item_num, True, HipBertModel(shape), pop)).to(DEV)
     m.eval()
     content = np.zeros((item_num + 1, 2 * T), dtype=np.int64)
@@ -225,21 +230,28 @@ def test_oracle_midsize_all_grads():
         lm[b, S + 1 - L:] = 1
     items = content[ids.reshape(-1)]
     loss = m(torch.from_numpy(ids).to(DEV).view(-1), torch.from_numpy(items).to(DEV), torch.from_numpy(lm).to(DEV), DEV)
-    loss.backward()
+    gs = 256.0 if dt == "fp16" else 1.0        # fp16: a fixed loss scale (the training step's GradScaler does it dynamically)
+    (loss * gs).backward()
+    tol_l, tol_g = (5e-5, 5e-4) if dt == "fp32" else (2e-3, 2e-2)
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     ref = orc.model_forward(p, torch.from_numpy(ids).view(-1), torch.from_numpy(items), torch.from_numpy(lm), pop,
                             max_seq_len=S, embedding_dim=D, n_heads=2, use_modal=True, bert_heads=4)
     ref.backward()
-    assert abs(loss.item() - ref.item()) < 5e-5
+    assert abs(loss.item() - ref.item()) < tol_l, (loss.item(), ref.item())
     for k, v in m.named_parameters():
         if "pooler" in k:
             continue
         gref = p[k].grad
+        got = v.grad.float() / gs
         scale = gref.abs().max().item()
         if scale < 1e-7:   # e.g. key biases: mathematically zero gradient
-            assert v.grad.abs().max().item() < 1e-5, k
+            assert got.abs().max().item() < (1e-5 if dt == "fp32" else 1e-3), k
             continue
-        assert relerr(v.grad.cpu().numpy(), gref.numpy()) < 5e-4, k
+        if dt == "fp32":
+            assert relerr(got.cpu().numpy(), gref.numpy()) < tol_g, k
+        else:      # 16-bit storage: pre-activations within half an ulp of 0 flip ReLU' for single elements -- bound the error of the whole tensor
+            e = float((got.cpu().double() - gref.double()).norm() / gref.double().norm())
+            assert e < tol_g, (k, e)
 
 
 def test_mask_with_holes_keeps_the_padded_layout(golden_dir):
