@@ -151,3 +151,26 @@ def test_fp32_gemm_mode_is_scoped_and_resolved_from_compute_dtype():
     except KeyError:
         pass
     assert ops.FP32_GEMM == "exact"
+
+
+def test_weight_gradient_split_fills_the_chip_once():
+    """``engine._splitk``: token chunks x 256 x 256 tiles of dW = dY^T X never exceed the 256 CUs in the large-tile regime (260 workgroups
+    -- 10 tiles x 26 chunks, the [1152, 384] gradient of Swin-T stage 3 -- ran as two rounds), and BERT-base keeps its measured splits."""
+    from idvs.morec_amd.engine import _cdiv, _splitk
+    for N, K, M, want in [(768, 768, 55000, 28), (2304, 768, 55000, 9), (3072, 768, 55000, 7), (768, 3072, 55000, 7)]:
+        assert _splitk(N, K, M) == want
+    shapes = [(c * a, c * b, rows) for c, rows in ((96, 2207744), (192, 551936), (384, 137984), (768, 34496), (128, 1103872), (256, 275968),
+                                                   (512, 68992), (1024, 17248)) for a, b in ((3, 1), (1, 1), (4, 1), (1, 4))]
+    for N, K, M in shapes:
+        s = _splitk(N, K, M)
+        big = _cdiv(N, 256) * _cdiv(K, 256)
+        assert s >= 1
+        if big * s >= 192:                      # the 256 x 256-tile kernel's regime
+            assert big * s <= 256, (N, K, M, s)
+
+
+def test_run_defaults_to_the_reference_arithmetic():
+    """``run.py --compute_dtype`` defaults to fp16: the reference's autocast + GradScaler step (T/run.py:210,242-247), the mode bench.py times."""
+    from idvs.morec_amd.parameters import parse_args
+    a = parse_args([])
+    assert a.compute_dtype == "fp16" and a.collate_workers == 2
