@@ -64,6 +64,7 @@ _SIGS = {
     "morec_strerror": (C.c_char_p, [C.c_int]),
     "morec_version": (C.c_int, []),
     "morec_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "morec_stream_wait_stream": (C.c_int, [_P, _P]),
     "morec_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P]),
     "morec_gemm_nt_colsum": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "morec_gemm_colsum_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),

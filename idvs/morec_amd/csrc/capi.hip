@@ -1,4 +1,5 @@
 // capi.hip -- library-level entry points: error strings, version, hardware probe.
+#include <atomic>
 #include "common.hpp"
 
 extern "C" const char* morec_strerror(int code) {
@@ -24,6 +25,29 @@ extern "C" int morec_dropout_seed_source(const void* dev_u64) {
     if (reinterpret_cast<uintptr_t>(dev_u64) & 7u) return MOREC_E_ALIGN;
     g_drop_seed_src = reinterpret_cast<const uint64_t*>(dev_u64);
     return MOREC_OK;
+}
+
+// `waiting` will not run anything issued after this call before everything issued to `signal` so far has finished: hipEventRecord +
+// hipStreamWaitEvent on an event of a process-wide ring (256 entries, created on first use on the calling thread's device; re-recording an
+// event that an earlier wait captured is well defined: the wait refers to the record that was current when it was issued).  What
+// torch.cuda.Stream.wait_stream does, in ONE foreign call on raw handles -- the weight-gradient stream is ordered behind the backward chain
+// once per dW launch (17 ... 57 times per step), and on the launch-bound configurations the host path IS the step time.  Capturable.
+extern "C" int morec_stream_wait_stream(void* waiting, void* signal) {
+    static hipEvent_t ring[256];
+    static std::atomic<unsigned> next{0};
+    static const hipError_t made = [] {
+        for (auto& e : ring) {
+            const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }();
+    if (made != hipSuccess) return (int)made;
+    hipEvent_t e = ring[next.fetch_add(1u, std::memory_order_relaxed) & 255u];
+    hipError_t rc = hipEventRecord(e, reinterpret_cast<hipStream_t>(signal));
+    if (rc != hipSuccess) return (int)rc;
+    rc = hipStreamWaitEvent(reinterpret_cast<hipStream_t>(waiting), e, 0);
+    return rc == hipSuccess ? MOREC_OK : (int)rc;
 }
 
 // Probe: (a) MFMA fragment/accumulator layouts with recognisable integer data, (b) what each lane of

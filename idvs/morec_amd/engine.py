@@ -130,9 +130,12 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
         if side is None:
             ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))    # transpose-free: ds_read_b64_tr_b16 fragments
             return None, None
-        side.wait_stream(torch.cuda.current_stream(dy.device))     # dy (and the zeroed arena) are produced on the main stream
-        with torch.cuda.stream(side):
-            ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M))
+        # dy (and the zeroed arena) are produced on the main stream.  Raw handles, one foreign call for the ordering, none for a stream context:
+        # 17 ... 57 of these per step, and on the launch-bound configurations the host path is the step time (scripts/host_profile.py:
+        # wait_stream + `with torch.cuda.stream(side)` were 0.95 of BERT-tiny's 1.9 ms)
+        sh = side.cuda_stream
+        ops.stream_wait_stream(sh)
+        ops.gemm_tn_(dy, x, dw, split_m=_splitk(N, K, M), stream=sh)
         WgradStream._keep.setdefault(dy.device, []).extend((dy, x))
         WgradStream._dirty.add(dy.device)
         return None, None
@@ -146,9 +149,9 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
         if side is None:
             ops.gemm_tn_x3_(dy3, x3, dw, N, K, split_m=_splitk(N, K, M))
             return None, None
-        side.wait_stream(torch.cuda.current_stream(dy.device))
-        with torch.cuda.stream(side):
-            ops.gemm_tn_x3_(dy3, x3, dw, N, K, split_m=_splitk(N, K, M))
+        sh = side.cuda_stream
+        ops.stream_wait_stream(sh)
+        ops.gemm_tn_x3_(dy3, x3, dw, N, K, split_m=_splitk(N, K, M), stream=sh)
         WgradStream._keep.setdefault(dy.device, []).extend((dy3, x3))
         WgradStream._dirty.add(dy.device)
         return None, None

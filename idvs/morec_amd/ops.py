@@ -26,11 +26,24 @@ def code(dt: torch.dtype) -> int:
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Raw device address (an int: every pointer parameter is declared ``c_void_p`` in ``_lib._SIGS``, ctypes converts; no wrapper object per argument)."""
+    return None if t is None else t.data_ptr()
+
+
+# the handle without building a torch.cuda.Stream object per launch (MOREC_STREAM_OBJ=1: the object path, for A/B timing of the host side)
+_raw_stream = None if os.environ.get("MOREC_STREAM_OBJ") == "1" else getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's CURRENT stream on the current device as a ``hipStream_t`` (every launch goes there; ~700 calls per training step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+def stream_wait_stream(waiting, signal=None):
+    """``waiting`` (raw handle) runs nothing issued later before what ``signal`` (default: torch's current stream) holds now has finished."""
+    check(_lib.lib().morec_stream_wait_stream(waiting, _stream() if signal is None else signal), "morec_stream_wait_stream")
 
 
 def _dev(t):
@@ -122,7 +135,7 @@ def split_cached(t):
     return s
 
 
-def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1):
+def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1, stream=None):
     """out[N, K] += dy^T x for fp32 dy [M, N], x [M, K] given as their [hi | hi | lo] splits (bf16 [M, 3 N], [M, 3 K]): the three
     products hi.hi + hi.lo + lo.hi on the transposing bf16 GEMM, reading the column blocks in place (row pitch 3 N / 3 K)."""
     _dev(dy3), _dev(x3)
@@ -134,7 +147,7 @@ def gemm_tn_x3_(dy3, x3, out, N, K, split_m=1):
     py, px = dy3.data_ptr(), x3.data_ptr()
     for sy, sx in ((0, 0), (0, 2), (2, 0)):      # (hi, hi), (hi, lo), (lo, hi)
         check(_lib.lib().morec_gemm_tn(C.c_void_p(py + 2 * sy * N), C.c_void_p(px + 2 * sx * K), _p(out), M, N, K, 3 * N, 3 * K, out.stride(0),
-                                       BF16, split_m, 1, _p(ws), _stream()), "morec_gemm_tn")
+                                       BF16, split_m, 1, _p(ws), _stream() if stream is None else stream), "morec_gemm_tn")
     return out
 
 
@@ -152,6 +165,9 @@ def _scratch(cache, device, need, floor):
         ws = torch.empty(max(need, floor), device=device, dtype=torch.float32)
         cache[device] = ws
     return ws
+
+
+_GEMM_DESCS = {}
 
 
 def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=None, dact=ACT_NONE, dact_in=None,
@@ -173,7 +189,10 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
         a = split_cached(a) if whole else split_bf16x3(a, 2, M, K, lda)
         b = split_bf16x3(b, 1, N, K, ldb)
         K, lda, ldb = 3 * K, 3 * K, 3 * K
-    d = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
+    key = (M, N, K, lda, ldb, ldc, a.dtype, out.dtype, act, dact, accumulate, split_k, alpha, bool(aux_deriv))
+    d = _GEMM_DESCS.get(key)
+    if d is None:      # the descriptor is read during the call only: one object per distinct launch shape, reused for the life of the process
+        d = _GEMM_DESCS[key] = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
     if colsum_out is not None:
         need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4
         ws = _scratch(_CS_WS, a.device, need, 4 * 1024 * 1024)
@@ -215,9 +234,10 @@ def mlp_dact_recompute(dy, w2t, x, w1, b1, colsum_out=None):
 _TN_WS = {}
 
 
-def gemm_tn_(dy, x, out, split_m=1, accumulate=True, slabs=True):
+def gemm_tn_(dy, x, out, split_m=1, accumulate=True, slabs=True, stream=None):
     """out[N, K] (+)= dy[M, N]^T @ x[M, K] (bf16 operands, fp32 out) without transposed copies.  ``slabs``: reduce the
-    split-m partials through a reusable fp32 workspace (deterministic) instead of fp32 atomics."""
+    split-m partials through a reusable fp32 workspace (deterministic) instead of fp32 atomics.  ``stream``: raw handle of the stream to
+    launch on (default: torch's current stream) -- the weight-gradient stream, without a ``torch.cuda.stream`` context per launch."""
     _dev(dy), _dev(x)
     M, N = dy.shape
     K = x.shape[1]
@@ -226,7 +246,7 @@ def gemm_tn_(dy, x, out, split_m=1, accumulate=True, slabs=True):
         need = _lib.lib().morec_gemm_tn_workspace_bytes(N, K, split_m) // 4
         ws = _scratch(_TN_WS, dy.device, need, 20 * 1024 * 1024)
     check(_lib.lib().morec_gemm_tn(_p(dy), _p(x), _p(out), M, N, K, dy.stride(0), x.stride(0), out.stride(0), code(dy.dtype),
-                                   split_m, int(accumulate), _p(ws), _stream()), "morec_gemm_tn")
+                                   split_m, int(accumulate), _p(ws), _stream() if stream is None else stream), "morec_gemm_tn")
     return out
 
 

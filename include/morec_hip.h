@@ -34,7 +34,8 @@
  *      launch or between steps, not concurrently with launches;
  *   2. with "gemm8p_tail_split" = 1 only: one device scratch allocation per stream (the only memory the library ever allocates);
  *   3. morec_comm handles (below): created and destroyed by the caller;
- *   4. the dropout seed source (morec_dropout_seed_source): one device pointer, NULL by default.
+ *   4. the dropout seed source (morec_dropout_seed_source): one device pointer, NULL by default;
+ *   5. the ring of 256 events behind morec_stream_wait_stream (created on first use, never destroyed).
  */
 #ifndef MOREC_HIP_H
 #define MOREC_HIP_H
@@ -399,6 +400,10 @@ typedef struct {
  * change between the forward and the backward launch that regenerate the same mask.  Stands where torch's global CUDA RNG state stands in
  * the reference (nn.Dropout under T/run.py:307-314 `setup_seed`). */
 int morec_dropout_seed_source(const void* dev_u64);
+/* Stream `waiting` runs nothing issued after this call before the work issued to stream `signal` so far has finished (event record + stream
+ * wait on an internal ring of 256 events; capturable; one device per process).  torch.cuda.Stream.wait_stream in one foreign call: orders the
+ * weight-gradient stream behind the backward chain per dW launch.  No reference counterpart (autograd runs its backward on one stream). */
+int morec_stream_wait_stream(void* waiting, void* signal);
 /* *sp = {step, loss_scale = init_scale, everything else clear} (init_scale = 1: no scaling, bf16 / fp32 modes) */
 int morec_step_params_init(morec_step_params* sp, float init_scale, int step, void* stream);
 /* sp->found_inf |= any element of grad[0 .. n) is inf or NaN   (GradScaler.unscale_'s found_inf; the division by S is left to AdamW) */
