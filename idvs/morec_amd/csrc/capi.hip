@@ -16,7 +16,7 @@ extern "C" const char* morec_strerror(int code) {
     return "unknown morec error";
 }
 
-extern "C" int morec_version(void) { return 104; }
+extern "C" int morec_version(void) { return 105; }
 
 // Process-wide dropout seed source (see morec_hip.h): a device uint64 folded into every dropout / DropPath stream at kernel entry.
 static const uint64_t* g_drop_seed_src = nullptr;
