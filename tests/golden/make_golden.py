@@ -292,6 +292,39 @@ def g6(out):
     np.savez_compressed(os.path.join(out, "g6_full_scalars.npz"), **res)
 
 
+def g18(out):
+    """Inputs longer than 32 positions on both towers: behaviour sequences of 40 items (--max_seq_len 40) and texts of 50 tokens (the
+    reference's abstracts / bodies: T/parameters.py:43-44, news_attributes) through the reference's own Model -- what the 64 x 64 form of the
+    attention kernels is pinned to.  BERT-tiny shape, D = 128."""
+    res = {}
+    tiny_kw = dict(vocab_size=30522, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                   intermediate_size=512, max_position_embeddings=512)
+    name, B, wdim = "long", 6, 128
+    S, D, T, item_num = 40, 128, 50, 300
+    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=wdim, num_words_title=T)
+    pop = zipf_pop(item_num, "pop.g18")
+    m = build_modal(args, tiny_kw, item_num, pop)
+    content = synth_titles("g18", item_num, T, 30522)
+    ids, log_mask = synth_batch("g18", B, S, item_num, ragged=True)
+    ids[0] = det_randint("g18.full", (S + 1,), 1, item_num + 1)          # one user with a FULL history: all 40 rows of the score tile are live
+    log_mask[0] = 1.0
+    items = torch.from_numpy(content[ids.reshape(-1)])
+    m.zero_grad()
+    loss = m(torch.from_numpy(ids).view(-1), items, torch.from_numpy(log_mask), "cpu")
+    loss.backward()
+    res[f"{name}.cfg"] = np.array([S, D, T, item_num, B])
+    res[f"{name}.content"], res[f"{name}.ids"], res[f"{name}.log_mask"], res[f"{name}.pop"] = content, ids, log_mask, pop
+    res[f"{name}.loss"] = np.float32(loss.item())
+    with torch.no_grad():
+        vec = m.bert_encoder(items)
+    res[f"{name}.item_vec_probe"] = vec[:, :8].numpy()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            res[f"{name}.grad_norm.{k}"] = np.float64(p.grad.double().norm().item())
+    print("g18 long loss", loss.item(), "titles of", int((content[1:, T:] != 0).sum(1).max()), "tokens at most,", int(log_mask.sum(1).max()), "behaviours at most")
+    np.savez_compressed(os.path.join(out, "g18_long_scalars.npz"), **res)
+
+
 def g7(out):
     import logging
     import torch.distributed as dist
@@ -356,7 +389,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7, g10=g10_keys)
+    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7, g10=g10_keys, g18=g18)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue

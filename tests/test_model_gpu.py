@@ -93,7 +93,7 @@ def _modal(golden, prefix, bert_name, dtype):
     S, D, T, item_num, B = (int(v) for v in golden[prefix + "cfg"])
     shape = BertShape.named(bert_name)
     args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=shape.hidden_size, compute_dtype=dtype,
-                     bert_model_load="bert_" + bert_name)
+                     bert_model_load="bert_" + bert_name, num_words_title=T)
     m = load_det(Model(args, item_num, True, HipBertModel(shape), golden[prefix + "pop"])).to(DEV)
     m.eval()   # goldens were captured with dropout off (RNG streams cannot match the reference's)
     ids = torch.from_numpy(golden[prefix + "ids"]).to(DEV)
@@ -197,6 +197,37 @@ def test_g6_full_size_golden(golden_dir, name, dtype):
         worst = max(worst, err)
         assert err < (2e-3 if f32 else 2e-1), (pn, got, float(gd[k]))
     print(f"g6 {name} {dtype}: worst grad-norm rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_g18_long_sequences_golden(golden_dir, dtype):
+    """S = 40 behaviours, T = 50 tokens (abstracts / bodies: T/parameters.py:43-44) against the reference's own loss and gradient norms
+    (tests/golden/make_golden.py --only g18): both towers run the 64 x 64 form of the attention kernels."""
+    gd = g(golden_dir, "g18_long_scalars.npz")
+    m, ids, items, lm, (S, D, T, item_num, B) = _modal(gd, "long.", "tiny", dtype)
+    assert S > 32 and T > 32
+    f32 = dtype == "fp32"
+    with torch.no_grad():
+        vec = m.bert_encoder(items)
+    real = (gd["long.ids"].reshape(-1) != 0)
+    assert relerr(vec[:, :8].float().cpu().numpy()[real], gd["long.item_vec_probe"][real]) < (5e-5 if f32 else 1e-2)
+    loss = m(ids, items, lm, DEV)
+    ref = float(gd["long.loss"])
+    print(f"g18 {dtype}: loss {loss.item():.6f} ref {ref:.6f}")
+    assert abs(loss.item() - ref) < (1e-4 if f32 else 5e-3)
+    gs = 1.0 if f32 else 256.0
+    (loss * gs).backward()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in [k for k in gd.files if k.startswith("long.grad_norm.")]:
+        pn = k[len("long.grad_norm."):]
+        if "pooler" in pn:
+            continue
+        got = named[pn].grad.double().norm().item() / gs
+        err = abs(got - float(gd[k])) / (float(gd[k]) + (1e-4 if f32 else 1e-2))   # key biases: true gradient is 0
+        worst = max(worst, err)
+        assert err < (2e-3 if f32 else 5e-2), (pn, got, float(gd[k]))
+    print(f"g18 {dtype}: worst grad-norm rel err {worst:.2e}")
 
 
 @pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16")])

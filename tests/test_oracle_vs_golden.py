@@ -183,6 +183,26 @@ def test_g6_full_size_scalars(golden_dir, name):
     assert abs(loss.item() - float(g[f"{name}.loss"])) < 5e-5
 
 
+def test_g18_long_sequences(golden_dir):
+    """Behaviour sequences of 40 items and texts of 50 tokens (the reference's abstracts / bodies, T/parameters.py:43-44): loss and every
+    gradient norm of the oracle against the reference's own numbers (what the 64 x 64 attention kernels are checked against on the GPU)."""
+    g = _load(golden_dir, "g18_long_scalars.npz")
+    S, D, T, item_num, B = (int(v) for v in g["long.cfg"])
+    assert S > 32 and T > 32 and int(g["long.log_mask"].sum(1).max()) == S
+    bert = BertShape.named("tiny")
+    p = _modal_state(S, D, item_num, bert)
+    items = torch.from_numpy(g["long.content"][g["long.ids"].reshape(-1)])
+    loss = orc.model_forward(p, torch.from_numpy(g["long.ids"]).view(-1), items, torch.from_numpy(g["long.log_mask"]), g["long.pop"],
+                             max_seq_len=S, embedding_dim=D, n_heads=2, use_modal=True, bert_heads=bert.num_attention_heads)
+    assert abs(loss.item() - float(g["long.loss"])) < 2e-5
+    loss.backward()
+    for k in [k for k in g.files if k.startswith("long.grad_norm.")]:
+        name = k[len("long.grad_norm."):]
+        if "pooler" in name:
+            continue
+        assert abs(p[name].grad.double().norm().item() - float(g[k])) <= 2e-4 * float(g[k]) + 2e-5, name
+
+
 def test_g7_eval(golden_dir):
     g = _load(golden_dir, "g7_eval.npz")
     S, D, item_num, U = (int(v) for v in g["cfg"])
