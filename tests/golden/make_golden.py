@@ -325,6 +325,36 @@ def g18(out):
     np.savez_compressed(os.path.join(out, "g18_long_scalars.npz"), **res)
 
 
+def g19(out):
+    """Two text attributes per item -- title (30 tokens) and abstract (50 tokens), ``--news_attributes title,abstract`` -- through the
+    reference's Bert_Encoder (T/model/encoders.py:76-117: each attribute through the SAME Text_Encoder, item vector = their mean)."""
+    res = {}
+    tiny_kw = dict(vocab_size=30522, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                   intermediate_size=512, max_position_embeddings=512)
+    B, S, D, Tt, Ta, item_num = 6, 20, 128, 30, 50, 300
+    args = make_args(max_seq_len=S, embedding_dim=D, word_embedding_dim=128, news_attributes=["title", "abstract"],
+                     num_words_title=Tt, num_words_abstract=Ta)
+    pop = zipf_pop(item_num, "pop.g19")
+    m = build_modal(args, tiny_kw, item_num, pop)
+    content = np.concatenate([synth_titles("g19t", item_num, Tt, 30522), synth_titles("g19a", item_num, Ta, 30522)], axis=1)   # [title ids | title mask | abstract ids | abstract mask]
+    ids, log_mask = synth_batch("g19", B, S, item_num, ragged=True)
+    items = torch.from_numpy(content[ids.reshape(-1)])
+    m.zero_grad()
+    loss = m(torch.from_numpy(ids).view(-1), items, torch.from_numpy(log_mask), "cpu")
+    loss.backward()
+    res["two.cfg"] = np.array([S, D, Tt, Ta, item_num, B])
+    res["two.content"], res["two.ids"], res["two.log_mask"], res["two.pop"] = content, ids, log_mask, pop
+    res["two.loss"] = np.float32(loss.item())
+    with torch.no_grad():
+        vec = m.bert_encoder(items)
+    res["two.item_vec_probe"] = vec[:, :8].numpy()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            res[f"two.grad_norm.{k}"] = np.float64(p.grad.double().norm().item())
+    print("g19 two attributes: loss", loss.item(), "row width", content.shape[1])
+    np.savez_compressed(os.path.join(out, "g19_two_attributes.npz"), **res)
+
+
 def g7(out):
     import logging
     import torch.distributed as dist
@@ -389,7 +419,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7, g10=g10_keys, g18=g18)
+    todo = dict(g1=g1_g4_g9, g2=g2, g3=g3, g5=g5_g8, g6=g6, g7=g7, g10=g10_keys, g18=g18, g19=g19)
     for k, fn in todo.items():
         if a.only and k not in a.only.split(","):
             continue
