@@ -191,7 +191,9 @@ def gemm_nt(a, b, *, bias=None, act=ACT_NONE, out=None, out_dtype=None, aux_out=
         K, lda, ldb = 3 * K, 3 * K, 3 * K
     key = (M, N, K, lda, ldb, ldc, a.dtype, out.dtype, act, dact, accumulate, split_k, alpha, bool(aux_deriv))
     d = _GEMM_DESCS.get(key)
-    if d is None:      # the descriptor is read during the call only: one object per distinct launch shape, reused for the life of the process
+    if d is None:      # the descriptor is read during the call only: one object per distinct launch shape, reused while the cache holds it
+        if len(_GEMM_DESCS) >= 8192:      # the unpadded token layout makes M a per-batch number: bound the cache instead of growing with the run
+            _GEMM_DESCS.clear()
         d = _GEMM_DESCS[key] = GemmDesc(M, N, K, lda, ldb, ldc, code(a.dtype), code(out.dtype), act, dact, accumulate, split_k, alpha, int(bool(aux_deriv)))
     if colsum_out is not None:
         need = _lib.lib().morec_gemm_colsum_workspace_bytes(M, N) // 4
