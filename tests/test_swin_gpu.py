@@ -292,7 +292,8 @@ def _full_size_swin_golden(golden_dir, dt, name, fname, tag):
         ref = float(G[f"grad_norm.{n}"])
         got = float(p.grad.double().norm()) / gs
         worst = max(worst, abs(got - ref) / (ref + 1e-9)) if ref > 1e-6 else worst
-        assert abs(got - ref) <= (5e-3 if not half else 1.5e-1 * k16) * ref + (1e-6 if not half else 1e-3), (n, got, ref)
+        kg = 1.0 if dt == "bf16" else 0.25      # fp16 gradient norms: measured worst 2.4e-2 (g13) / 2.7e-3 (g15); a quarter of the bf16 bound
+        assert abs(got - ref) <= (5e-3 if not half else 1.5e-1 * kg) * ref + (1e-6 if not half else 1e-3), (n, got, ref)
     print(f"{tag} {name} {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
 
 
