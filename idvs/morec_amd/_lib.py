@@ -78,6 +78,7 @@ _SIGS = {
     "morec_cast": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
     "morec_split_bf16x3": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_act_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, C.c_int, _P]),
+    "morec_scaled_sum": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, C.c_int, _P]),
     "morec_colsum": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "morec_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P, C.c_int, _P]),

@@ -328,3 +328,43 @@ extern "C" int morec_act_bwd(const void* dy, const void* pre, void* out, size_t 
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
+
+// out = scale * (x0 + x1 + x2), elementwise with fp32 arithmetic (x1 / x2 may be null): the mean over a news item's text attributes
+// (T/model/encoders.py:113-116: torch.mean(torch.stack(text_vectors, dim=1), dim=1)) and, with one input, its backward (d / k).
+template <typename T>
+__global__ void scaled_sum_kernel(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2, T* __restrict__ out,
+                                  size_t n4, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float a[4], b[4];
+        io<T>::load4(x0 + i * 4, a);
+        if (x1) {
+            io<T>::load4(x1 + i * 4, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += b[k];
+        }
+        if (x2) {
+            io<T>::load4(x2 + i * 4, b);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += b[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] *= scale;
+        io<T>::store4(out + i * 4, a);
+    }
+}
+
+extern "C" int morec_scaled_sum(const void* x0, const void* x1, const void* x2, void* out, size_t n, float scale, int dtype, void* stream) {
+    if (!x0 || !out || (x2 && !x1)) return MOREC_E_ARG;
+    if (n == 0) return MOREC_OK;
+    if (n % 4) return MOREC_E_ALIGN;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!by_dtype(dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            hipLaunchKernelGGL((scaled_sum_kernel<T>), dim3(blocks), dim3(256), 0, s, (const T*)x0, (const T*)x1, (const T*)x2, (T*)out, n4, scale);
+        }))
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}

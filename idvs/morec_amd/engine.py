@@ -48,6 +48,13 @@ class DropCfg:
     def site(self, k: int) -> int:
         return (self.seed + (k + 1) * _GOLD) & 0xFFFFFFFFFFFFFFFF
 
+    def stream(self, j: int) -> "DropCfg":
+        """Independent dropout streams for the j-th pass of the SAME stack within one step (one pass per text attribute,
+        ``T/model/encoders.py:107-112``: every call of the shared Text_Encoder draws its own masks); j = 0 is this configuration itself."""
+        if j == 0 or (self.p_hidden <= 0 and self.p_attn <= 0):
+            return self
+        return DropCfg(self.p_hidden, self.p_attn, (self.seed ^ (j * 0xC2B2AE3D27D4EB4F)) & 0xFFFFFFFFFFFFFFFF)
+
 
 NO_DROP = DropCfg()
 

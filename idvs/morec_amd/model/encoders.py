@@ -92,12 +92,14 @@ class Bert_Encoder(nn.Module):
             raise NotImplementedError("OPT mean-pooling encoder (T/model/encoders.py:31-50) is outside the hot path")
         self.text_encoders = nn.ModuleDict({
             'title': Text_Encoder(bert_model, args.embedding_dim, args.word_embedding_dim, resolve_dtype(args))})
-        self.newsname = [name for name in set(args.news_attributes) & {'title', 'abstract', 'body'}]
+        # (the reference iterates a set intersection, i.e. in hash order; the mean over attributes does not depend on it -- a fixed order
+        # keeps the fp32 sum of three passes identical across processes)
+        self.newsname = [name for name in ('title', 'abstract', 'body') if name in set(args.news_attributes)]
 
     def encode(self, news, drop: DropCfg = NO_DROP):
         vecs = [self.text_encoders['title'].encode(
-            torch.narrow(news, 1, self.attributes2start[name], self.attributes2length[name]).contiguous(), drop)
-            for name in self.newsname]
+            torch.narrow(news, 1, self.attributes2start[name], self.attributes2length[name]).contiguous(), drop.stream(j))
+            for j, name in enumerate(self.newsname)]
         return vecs[0] if len(vecs) == 1 else torch.mean(torch.stack(vecs, dim=1), dim=1)
 
     def forward(self, news):

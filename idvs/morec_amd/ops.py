@@ -280,6 +280,19 @@ def act_bwd(dy, pre, act):
     return out
 
 
+def scaled_sum(xs, scale, out=None):
+    """``scale * (xs[0] + xs[1] + xs[2])`` with fp32 arithmetic and one rounding (``morec_scaled_sum``; one to three same-shaped tensors):
+    the mean over the text attributes of an item (``T/model/encoders.py:113-116``) and, with one input, the gradient each attribute's
+    encoder pass receives."""
+    xs = [_dev(x) for x in xs]
+    assert 1 <= len(xs) <= 3 and all(x.shape == xs[0].shape and x.dtype == xs[0].dtype for x in xs)
+    if out is None:
+        out = torch.empty_like(xs[0])
+    ptr = [_p(x) for x in xs] + [None] * (3 - len(xs))
+    check(_lib.lib().morec_scaled_sum(ptr[0], ptr[1], ptr[2], _p(out), xs[0].numel(), float(scale), code(xs[0].dtype), _stream()), "morec_scaled_sum")
+    return out
+
+
 def colsum_(x, out, M=None, N=None, ld=None):
     """out[N] += column sums of x[M, N] (fp32 atomics)."""
     _dev(x)

@@ -45,9 +45,11 @@ def setup_seed(seed):   # T/run.py:307-314
     random.seed(seed)
 
 
-def synthetic_dataset(n_users, n_items, S, T, seed=12345, full_len=False):
+def synthetic_dataset(n_users, n_items, S, T, seed=12345, full_len=False, extra_T=()):
     """MIND-shaped synthetic data in the structures ``read_behaviors`` / ``get_doc_input_bert`` return.
-    ``full_len``: every user has raw history S + 3 (train sequence of S + 1 items: the throughput shape of bench.py)."""
+    ``full_len``: every user has raw history S + 3 (train sequence of S + 1 items: the throughput shape of bench.py).
+    ``extra_T``: token counts of further text attributes (abstract, body: ``--news_attributes title,abstract``); their [ids | mask]
+    blocks follow the title's in the item rows, as ``get_doc_input_bert`` + ``T/run.py:86-90`` lay them out."""
     rng = np.random.default_rng(seed)
     w = 1.0 / np.arange(1, n_items + 1)
     w /= w.sum()
@@ -70,6 +72,16 @@ def synthetic_dataset(n_users, n_items, S, T, seed=12345, full_len=False):
     toks[:, 0] = 101
     toks[np.arange(n_items), tl - 1] = 102
     content[1:, :T], content[1:, T:] = toks, valid
+    for Tx in extra_T:
+        blk = np.zeros((n_items + 1, 2 * Tx), dtype=np.int64)
+        tl = rng.integers(8, Tx + 1, n_items)
+        toks = rng.integers(1000, 30522, (n_items, Tx))
+        valid = np.arange(Tx)[None, :] < tl[:, None]
+        toks = np.where(valid, toks, 0)
+        toks[:, 0] = 101
+        toks[np.arange(n_items), tl - 1] = 102
+        blk[1:, :Tx], blk[1:, Tx:] = toks, valid
+        content = np.concatenate((content, blk), axis=1)
     return n_items, content, users_train, users_valid, users_test, hist_valid, hist_test, pop
 
 
@@ -84,6 +96,78 @@ class _BatchSet(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         return self.make(self.batches[i])
+
+
+class BatchMaker:
+    """Host side of one batch -- the work of ``T/run.py:111-124``'s DataLoader workers -- as a PICKLABLE object: it holds the user
+    lists, the item table (numpy) and flags, no closure over the model or the stepper, so DataLoader worker processes can be started by
+    fork, forkserver or spawn alike.  ``text_attrs`` (fused step, text tower): [(name, first column, width)] of the [ids | mask] blocks of
+    the item rows -- the collate then also prepares the unpadded token layout's index vectors (``engine.token_packing_host``), one tuple
+    for a single attribute, one per attribute otherwise.  ``pin``: False inside worker processes (they must not touch the HIP runtime;
+    the loader's pin thread page-locks), None = page-lock when a GPU is present."""
+
+    def __init__(self, users, users_train, item_content, S, use_modal, *, bce=False, item_num=0, neg_seed=0, text_attrs=None, pad_to=0, pin=None):
+        self.users, self.users_train, self.item_content, self.S, self.use_modal = users, users_train, item_content, S, use_modal
+        self.bce, self.item_num, self.neg_seed = bce, item_num, neg_seed
+        self.text_attrs, self.pad_to, self.pin = list(text_attrs or []), pad_to, pin
+        self._neg_rng = None
+
+    def __call__(self, batch_idx):
+        batch_users = [self.users[i] for i in batch_idx]
+        if self.bce:      # bce_text/main-end2end/run.py:224-237
+            if self._neg_rng is None:
+                self._neg_rng = np.random.default_rng(self.neg_seed)
+            items, log_mask = collate_bce_batch(self.users_train, batch_users, self.item_content, self.S, self.item_num, self.use_modal, self._neg_rng)
+            return None, items, log_mask, None
+        ids, items, log_mask = collate_train_batch(self.users_train, batch_users, self.item_content, self.S, self.use_modal)
+        pack = None
+        if self.text_attrs:      # the collate's share of the unpadded token layout (no host sync in the step)
+            rows = items.view(-1, items.size(-1))
+            packs = []
+            for _, a0, aw in self.text_attrs:
+                h = aw // 2
+                packs.append(engine.token_packing_host(rows[:, a0 + h:a0 + aw], rows[:, a0:a0 + h], pad_to=self.pad_to, pin=self.pin))
+            pack = packs[0] if len(packs) == 1 else (None if any(x is None for x in packs) else tuple(packs))
+        return ids, items, log_mask, pack
+
+
+class _EpochBatchSet(torch.utils.data.Dataset):
+    """Dataset of a loader that lives for the whole run (``persistent_workers``): a sample key is ``(epoch, b)`` and the worker derives
+    that epoch's index batches itself (``epoch_batches``: the reference's DistributedSampler + batching, cached per epoch), so nothing has
+    to be sent to the workers when an epoch starts."""
+
+    def __init__(self, make, n_users, batch_size, world, rank):
+        self.make, self.n_users, self.batch_size, self.world, self.rank = make, n_users, batch_size, world, rank
+        self._ep, self._batches = None, None
+
+    def __getitem__(self, key):
+        ep, b = key
+        if ep != self._ep:
+            self._batches, self._ep = epoch_batches(self.n_users, self.batch_size, self.world, self.rank, ep), ep
+        return self.make(self._batches[b])
+
+
+class _EpochSampler:
+    def __init__(self):
+        self.keys = []
+
+    def set_epoch(self, epoch, n_batches):
+        self.keys = [(epoch, b) for b in range(n_batches)]
+
+    def __iter__(self):
+        return iter(self.keys)
+
+    def __len__(self):
+        return len(self.keys)
+
+
+def _to_device(t, dev):
+    """Tensors of a (possibly nested) tuple to the device, asynchronously; None entries stay."""
+    if t is None:
+        return None
+    if isinstance(t, (tuple, list)):
+        return tuple(_to_device(x, dev) for x in t)
+    return t.to(dev, non_blocking=True)
 
 
 class BatchPrefetcher:
@@ -236,8 +320,10 @@ def train(args, use_modal, local_rank):
     if not vision and hasattr(args, "CV_model_load"):
         del args.CV_model_load                # `Model` picks the vision tower by the presence of this attribute (V/model/model.py:24-29)
     if args.synthetic > 0:
+        extra_T = [w for n, w in (("abstract", args.num_words_abstract), ("body", args.num_words_body))
+                   if use_modal and not vision and n in args.news_attributes]
         item_num, content, users_train, users_valid, users_test, hist_valid, hist_test, pop = synthetic_dataset(
-            args.synthetic, args.synthetic_items, S, T, full_len=bool(getattr(args, "synthetic_full_len", False)))
+            args.synthetic, args.synthetic_items, S, T, full_len=bool(getattr(args, "synthetic_full_len", False)), extra_T=extra_T)
         item_content = content if use_modal else np.arange(item_num + 1)
         if vision:      # decoded uint8 images; a real run passes --images_npy (what the LMDB of V/data_utils holds after Resize)
             R = args.CV_resize
@@ -289,7 +375,6 @@ def train(args, use_modal, local_rank):
     if bce and (args.fused_step or vision):
         raise SystemExit("--loss bce runs on the drop-in autograd path with the text / ID towers (bce_text/main-end2end)")
     model = (BceModel(args, item_num, use_modal, bert) if bce else Model(args, item_num, use_modal, bert, pop)).to(local_rank)
-    neg_rng = np.random.default_rng(777 + rank)
     users = list(users_train.keys())
     model_dir = model_dir_of(args, world)
     ckpt, start_epoch, is_early_stop = None, 0, True
@@ -323,6 +408,8 @@ def train(args, use_modal, local_rank):
                             graph=(world == 1 and bool(getattr(args, "graph", False))))
         if ckpt is not None and ckpt.get("optimizer") is not None:     # T/run.py:193-195
             stepper.load_optimizer_state_dict(ckpt["optimizer"])
+        if ckpt is not None and ckpt.get("scaler_state"):              # (the reference never saves its GradScaler: an empty dict there)
+            stepper.load_scaler_state_dict(ckpt["scaler_state"])
         wrapped = model
     else:
         wrapped = DDP(model, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True) if world > 1 else model
@@ -339,37 +426,37 @@ def train(args, use_modal, local_rank):
     # T/run.py:210: `scaler = torch.cuda.amp.GradScaler()` -- engaged for the fp16 compute dtype (bf16 / fp32 gradients need no scaling);
     # the fused step keeps the same protocol in its device block (TrainStep.sp)
     scaler = torch.amp.GradScaler("cuda", enabled=True) if (optimizer is not None and args.compute_dtype == "fp16") else None
+    if scaler is not None and ckpt is not None and ckpt.get("scaler_state"):
+        scaler.load_state_dict(ckpt["scaler_state"])
     best, step = 0.0, 0
     max_epoch, early_stop_epoch, early_stop_count = 0, args.epoch, 0
     early_stop_gap = 6 if vision else 10                               # T/run.py:221 / V/run.py:185
+    on_device = hasattr(item_content, "device_batch")       # LMDB catalogue: the collate itself issues device work (decode -> H2D -> resize)
+    n_workers = 0 if (bce or on_device) else max(0, int(getattr(args, "collate_workers", 0)))
+    depth = 0 if on_device else int(getattr(args, "prefetch", 2))
+    # host side of a batch: a picklable object over numpy tables and flags (no closure over the model / stepper)
+    make_batch = BatchMaker(users, users_train, item_content, S, use_modal, bce=bce, item_num=item_num, neg_seed=777 + rank,
+                            text_attrs=(stepper.text_attrs if (stepper is not None and use_modal and not vision) else None),
+                            pad_to=512 if (stepper is not None and stepper.graph) else 0, pin=False if n_workers > 0 else None)
+    loader, sampler = None, None
+    if n_workers > 0:
+        # T/run.py:111-124: DataLoader worker processes + its pin-memory thread; one "sample" = one whole collated batch.  ONE loader for
+        # the run (persistent workers: no re-start per epoch); the start method is explicit -- "fork" by default (the item table is shared
+        # copy-on-write; the workers never touch the HIP runtime), MOREC_LOADER_CONTEXT=forkserver | spawn for runtimes that mind a fork
+        # of a process holding HIP / RCCL threads (everything the workers need pickles)
+        sampler = _EpochSampler()
+        loader = torch.utils.data.DataLoader(_EpochBatchSet(make_batch, len(users), args.batch_size, world, rank), batch_size=None, sampler=sampler,
+                                             num_workers=n_workers, pin_memory=True, prefetch_factor=max(2, depth // max(1, n_workers)),
+                                             persistent_workers=True, multiprocessing_context=os.environ.get("MOREC_LOADER_CONTEXT", "fork"))
     for ep in range(1, args.epoch + 1):
         now_epoch = start_epoch + ep
         model.train()
         # T/run.py:114,123-124,230: DistributedSampler(seed 0 + epoch, padded to a multiple of the world size) + a loader
         # without drop_last -- the last batch of an epoch is short
         batches = epoch_batches(len(users), args.batch_size, world, rank, now_epoch)
-        n_workers = 0 if (bce or hasattr(item_content, "device_batch")) else max(0, int(getattr(args, "collate_workers", 0)))
-
-        def make_batch(batch_idx):      # host side of a batch (collate thread): T/run.py:111-124's DataLoader work
-            batch_users = [users[i] for i in batch_idx]
-            if bce:      # bce_text/main-end2end/run.py:224-237
-                items, log_mask = collate_bce_batch(users_train, batch_users, item_content, S, item_num, use_modal, neg_rng)
-                return None, items, log_mask, None
-            ids, items, log_mask = collate_train_batch(users_train, batch_users, item_content, S, use_modal)
-            pack = None
-            if args.fused_step and use_modal and not vision:      # the collate's share of the unpadded token layout (no host sync in the step)
-                rows = items.view(-1, items.size(-1))
-                pack = engine.token_packing_host(rows[:, T:], rows[:, :T], pad_to=512 if (stepper is not None and stepper.graph) else 0,
-                                                 pin=False if n_workers > 0 else None)
-            return ids, items, log_mask, pack
-
-        on_device = hasattr(item_content, "device_batch")       # LMDB catalogue: the collate itself issues device work (decode -> H2D -> resize)
-        depth = 0 if on_device else int(getattr(args, "prefetch", 2))
         feeder = None
-        if n_workers > 0 and not on_device:
-            # T/run.py:111-124: DataLoader worker processes + its pin-memory thread; one "sample" = one whole collated batch
-            loader = torch.utils.data.DataLoader(_BatchSet(make_batch, batches), batch_size=None, shuffle=False, num_workers=n_workers,
-                                                 pin_memory=True, prefetch_factor=max(2, depth // max(1, n_workers)))
+        if loader is not None:
+            sampler.set_epoch(now_epoch, len(batches))
             source = enumerate(loader)
         else:
             feeder = BatchPrefetcher(make_batch, batches, depth) if depth > 0 else None
@@ -398,8 +485,7 @@ def train(args, use_modal, local_rank):
                 if args.max_steps and step >= args.max_steps:
                     break
                 continue
-            if pack is not None:
-                pack = tuple(t.to(local_rank, non_blocking=True) for t in pack)
+            pack = _to_device(pack, local_rank)
             ids, items, log_mask = (ids.to(local_rank, non_blocking=True), items.to(local_rank, non_blocking=True),
                                     log_mask.to(local_rank, non_blocking=True))
             if vision:
@@ -449,7 +535,8 @@ def train(args, use_modal, local_rank):
             best, max_epoch, early_stop_count = hit10, now_epoch, 0
             if use_modal and rank == 0:                                 # T/run.py:265-267: modal runs only, rank 0 only
                 save_model(now_epoch, model, model_dir, stepper if stepper is not None else optimizer, torch.get_rng_state(),
-                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None, None, Log,
+                           torch.cuda.get_rng_state() if torch.cuda.is_available() else None,
+                           stepper if (stepper is not None and stepper.sp is not None) else scaler, Log,      # loss-scaler state: exact fp16 resumption
                            extra={"morec_drop_calls": int(getattr(model, "_drop_calls", 0))})
         else:
             early_stop_count += 1
@@ -466,10 +553,13 @@ def main(argv=None):
     args = parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="[%(levelname)s %(asctime)s] %(message)s")
     local_rank = args.local_rank if args.local_rank >= 0 else int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("MOREC_DEVICE_INDEX") is not None:      # several ranks on ONE device (functional tests of the N > 1 driver over gloo)
+        local_rank = int(os.environ["MOREC_DEVICE_INDEX"])
     torch.cuda.set_device(local_rank)
     if int(os.environ.get("WORLD_SIZE", 1)) > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")                         # RCCL on ROCm (T/run.py:321)
+        # RCCL on ROCm (T/run.py:321: backend 'nccl'); MOREC_DIST_BACKEND=gloo is for tests that put two ranks on one GPU, which RCCL refuses
+        dist.init_process_group(backend=os.environ.get("MOREC_DIST_BACKEND", "nccl"))
     setup_seed(12345)
     use_modal = "modal" in args.item_tower
     if dist.is_initialized() and dist.get_rank() != 0:

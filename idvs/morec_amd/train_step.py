@@ -137,7 +137,8 @@ class TrainStep:
         defaults 65536, x2 after 2000 clean steps, x0.5 and a skipped step on inf / NaN), kept in a device block (``ops.StepParams``).
         Engaged automatically for ``compute_dtype == "fp16"``; ``loss_scale=`` a number forces it on for the other dtypes too
         (``MOREC_STEP_PARAMS=1``: with scale 1) -- the device-resident step state without the scaling.
-        ``defer_update`` (``MOREC_DEFER_UPDATE=1``; text tower with a step block, i.e. the fp16 mode): ``step()`` leaves the AdamW launches of
+        ``defer_update`` (default: ``MOREC_DEFER_UPDATE``, off when unset -- ``run.py`` turns it ON for its ``--fused_step`` loop, whose epochs
+        end in a device synchronisation before anything reads the parameters; text tower with a step block, i.e. the fp16 mode): ``step()`` leaves the AdamW launches of
         step t on the side stream, slice by slice in the order the forward pass reads the parameters, and the forward pass of step t + 1
         waits for each slice right before its first use -- the update (28 B / parameter of HBM traffic) then runs under the MFMA-bound
         encoder GEMMs of the next step instead of behind the overflow verdict at the end of its own (the other dtypes hide it under their
@@ -166,13 +167,15 @@ class TrainStep:
                           [f"{x}.{k}" for x in ("query", "key", "value") for k in ("weight", "bias")])
         _check_qkv_groups(train, list(named), r"\.attention\.((?:q|k|v)_proj\.(?:weight|bias))$",
                           [f"{x}_proj.{k}" for x in ("q", "k", "v") for k in ("weight", "bias")])
+        self.text_attrs = []
         if model.use_modal and not self.vision:
-            # the fused path encodes ONE attribute (what every reference launcher builds, T/model/encoders.py:95-103); with
-            # title,abstract[,body] the token row is [ids | mask | ids | mask ...] and must be narrowed per attribute and averaged
-            # (encoders.py:107-116) -- the drop-in Model does that, TrainStep does not
-            attrs = list(getattr(model.args, "news_attributes", ["title"]))
-            if attrs != ["title"]:
-                raise ValueError(f"TrainStep supports news_attributes == ['title'] (got {attrs}); use the autograd path for several attributes")
+            # T/model/encoders.py:76-116: the token row is [ids | mask] per attribute, title | abstract | body; every attribute goes through
+            # the SAME Text_Encoder and the item vector is the mean of the passes.  (name, first column, width) in that fixed order.
+            enc = model.bert_encoder
+            self.text_attrs = [(n, int(enc.attributes2start[n]), int(enc.attributes2length[n])) for n in ("title", "abstract", "body")
+                               if n in set(enc.newsname)]
+            if not self.text_attrs:
+                raise ValueError(f"no text attribute among news_attributes = {list(getattr(model.args, 'news_attributes', []))}")
         if self.vision:
             # V/run.py:121-130, applied literally to the installed-HF names: 'image_net' parameters whose name contains
             # 'fc' or 'classifier' (the replaced head -- and, with transformers >= 5 naming, mlp.fc1 / mlp.fc2) train
@@ -429,13 +432,23 @@ class TrainStep:
             E, saved_b = swin_engine.swin_forward(p, prep_b, self.swin_shape, sample_items, self.dtype, True, swin_engine.IN,
                                                   d_item, m.training)
         elif m.use_modal:
-            if sample_items.shape[1] != 2 * m.args.num_words_title:
-                raise ValueError(f"token rows of width {sample_items.shape[1]}: expected [input_ids | attention_mask] of the title, "
-                                 f"2 x {m.args.num_words_title}")
+            width = sum(w for _, _, w in self.text_attrs)
+            if sample_items.shape[1] != width:
+                raise ValueError(f"token rows of width {sample_items.shape[1]}: expected [input_ids | attention_mask] per attribute "
+                                 f"({', '.join(f'{n}: {w}' for n, _, w in self.text_attrs)}) = {width}")
             prep_b = engine.bert_prepare(p, self.bert_layers, self.dtype, engine.TE, self.sh)
-            E, saved_b = engine.bert_forward(p, prep_b, sample_items, self.bert_heads, self.dtype, True, self.bert_eps,
-                                             self.bert_mask_value, engine.TE, d_item, grad_from=self.bert_grad_from,
-                                             packing=None if dedup else token_packing, on_use=self._await_params if self._param_ready else None)
+            n_attr = len(self.text_attrs)
+            # ``token_packing``: one (cu, tok[, order, inv]) tuple for the single attribute, a sequence of such tuples (or None) per attribute otherwise
+            packs = [None] * n_attr if (dedup or token_packing is None) else ([token_packing] if n_attr == 1 else list(token_packing))
+            if len(packs) != n_attr:
+                raise ValueError(f"token_packing: {len(packs)} entries for {n_attr} text attributes")
+            passes = []
+            for ai, (_, a0, aw) in enumerate(self.text_attrs):      # every attribute through the SAME encoder (T/model/encoders.py:107-112)
+                sub = sample_items if n_attr == 1 else sample_items[:, a0:a0 + aw].contiguous()
+                passes.append(engine.bert_forward(p, prep_b, sub, self.bert_heads, self.dtype, True, self.bert_eps,
+                                                  self.bert_mask_value, engine.TE, d_item.stream(ai), grad_from=self.bert_grad_from,
+                                                  packing=packs[ai], on_use=self._await_params if (self._param_ready and ai == 0) else None))
+            E = passes[0][0] if n_attr == 1 else ops.scaled_sum([e for e, _ in passes], 1.0 / n_attr)      # encoders.py:113-116: the mean
             self._await_params(None)      # whatever the tower did not ask for (the recommender group's slice) before SASRec reads it
         else:
             idx32 = sample_items.view(-1).to(torch.int32).contiguous()
@@ -466,7 +479,11 @@ class TrainStep:
         if self.vision:
             swin_engine.swin_backward(p, prep_b, saved_b, dE, grads, swin_engine.IN, on_ready=self._on_ready)
         elif m.use_modal:
-            engine.bert_backward(p, prep_b, saved_b, dE, grads, engine.TE, on_ready=self._on_ready)
+            # mean over attributes: each pass receives dE / n; the passes share every parameter, their gradients ACCUMULATE in the arenas, so
+            # a bucket is final -- reduced over ranks / stepped -- only behind the LAST pass
+            d_pass = dE if len(passes) == 1 else ops.scaled_sum([dE.contiguous()], 1.0 / len(passes))
+            for ai, (_, saved_a) in enumerate(passes):
+                engine.bert_backward(p, prep_b, saved_a, d_pass, grads, engine.TE, on_ready=self._on_ready if ai == len(passes) - 1 else None)
         else:
             ops.scatter_add_rows_(dE, idx32, grads["id_embedding.weight"], 0)
         engine.WgradStream.join(self.device)       # the weight gradients of the side stream are final from here on
@@ -710,6 +727,27 @@ class TrainStep:
         return {"scale": float(h.loss_scale), "growth_factor": self.sp.growth_factor, "backoff_factor": self.sp.backoff_factor,
                 "growth_interval": self.sp.growth_interval, "_growth_tracker": int(h.growth_tracker)}
 
+    def load_scaler_state_dict(self, sd):
+        """Counterpart of ``scaler_state_dict`` (``GradScaler.load_state_dict``): the loss scale and the count of clean steps since its
+        last change go back into the device block, so a resumed fp16 run does not restart at 65536 and skip its first steps.  An empty
+        dict (a checkpoint of the reference, which never saves its scaler) leaves the block as it is."""
+        if self.sp is None or not sd:
+            return
+        self.flush()
+        scale = float(sd["scale"])
+        if not scale > 0.0:
+            raise ValueError(f"loss scale {scale}")
+        self.sp.f32[4:5].fill_(scale)
+        self.sp.f32[5:6].fill_(1.0 / scale)
+        self.sp.i32[2:3].fill_(int(sd.get("_growth_tracker", 0)))
+        self.sp.growth_factor = float(sd.get("growth_factor", self.sp.growth_factor))
+        self.sp.backoff_factor = float(sd.get("backoff_factor", self.sp.backoff_factor))
+        self.sp.growth_interval = int(sd.get("growth_interval", self.sp.growth_interval))
+
+    def state_dict(self):
+        """``GradScaler.state_dict()`` spelling of ``scaler_state_dict`` (what ``data_utils.utils.save_model(scaler=...)`` calls)."""
+        return self.scaler_state_dict()
+
     def global_loss(self, loss):
         """With pooled negatives ``step`` returns THIS rank's share ``loss_sum_local / n_valid_global`` (the shares add up to
         the loss of the single-process step at batch N*B); this is the SUM over ranks, for logging."""
@@ -828,7 +866,8 @@ class TrainStep:
         read from the device block, so nothing of it is frozen into the graph.  Text tower: pass ``token_packing`` (host-prepared index
         vectors) or run the padded layout -- the device-side packing synchronises with the host and cannot be captured."""
         tp = token_packing
-        if (not self.graph or self.dedup_items or (self.model.use_modal and not self.vision and tp is None and engine.UNPAD_DEFAULT)):
+        if (not self.graph or self.dedup_items or len(self.text_attrs) > 1
+                or (self.model.use_modal and not self.vision and tp is None and engine.UNPAD_DEFAULT)):
             return self.step(sample_items_id, sample_items, log_mask, token_packing)
         ins = [sample_items_id, sample_items, log_mask] + (list(tp) if tp is not None else [])
         key = tuple((tuple(t.shape), t.dtype) for t in ins)

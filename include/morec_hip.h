@@ -168,6 +168,10 @@ int morec_cast(const void* in, void* out, size_t n, int in_dtype, int out_dtype,
 int morec_split_bf16x3(const float* in, void* out, int R, int C, int ld_in, int ld_out, int lo_slot, void* stream);
 /* out = dy * act'(pre), elementwise (act = MOREC_ACT_GELU | MOREC_ACT_RELU); T/model/encoders.py:70 backward */
 int morec_act_bwd(const void* dy, const void* pre, void* out, size_t n, int act, int dtype, void* stream);
+/* out = scale * (x0 + x1 + x2), elementwise, fp32 arithmetic, one rounding to `dtype` (x1, x2 may be NULL; x2 needs x1): the mean over the text
+ * attributes of a news item -- T/model/encoders.py:107-116, torch.mean(torch.stack(text_vectors, dim=1), dim=1) -- and, with one input and
+ * scale = 1 / k, the gradient each attribute's encoder pass receives.  n % 4 == 0. */
+int morec_scaled_sum(const void* x0, const void* x1, const void* x2, void* out, size_t n, float scale, int dtype, void* stream);
 /* out[n] = sum_m in[m, n]  (bias gradients), atomically accumulated into fp32 out */
 int morec_colsum(const void* in, float* out, int M, int N, int ld, int dtype, void* stream);
 

@@ -63,4 +63,5 @@ def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
         assert "error" not in c and c["ms_per_step"] > 0 and "error" not in c["trace"] and "exposed_join_ms" in c["trace"]
         assert abs(c["user_seq_per_s"] - 32 * 1e3 / c["ms_per_step"]) < 1e-2 * c["user_seq_per_s"]
     no_overlap = [c for c in timed if not c["overlap_reduce"]][0]["trace"]
-    assert all(b["issued_at_ms"] >= no_overlap["join_begin_ms"] - 1e-3 or True for b in no_overlap["buckets"])
+    # without overlap nothing is issued from the backward pass: one closing sweep per arena, at the join
+    assert len(no_overlap["buckets"]) <= 2 and all("issued_at_ms" in b for b in no_overlap["buckets"])

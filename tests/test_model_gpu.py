@@ -233,8 +233,8 @@ def test_g18_long_sequences_golden(golden_dir, dtype):
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_g19_two_text_attributes_golden(golden_dir, dtype):
     """``--news_attributes title,abstract`` (T/model/encoders.py:76-117: both attributes through the SAME Text_Encoder, item vector = their
-    mean; 30 + 50 tokens) on the drop-in module path against the reference's own numbers (tests/golden/make_golden.py --only g19).  The
-    fused ``TrainStep`` takes title-only rows and says so."""
+    mean; 30 + 50 tokens) on the drop-in module path AND through the fused ``TrainStep`` against the reference's own numbers
+    (tests/golden/make_golden.py --only g19)."""
     from idvs.morec_amd.train_step import TrainStep
     gd = g(golden_dir, "g19_two_attributes.npz")
     S, D, Tt, Ta, item_num, B = (int(v) for v in gd["two.cfg"])
@@ -268,9 +268,35 @@ def test_g19_two_text_attributes_golden(golden_dir, dtype):
         worst = max(worst, err)
         assert err < (2e-3 if f32 else 5e-2), (pn, got, float(gd[k]))
     print(f"g19 {dtype}: worst grad-norm rel err {worst:.2e}")
-    if f32:
-        with pytest.raises(ValueError, match="news_attributes"):
-            TrainStep(m, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0, pool_negatives=False)
+    # the fused TrainStep on the same rows (round 5: one encoder pass per attribute, mean, gradients accumulated over the passes): the
+    # reference's loss and gradient norms again, with the host-prepared unpadded layout of BOTH attributes and without it
+    from idvs.morec_amd import engine
+    for packed in (False, True):
+        m2 = load_det(Model(args, item_num, True, HipBertModel(shape), gd["two.pop"])).to(DEV)
+        m2.eval()
+        ts = TrainStep(m2, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0, pool_negatives=False,
+                       loss_scale=None if f32 else 256.0)      # (the module path above scales its fp16 loss by the same 256)
+        assert [n for n, _, _ in ts.text_attrs] == ["title", "abstract"]
+        pack = None
+        if packed:
+            rows = items.cpu()
+            pack = tuple(tuple(t.to(DEV) for t in engine.token_packing_host(rows[:, a0 + aw // 2:a0 + aw], rows[:, a0:a0 + aw // 2]))
+                         for _, a0, aw in ts.text_attrs)
+        loss2 = ts.forward_backward(ids, items, lm, token_packing=pack)
+        ts.reduce_gradients()
+        torch.cuda.synchronize()
+        assert abs(loss2.item() - ref) < (1e-4 if f32 else 5e-3), (packed, loss2.item(), ref)
+        scale = float(ts.sp.host().loss_scale) if ts.sp is not None else 1.0
+        worst2 = 0.0
+        for k in [k for k in gd.files if k.startswith("two.grad_norm.")]:
+            pn = k[len("two.grad_norm."):]
+            if "pooler" in pn:
+                continue
+            got = ts.g[pn].double().norm().item() / scale
+            err = abs(got - float(gd[k])) / (float(gd[k]) + (1e-4 if f32 else 1e-2))
+            worst2 = max(worst2, err)
+            assert err < (2e-3 if f32 else 5e-2), (packed, pn, got, float(gd[k]))
+        print(f"g19 {dtype} fused step (packed={packed}): loss {loss2.item():.6f}, worst grad-norm rel err {worst2:.2e}")
 
 
 @pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16")])
