@@ -39,10 +39,11 @@ def parse():
     ap.add_argument("--bert", default="base")
     ap.add_argument("--tower", default="text", help="text (BASELINE.json metric: BERT item encoder) | swin_tiny | swin_base | swin_micro "
                     "(vision configs of BASELINE.json: Swin item encoder, S=10, D=2048, 224x224 images; default --batch 64)")
-    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp32x3"],
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp32x3", "fp16_res32", "bf16_res32"],
                     help="fp16 (default): IEEE-half operands on the MFMA + GradScaler loss scaling -- the reference's own GPU arithmetic "
                          "(T/run.py:210,242-247; V/run.py likewise) and the 16-bit mode whose loss stays within north_star's 1e-3 of the fp32 parity mode; bf16: the "
-                         "same kernels on bf16 operands (no loss scaling); fp32 / fp32x3: the parity modes")
+                         "same kernels on bf16 operands (no loss scaling); fp32 / fp32x3: the parity modes; fp16_res32 / bf16_res32: 16-bit GEMMs with an "
+                         "fp32 residual stream (LayerNorm in and out fp32) -- the data flow of torch.cuda.amp.autocast itself")
     ap.add_argument("--vision-input", default="resident", choices=["resident", "u8"],
                     help="vision towers: resident = fp32 NCHW catalogue in HBM, a step gathers its images on the device (what V/run.py:201-204 has after "
                          "the DataLoader); u8 = the input pipeline inside the timed step (SURVEY §8 a3 / f3): decoded uint8 images of --native-size on the "
@@ -51,7 +52,7 @@ def parse():
     ap.add_argument("--native-size", type=int, default=256, help="--vision-input u8: side of the synthetic decoded images before the resize")
     ap.add_argument("--item-num", type=int, default=80000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--dedup", action="store_true", help="encode each distinct item of the batch once (SURVEY §8(f)-2; opt-in: with "
                     "dropout on, duplicates then share a mask). The default run reports it as a secondary measurement only.")
     ap.add_argument("--padded", action="store_true", help="text tower: run the encoder layers on all T positions of every title (the "
@@ -70,7 +71,9 @@ def parse():
                     "world size it observed as one JSON line and exits (no GPU work; used by the CPU test of the N > 1 launch path)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-timeout", type=int, default=150)
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.dtype16 = a.dtype.split("_")[0]      # storage type of the GEMM operands ("fp16_res32" -> "fp16")
+    return a
 
 
 _T0 = time.time()
@@ -594,7 +597,7 @@ def main():
     fp32_info = fp32x3_info = None
     main_gemm_log = list(gemm_log)
     main_ce_log, main_ce_shapes = list(ce_log), list(ce_shapes)
-    if not vision and not id_tower and a.dtype in ("bf16", "fp16") and not a.no_secondary and world == 1:
+    if not vision and not id_tower and a.dtype16 in ("bf16", "fp16") and not a.no_secondary and world == 1:
         def fp32_mode_line(mode):
             nonlocal ts
             info = None
@@ -652,7 +655,7 @@ def main():
     tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # fp32x3: three bf16 MFMA passes per fp32 product -> a third of the bf16 peak in fp32-equivalent FLOPs
     peak = {"bf16": MFMA_PEAK_TFLOPS["bf16"], "fp16": MFMA_PEAK_TFLOPS["fp16"], "fp32": MFMA_PEAK_TFLOPS["f32"],
-            "fp32x3": round(MFMA_PEAK_TFLOPS["bf16"] / 3.0, 1)}[a.dtype]
+            "fp32x3": round(MFMA_PEAK_TFLOPS["bf16"] / 3.0, 1)}[a.dtype16]
     launches_per_step = len(gemm_log) / max(1, n_inst)
     flops_per_step = fl / max(1, n_inst)
     alg_bytes_per_launch = sum(g_[4] for g_ in gemm_log) / max(1, len(gemm_log))
@@ -703,14 +706,14 @@ def main():
 
     # the scoring kernels at the 8-rank POOLED size (this rank's B S rows against eight ranks' worth of item vectors, emulated on one
     # GPU): the size north_star's multi-GPU step runs them at; never part of `value`
-    if not a.no_secondary and not vision and world == 1 and a.dtype in ("bf16", "fp16"):
+    if not a.no_secondary and not vision and world == 1 and a.dtype16 in ("bf16", "fp16"):
         try:
-            roof["scoring"]["pooled_8_ranks"] = scoring_pooled(ops, a.batch, S, D, dev, peak, dt=torch.float16 if a.dtype == "fp16" else torch.bfloat16)
+            roof["scoring"]["pooled_8_ranks"] = scoring_pooled(ops, a.batch, S, D, dev, peak, dt=torch.float16 if a.dtype16 == "fp16" else torch.bfloat16)
         except Exception as e:  # noqa: BLE001
             roof["scoring"]["pooled_8_ranks"] = {"error": f"{type(e).__name__}: {e}"}
 
     eval_info = None
-    if not a.no_secondary and not vision and not id_tower and world == 1 and a.dtype in ("bf16", "fp16"):
+    if not a.no_secondary and not vision and not id_tower and world == 1 and a.dtype16 in ("bf16", "fp16"):
         keep = (list(gemm_log), list(ce_log), list(ce_shapes))
         eval_info = eval_lines(model, ops, args, content, a.item_num, S, D, dev, gemm_log, timing_on, peak)
         gemm_log[:], ce_log[:], ce_shapes[:] = keep
@@ -757,7 +760,7 @@ def main():
     # secondary lines (never `value`): the other BASELINE.json configurations, each measured by a child run of this file so that the
     # driver's record carries a time for every config: configs[3] Swin-T (V/train_swin_tiny.py:22-41: B = 64/GPU, 704 images per
     # step), configs[4] Swin-B (B = 32/GPU, 352 images per step), configs[0] IDRec (T/train_id.py:22-26), configs[1] BERT-tiny
-    if not vision and not id_tower and a.dtype in ("bf16", "fp16") and not a.no_secondary and world == 1 and a.bert == "base":
+    if not vision and not id_tower and a.dtype16 in ("bf16", "fp16") and not a.no_secondary and world == 1 and a.bert == "base":
         import subprocess
 
         def child(extra, timeout=240):
@@ -765,15 +768,17 @@ def main():
                                capture_output=True, text=True, timeout=timeout)
             return json.loads(r.stdout.strip().splitlines()[-1])
 
-        other16 = "bf16" if a.dtype == "fp16" else "fp16"
+        other16 = "bf16" if a.dtype16 == "fp16" else "fp16"
+        res32 = a.dtype16 + "_res32" if a.dtype == a.dtype16 else a.dtype16
         for key, extra, per_seq in ((other16 + "_mode", ["--dtype", other16, "--batch", str(a.batch), "--steps", "20", "--warmup", "5"], 0),
+                                    (res32 + "_mode", ["--dtype", res32, "--batch", str(a.batch), "--steps", "20", "--warmup", "5"], 0),
                                     ("vision_swin_tiny", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2"], 11),
                                     ("vision_swin_base", ["--tower", "swin_base", "--batch", "32", "--steps", "4", "--warmup", "2"], 11),
                                     ("vision_u8_pipeline", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2", "--vision-input", "u8"], 11),
                                     ("id_tower", ["--tower", "id", "--batch", "128", "--steps", "20", "--warmup", "5"], 0),
                                     ("bert_tiny", ["--bert", "tiny", "--batch", "128", "--steps", "20", "--warmup", "5"], 0)):
             try:
-                vj = child(extra if "--dtype" in extra else extra + ["--dtype", a.dtype])
+                vj = child(extra if "--dtype" in extra else extra + ["--dtype", a.dtype16])
                 out[key] = {"ms_per_step": vj["ms_per_step"], "user_seq_per_s": vj["value"], "dtype": vj["dtype"], "config": vj["config"]["workload"],
                             "gemm_roofline_frac": vj.get("roofline", {}).get("frac"),
                             "note": "python bench.py " + " ".join(extra)}
@@ -788,6 +793,8 @@ def main():
                    "golden g6 BERT-base loss 1e-3 relative (measured 5.3e-4); HR@10 of the modal eval golden g17 equal to the reference's",
            "bf16": "bf16 vs the exact-fp32 parity mode at this configuration (tests/test_bench_mode_parity_gpu.py, asserted): step-0 loss 3e-2 absolute "
                    "(measured 1.3e-3 ... 1.5e-2 depending on the GEMM summation order), gradient norms 5e-2 (0.6e-2 ... 2.3e-2), 20-step loss curve 2 %"}
+    TOL["fp16_res32"] = ("fp16 GEMM operands / outputs with an fp32 residual stream (LayerNorm in and out fp32): the data flow of the reference's "
+                         "torch.cuda.amp.autocast step (T/run.py:242); against the exact-fp32 mode at this configuration: tests/test_fp16_mode_gpu.py")
     if a.dtype in TOL and not vision and not id_tower:
         out["config"]["tolerance_vs_fp32_mode"] = TOL[a.dtype]
     TOL_V = {"fp16": "fp16 vs the exact-fp32 parity mode, Swin-T at 176 images (tests/test_bench_mode_parity_vision_gpu.py, asserted): step-0 loss 4e-3 "
@@ -796,7 +803,7 @@ def main():
              "bf16": "bf16 vs the exact-fp32 parity mode, Swin-T at 176 images (same file): step-0 loss 3e-2 (measured 1.2e-2), gradient norms 5e-2 (1.1e-2)"}
     if vision and a.dtype in TOL_V:
         out["config"]["tolerance_vs_fp32_mode"] = TOL_V[a.dtype]
-    if a.dtype == "fp16":
+    if a.dtype16 == "fp16":
         out["config"]["loss_scaling"] = ("GradScaler protocol on the device (morec_step_params: init 65536, x0.5 + skipped step on inf / NaN, x2 after 2000 clean "
                                          "steps); the overflow check, the decision and AdamW are inside the timed step")
     if fp32_info is not None:
@@ -965,7 +972,8 @@ def cpu_baseline(a):
     Bc = a.cpu_batch
     rng = np.random.default_rng(1)
     content = synth_catalog(a.item_num, T, rng)
-    ids = synth_batches(2, Bc, S, a.item_num, rng)
+    n_max = 4                                # one untimed warm-up step + up to three timed ones
+    ids = synth_batches(n_max, Bc, S, a.item_num, rng)
     counts = np.bincount(ids.reshape(-1), minlength=a.item_num + 1).astype(np.float64) + 1.0
     pop = counts / counts[1:].sum()
     pop[0] = 1.0
@@ -973,8 +981,11 @@ def cpu_baseline(a):
     g = torch.Generator().manual_seed(0)
     p = {k: (torch.randn(*s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
     states = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()}
+    # Bounded sample of the SAME workload (BERT-base, S = 20, T = 30, D = 512; Bc user sequences per step instead of 128): the first step
+    # warms the allocator / thread pool and is not timed; then whole steps until ~20 s of timed CPU work (or three steps) are in.
     times = []
-    for it in range(2):
+    t_begin = time.perf_counter()
+    for it in range(n_max):
         t0 = time.perf_counter()
         items = torch.from_numpy(content[ids[it].reshape(-1)])
         loss = orc.model_forward(p, torch.from_numpy(ids[it]).view(-1), items, torch.ones(Bc, S), pop, max_seq_len=S,
@@ -988,12 +999,15 @@ def cpu_baseline(a):
                 orc.adamw_step(v, v.grad, states[k][0], states[k][1], it + 1, lr, 0.01)
                 v.grad = None
         times.append(time.perf_counter() - t0)
-        if times[-1] > 40:
+        timed = sum(times[1:])
+        if (len(times) >= 2 and (timed >= 20.0 or time.perf_counter() - t_begin + times[-1] > 0.8 * a.cpu_timeout)) or times[-1] > 60:
             break
-    best = min(times)
-    return {"value": round(Bc / best, 4), "unit": "user-seq/s", "cores": threads, "kind": "port",
-            "sample": f"{Bc} user sequences x {len(times)} step(s) (fwd+bwd+AdamW, PyTorch-CPU fp32 oracle, BERT-{a.bert}), "
-                      f"best step {best:.2f} s"}
+    timed_steps = times[1:] if len(times) > 1 else times
+    mean = sum(timed_steps) / len(timed_steps)
+    return {"value": round(Bc / mean, 4), "unit": "user-seq/s", "cores": threads, "kind": "port",
+            "sample": f"{Bc} user sequences per step x {len(timed_steps)} timed step(s) after one untimed warm-up step = {sum(timed_steps):.1f} s of CPU work "
+                      f"(fwd + bwd + AdamW of the PyTorch-CPU fp32 oracle, BERT-{a.bert}, S = 20, T = 30, D = 512: the bench workload at batch {Bc} "
+                      f"instead of 128); mean step {mean:.2f} s, best {min(timed_steps):.2f} s"}
 
 
 if __name__ == "__main__":

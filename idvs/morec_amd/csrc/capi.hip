@@ -1,5 +1,7 @@
 // capi.hip -- library-level entry points: error strings, version, hardware probe.
 #include <atomic>
+#include <mutex>
+#include <stdlib.h>
 #include "common.hpp"
 
 extern "C" const char* morec_strerror(int code) {
@@ -24,6 +26,70 @@ const uint64_t* morec_drop_seed_src() { return g_drop_seed_src; }
 extern "C" int morec_dropout_seed_source(const void* dev_u64) {
     if (reinterpret_cast<uintptr_t>(dev_u64) & 7u) return MOREC_E_ALIGN;
     g_drop_seed_src = reinterpret_cast<const uint64_t*>(dev_u64);
+    return MOREC_OK;
+}
+
+// ---- deterministic mode (common.hpp) ----------------------------------------------------------------------------------------------
+static int g_deterministic = -1;
+bool morec_deterministic() {
+    if (g_deterministic < 0) {
+        const char* e = getenv("MOREC_DETERMINISTIC");
+        g_deterministic = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return g_deterministic != 0;
+}
+void morec_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }
+
+float* morec_det_scratch(hipStream_t s, size_t n) {
+    struct Slot { hipStream_t s; int dev; float* p; size_t n; };
+    static Slot slots[16];
+    static int n_slots = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Slot* sl = nullptr;
+    for (int i = 0; i < n_slots; ++i)
+        if (slots[i].s == s && slots[i].dev == dev) sl = &slots[i];
+    if (!sl) {
+        if (n_slots == 16) return nullptr;
+        sl = &slots[n_slots++];
+        *sl = Slot{s, dev, nullptr, 0};
+    }
+    if (sl->n < n) {
+        if (sl->p) {      // launches that still read the old buffer are on this stream
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(sl->p);
+            sl->p = nullptr; sl->n = 0;
+        }
+        size_t want = n + n / 4;
+        if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+        if (hipMalloc(reinterpret_cast<void**>(&sl->p), want * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); sl->p = nullptr; return nullptr; }
+        sl->n = want;
+    }
+    return sl->p;
+}
+
+__global__ __launch_bounds__(256) void det_fold_add_kernel(const float* __restrict__ part, float* __restrict__ dst, int n_parts, size_t n, size_t stride) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four chains for the memory latency; their combination order is fixed as well
+        int p = 0;
+        for (; p + 4 <= n_parts; p += 4) {
+            a0 += part[(size_t)p * stride + j];
+            a1 += part[(size_t)(p + 1) * stride + j];
+            a2 += part[(size_t)(p + 2) * stride + j];
+            a3 += part[(size_t)(p + 3) * stride + j];
+        }
+        for (; p < n_parts; ++p) a0 += part[(size_t)p * stride + j];
+        dst[j] += (a0 + a1) + (a2 + a3);
+    }
+}
+int morec_det_fold_add(const float* part, float* dst, int n_parts, size_t n, size_t stride, hipStream_t s) {
+    if (n == 0 || n_parts <= 0) return MOREC_OK;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(det_fold_add_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, dst, n_parts, n, stride);
+    MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }
 

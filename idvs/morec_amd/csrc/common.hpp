@@ -398,6 +398,19 @@ static inline bool by_h16(int dtype, F&& f) {
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+// ---- deterministic mode (MOREC_DETERMINISTIC=1 / morec_tuning_set("deterministic", 1); capi.hip).  The reference sets torch's
+// deterministic flags (T/run.py:313-314).  The kernels that end in fp32 atomics -- column sums of LayerNorm / bias gradients, the
+// embedding-table scatters -- then leave per-block partials in a library-owned scratch instead and a second launch adds them to the
+// destination in a FIXED order (or, for the scatters, one wave owns a destination row and sums its sources in index order): two runs of
+// the same step on the same inputs give the same bits.  Covered: the 16-bit and fp32 text / ID towers.
+bool morec_deterministic();
+void morec_set_deterministic(int on);
+// fp32 scratch of at least n floats for launches on stream s (one buffer per (device, stream): launches of one stream are ordered, two
+// streams must not share); nullptr on allocation failure.  Grows by re-allocation behind a stream synchronisation.
+float* morec_det_scratch(hipStream_t s, size_t n);
+// dst[j] += part[0 * stride + j] + part[1 * stride + j] + ... (p ascending; j < n): plain read-modify-write, one thread per element
+int morec_det_fold_add(const float* part, float* dst, int n_parts, size_t n, size_t stride, hipStream_t s);
+
 // XCD-aware workgroup -> tile mapping: the dispatcher round-robins consecutive workgroup ids over
 // the 8 XCDs (private L2 each); remap so that each XCD walks a CONTIGUOUS run of tiles, i.e. the
 // tiles that share an A row-panel hit the same L2.  Bijective for any grid size.

@@ -227,6 +227,54 @@ __global__ __launch_bounds__(256) void word_scatter_sorted_kernel(const int32_t*
     flush();
 }
 
+// Deterministic mode: ONE wave owns a table row.  The wave at sorted position i acts only when i starts a run of equal ids; it then sums
+// the run's rows in `order` (four rows in flight) and adds the total to the table row with a plain read-modify-write -- no other wave
+// touches that row, and the summation order is the (stable) sort order.  Long runs ([CLS] / [SEP]: one row per title) are serial in one
+// wave: slower than the atomics (~0.3 ms at B = 128), which is the price of the mode.
+template <typename T>
+__global__ __launch_bounds__(256) void word_scatter_runs_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ order,
+                                                                const T* __restrict__ dz, float* __restrict__ dword, int pad_id, int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= M) return;
+    const int id = ids[order[i]];
+    if (id == pad_id || (i > 0 && ids[order[i - 1]] == id)) return;
+    for (int c0 = 0; c0 < H; c0 += 256) {      // 256 columns (4 per lane) per sweep over the run
+        const int c = c0 + lane * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int j = i;
+        while (j < M) {
+            int rows[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rows[u] = -1;
+                if (j + u < M) {
+                    const int r = order[j + u];
+                    if (ids[r] == id && n == u) { rows[u] = r; ++n; }
+                }
+            }
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (rows[u] >= 0 && c < H) io<T>::load4(dz + (size_t)rows[u] * H + c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (rows[u] >= 0 && c < H) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] += v[u][k];
+                }
+            j += n;
+            if (n < 4) break;
+        }
+        if (c < H) {
+            float4 o = *reinterpret_cast<const float4*>(dword + (size_t)id * H + c);
+            o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+            *reinterpret_cast<float4*>(dword + (size_t)id * H + c) = o;
+        }
+    }
+}
+
 template <typename T>      // row width not a multiple of the 16-byte vector: one element per lane per trip
 __global__ __launch_bounds__(256) void pos_type_grad_scalar_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
                                                                    float* __restrict__ dtype0, int nseq, int Tlen, int H,
@@ -256,7 +304,9 @@ extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* d
     const int T_ = T;      // (the lambda below names its storage type T)
     if (!by_dtype(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<T, 4>), g3, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H, rpw);
+            if (order != nullptr && morec_deterministic())
+                hipLaunchKernelGGL((word_scatter_runs_kernel<T>), g1, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H);
+            else if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<T, 4>), g3, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H, rpw);
             else hipLaunchKernelGGL((word_scatter_kernel<T>), g1, dim3(256), 0, s, ids, (const T*)dz, dword, pad_id, M, H);
             if (vec) pos_type_grad_launch<T>((const T*)dz, dpos, dtype0, M / T_, T_, H, s);
             else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<T>), g2, dim3(256), 0, s, (const T*)dz, dpos, dtype0, M / T_, T_, H, spb);
@@ -312,15 +362,54 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restri
     }
 }
 
+// Deterministic mode: the wave of source row r acts only when no EARLIER row carries the same index (it scans idx[0 .. r): R is the
+// B (S + 1) slots of a batch, a few thousand); it then adds the rows r, r' > r, ... with that index in row order -- one writer per table row.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_det_kernel(const T* __restrict__ d, const int32_t* __restrict__ idx,
+                                                                   float* __restrict__ dtable, int R, int D, int pad_id) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int id = idx[row];
+    if (id == pad_id) return;
+    bool dup = false;
+    for (int r0 = 0; r0 < row && !dup; r0 += 64) {
+        const int r = r0 + lane;
+        dup = __ballot(r < row && idx[r] == id) != 0ull;
+    }
+    if (dup) return;
+    float* dst = dtable + (size_t)id * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r0 = row; r0 < R; r0 += 64) {      // 64 candidate rows at a time: the lanes test, the wave walks the hits in order
+            const int r = r0 + lane;
+            unsigned long long hit = __ballot(r < R && idx[r] == id);
+            while (hit) {
+                const int b = __builtin_ctzll(hit);
+                hit &= hit - 1;
+                float v[4];
+                io<T>::load4(d + (size_t)(r0 + b) * D + c, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += v[k];
+            }
+        }
+        float4 o = *reinterpret_cast<const float4*>(dst + c);
+        o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+        *reinterpret_cast<float4*>(dst + c) = o;
+    }
+}
+
 extern "C" int morec_scatter_add_rows(const void* d, const int32_t* idx, float* dtable, int R, int D, int pad_id,
                                       int dtype, void* stream) {
     if (!d || !idx || !dtable || R <= 0 || D <= 0) return MOREC_E_ARG;
     if (D % 4) return MOREC_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((R + 3) / 4);
+    const bool det = morec_deterministic();
     if (!by_dtype(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            hipLaunchKernelGGL((scatter_add_rows_kernel<T>), grid, dim3(256), 0, s, (const T*)d, idx, dtable, R, D, pad_id);
+            if (det) hipLaunchKernelGGL((scatter_add_rows_det_kernel<T>), grid, dim3(256), 0, s, (const T*)d, idx, dtable, R, D, pad_id);
+            else hipLaunchKernelGGL((scatter_add_rows_kernel<T>), grid, dim3(256), 0, s, (const T*)d, idx, dtable, R, D, pad_id);
         }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();

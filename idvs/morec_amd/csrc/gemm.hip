@@ -239,9 +239,10 @@ extern "C" int morec_cast(const void* in, void* out, size_t n, int in_dtype, int
 
 // column sums: each block reduces a [rows_per_block x 64-column] slab with 4-element vector loads (16 column
 // groups x 16 row lanes), folds the row lanes through LDS and leaves ONE atomicAdd per column per block
+// det (deterministic mode): out is a [gridDim.y][N] partial buffer written with plain stores; the launcher folds the rows in order
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, float* __restrict__ out, int M, int N,
-                                                     int ld, int rows_per_block) {
+                                                     int ld, int rows_per_block, int det = 0) {
     __shared__ float part[16][65];
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int n = blockIdx.x * 64 + cg * 4;
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += part[r][threadIdx.x];
-            atomicAdd(out + c, t);
+            if (det) out[(size_t)blockIdx.y * N + c] = t;
+            else atomicAdd(out + c, t);
         }
     }
 }
@@ -277,6 +279,13 @@ int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t 
     rpb = rpb < 16 ? 16 : rpb > 512 ? 512 : rpb;
     if ((long)rows * N <= (1L << 20) && rows <= 512) rpb = 512;     // small folds: one block per column group, i.e. a fixed summation order
     dim3 grid(cb, (rows + rpb - 1) / rpb);
+    if (grid.y > 1 && morec_deterministic()) {      // several row blocks per column: their partials through the scratch, folded in order
+        float* part = morec_det_scratch(s, (size_t)grid.y * N);
+        if (!part) return (int)hipErrorOutOfMemory;
+        hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, in, part, rows, N, N, rpb, 1);
+        MOREC_CHECK_LAUNCH();
+        return morec_det_fold_add(part, out, (int)grid.y, (size_t)N, (size_t)N, s);
+    }
     hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, in, out, rows, N, N, rpb);
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
@@ -288,12 +297,18 @@ extern "C" int morec_colsum(const void* in, float* out, int M, int N, int ld, in
     const int rpb = 512;
     dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* part = nullptr;
+    if (grid.y > 1 && morec_deterministic()) {
+        part = morec_det_scratch(s, (size_t)grid.y * N);
+        if (!part) return (int)hipErrorOutOfMemory;
+    }
     if (!by_dtype(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)in, out, M, N, ld, rpb);
+            hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)in, part ? part : out, M, N, ld, rpb, part ? 1 : 0);
         }))
         return MOREC_E_DTYPE;
     MOREC_CHECK_LAUNCH();
+    if (part) return morec_det_fold_add(part, out, (int)grid.y, (size_t)N, (size_t)N, s);
     return MOREC_OK;
 }
 

@@ -585,6 +585,7 @@ static int g_mode8p = -1, g_debug8p = 0, g_tail_bias = 2, g_tail_split = 0;
 static unsigned long long g_stamps = 0;
 extern "C" int morec_tuning_set(const char* key, int value) {
     if (!key) return MOREC_E_ARG;
+    if (!strcmp(key, "deterministic")) { morec_set_deterministic(value); return MOREC_OK; }
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_split")) { g_tail_split = value != 0; return MOREC_OK; }

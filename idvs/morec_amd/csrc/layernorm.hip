@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
                                                      T* __restrict__ dz, T* __restrict__ dzd, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, float* __restrict__ dbias, int M, int N,
                                                      int rows_per_block, DropRng din, DropRng dout,
-                                                     const T* __restrict__ dres, const float* __restrict__ rowscale, int rps) {
+                                                     const T* __restrict__ dres, const float* __restrict__ rowscale, int rps,
+                                                     float* __restrict__ det) {
     din = drop_resolve(din);
     dout = drop_resolve(dout);
     constexpr int EV = vio<T>::EV;
@@ -308,6 +309,11 @@ __global__ __launch_bounds__(256, (VPL * vio<T>::EV <= 24 ? 2 : 1)) void ln_bwd_
                 tb += sb[q * N + c];
                 if (dbias) td += sd[q * N + c];
             }
+            if (det) {      // deterministic mode: this block's [3][N] partial row; the launcher folds the blocks in order
+                float* o = det + (size_t)blockIdx.x * 3 * N;
+                o[c] = tg; o[N + c] = tb; o[2 * N + c] = td;
+                continue;
+            }
             if (dgamma) {
                 atomicAdd(dgamma + c, tg);
                 atomicAdd(dbeta + c, tb);
@@ -374,7 +380,7 @@ extern "C" int morec_layernorm_fwd(const void* x, const float* bias, const void*
 // C = 96 launch empty), never fewer than 64 rows so that the per-block column flush (3 N atomics) stays small.
 // (64-row blocks at M = 51200, H = 768: 800 blocks = 1.56 rounds, 12 % slower than one round.)
 template <typename T, int V, int L, bool FULL>
-static void ln_bwd_launch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd, const float* gamma,
+static int ln_bwd_launch(const void* dy_a, const void* dy_b, const void* z, const float* mean, const float* rstd, const float* gamma,
                           void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M, int N, DropRng din, DropRng dout,
                           const void* dres, const float* rowscale, int rps, hipStream_t s) {
     const size_t lds = ((dgamma || dbias) ? (size_t)12 * (64 / L) * N : 0) * sizeof(float) + N * sizeof(float);
@@ -395,8 +401,24 @@ static void ln_bwd_launch(const void* dy_a, const void* dy_b, const void* z, con
     }
     const int rpb = std::max(64, (((M + slots - 1) / slots) + 15) & ~15);
     dim3 grid((M + rpb - 1) / rpb), block(256);
+    float* det = nullptr;
+    if ((dgamma || dbias) && morec_deterministic()) {      // per-block partial rows instead of one atomic per column per block
+        det = morec_det_scratch(s, (size_t)grid.x * 3 * N);
+        if (!det) return (int)hipErrorOutOfMemory;
+    }
     hipLaunchKernelGGL((ln_bwd_kernel<T, V, L, FULL>), grid, block, lds, s, (const T*)dy_a, (const T*)dy_b, (const T*)z, mean, rstd, gamma,
-                       (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, dout, (const T*)dres, rowscale, rps);
+                       (T*)dz, (T*)dzd, dgamma, dbeta, dbias, M, N, rpb, din, dout, (const T*)dres, rowscale, rps, det);
+    if (det) {
+        MOREC_CHECK_LAUNCH();
+        int rc = MOREC_OK;
+        if (dgamma) {
+            rc = morec_det_fold_add(det, dgamma, (int)grid.x, (size_t)N, (size_t)3 * N, s);
+            if (rc == MOREC_OK) rc = morec_det_fold_add(det + N, dbeta, (int)grid.x, (size_t)N, (size_t)3 * N, s);
+        }
+        if (rc == MOREC_OK && dbias) rc = morec_det_fold_add(det + 2 * (size_t)N, dbias, (int)grid.x, (size_t)N, (size_t)3 * N, s);
+        return rc;
+    }
+    return MOREC_OK;
 }
 
 template <typename T>
@@ -405,7 +427,8 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
                            int N, DropRng din, DropRng dout, const void* dres, const float* rowscale, int rps, hipStream_t s) {
     if (N % vio<T>::EV) return MOREC_E_ALIGN;
     const int vpl = (N + 64 * vio<T>::EV - 1) / (64 * vio<T>::EV);
-#define LN_BWD_L(V, L, F) ln_bwd_launch<T, V, L, F>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rps, s)
+#define LN_BWD_L(V, L, F) rc = ln_bwd_launch<T, V, L, F>(dy_a, dy_b, z, mean, rstd, gamma, dz, dzd, dgamma, dbeta, dbias, M, N, din, dout, dres, rowscale, rps, s)
+    int rc = MOREC_OK;
     if (N <= 16 * vio<T>::EV) LN_BWD_L(1, 16, false);
     else if (N <= 32 * vio<T>::EV) LN_BWD_L(1, 32, false);
     else if (N == 96 * vio<T>::EV) LN_BWD_L(3, 32, true);
@@ -417,6 +440,7 @@ static int ln_bwd_dispatch(const void* dy_a, const void* dy_b, const void* z, co
     else if (vpl <= 16) LN_BWD_L(16, 64, false);
     else return MOREC_E_UNSUPPORTED;
 #undef LN_BWD_L
+    if (rc != MOREC_OK) return rc;
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

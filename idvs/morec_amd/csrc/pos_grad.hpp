@@ -12,7 +12,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict__ dz, float* __restrict__ dpos,
                                                             float* __restrict__ dtype0, int nseq, int Tlen, int H,
-                                                            int t_per_block) {
+                                                            int t_per_block, int det = 0) {
     constexpr int EV = vio<T>::EV, R = 4;
     extern __shared__ __attribute__((aligned(16))) float sm_pt[];      // [groups][H]
     const int nv = H / EV;                                   // <= 256, H % EV == 0 (launcher)
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict_
         for (int c = threadIdx.x; c < H; c += 256) {
             float v = 0.f;
             for (int g = 0; g < groups; ++g) v += sm_pt[(size_t)g * H + c];
-            atomicAdd(dst + c, v);
+            if (det) dst[c] = v;      // deterministic mode: dst is this block's own partial row (launcher folds the blocks in order)
+            else atomicAdd(dst + c, v);
         }
         __syncthreads();
     };
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict_
         }                                                                                     \
         PT_FETCH(r, (t) + 2);                                                                 \
         _Pragma("unroll") for (int k = 0; k < EV; ++k) ty[k] += acc[k];                       \
-        fold(acc, dpos + (size_t)(t) * H);                                                    \
+        fold(acc, dpos + ((size_t)(det ? blockIdx.x * Tlen : 0) + (t)) * H);                  \
     }
     PT_FETCH(ra, t0);
     PT_FETCH(rb, t0 + 1);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict_
         PT_POSITION(ra, t);
         if (t + 1 < t1) PT_POSITION(rb, t + 1);
     }
-    if (dtype0) fold(ty, dtype0);
+    if (dtype0) fold(ty, dtype0 + (det ? ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * H : 0));
 #undef PT_FETCH
 #undef PT_POSITION
 }
@@ -78,7 +79,19 @@ inline bool pos_type_grad_launch(const T* dz, float* dpos, float* dtype0, int ns
     int t_chunks = 512 / seq_blocks;
     t_chunks = t_chunks < 1 ? 1 : t_chunks > Tlen ? Tlen : t_chunks;
     const int tpb = (Tlen + t_chunks - 1) / t_chunks;
-    hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, (Tlen + tpb - 1) / tpb), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
+    const int ty_blocks = (Tlen + tpb - 1) / tpb;
+    if (morec_deterministic()) {      // per-block partial rows [seq_blocks][Tlen][H] (+ [seq_blocks * ty_blocks][H] for the type row), folded in block order
+        const size_t n_pos = (size_t)seq_blocks * Tlen * H, n_ty = dtype0 ? (size_t)seq_blocks * ty_blocks * H : 0;
+        float* part = morec_det_scratch(s, n_pos + n_ty);
+        if (part) {
+            hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, ty_blocks), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
+                               part, dtype0 ? part + n_pos : nullptr, nseq, Tlen, H, tpb, 1);
+            (void)morec_det_fold_add(part, dpos, seq_blocks, (size_t)Tlen * H, (size_t)Tlen * H, s);
+            if (dtype0) (void)morec_det_fold_add(part + n_pos, dtype0, seq_blocks * ty_blocks, (size_t)H, (size_t)H, s);
+            return true;
+        }
+    }
+    hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, ty_blocks), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
                        dpos, dtype0, nseq, Tlen, H, tpb);
     return true;
 }

@@ -32,6 +32,10 @@ class LayerCfg:
     eps: float
     causal: bool
     mask_value: float    # additive value on masked keys: -1e9 (T/model/encoders.py:27) | finfo.min (HF eager)
+    # the reference autocast's data flow (T/run.py:242: LayerNorm runs and returns fp32 under torch.cuda.amp.autocast): the residual stream
+    # is fp32, GEMM operands / outputs 16-bit.  The layer's input / output is then a PAIR (x16, x32): the next GEMM's operand and the
+    # residual stream (``ops.layernorm_fwd_res32``); the backward tells the two flows apart by the dtypes of what it is handed.
+    res32: bool = False
 
 
 _GOLD = 0x9E3779B97F4A7C15
@@ -130,7 +134,9 @@ class WgradStream:
 
 
 def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None, xt=None):
-    """dw[N, K] += dy[M, N]^T @ x[M, K]  (split over M, slabs folded in a fixed order; on the weight-gradient stream, see ``WgradStream``)."""
+    """dw[N, K] += dy[M, N]^T @ x[M, K]  (split over M, slabs folded in a fixed order; on the weight-gradient stream, see ``WgradStream``).
+    The accumulation into ``dw`` is a plain read-modify-write (``morec_gemm_tn``: single writer): every call that adds into the same
+    ``dw`` goes through THIS function, i.e. onto the one weight-gradient stream (or the current stream when there is none), in issue order."""
     if ops.is16(dy.dtype) and dyt is None and xt is None and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
         M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
         side = WgradStream.get(dy.device)
@@ -165,7 +171,8 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
     dyt = ops.transpose(dy) if dyt is None else dyt
     xt = ops.transpose(x) if xt is None else xt
     N, K, Mp = dyt.shape[0], xt.shape[0], dyt.shape[1]
-    ops.gemm_nt(dyt, xt, out=dw, accumulate=2, split_k=_splitk(N, K, Mp))
+    # (deterministic mode: one K range per output element -- a single contribution per launch instead of split-K atomics in arrival order)
+    ops.gemm_nt(dyt, xt, out=dw, accumulate=2, split_k=1 if ops.DETERMINISTIC else _splitk(N, K, Mp))
     return dyt, xt
 
 
@@ -182,18 +189,27 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
                          drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
+    x0r = None
+    if cfg.res32:
+        x0, x0r = x0
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     a = ops.gemm_nt(ctx, w["o"].w)
-    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True,
-                                             p_in=ph, seed_in=s1)
+    if cfg.res32:
+        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0r, p_in=ph, seed_in=s1)
+    else:
+        x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True,
+                                                 p_in=ph, seed_in=s1)
     u = torch.empty((x0.shape[0], w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
     g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
-    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
-                                             p_in=ph, seed_in=s2)
+    if cfg.res32:
+        x2, x2r, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2)
+    else:
+        x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
+                                                 p_in=ph, seed_in=s2)
     saved = (desc, x0, qkv, ctx, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2) if need_grad else None
-    return x2, saved
+    return ((x2, x2r) if cfg.res32 else x2), saved
 
 
 def layer_backward(cfg: LayerCfg, w: dict, saved, dx2_a, dx2_b, g: dict, need_dx: bool = True):
@@ -246,18 +262,27 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
                          drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
+    x0r = None
+    if cfg.res32:
+        x0, x0r = x0
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     ctx_c = gather_cls(ctx, n_seq, T, cu)
-    x0_c = gather_cls(x0, n_seq, T, cu)
+    x0_c = gather_cls(x0r if cfg.res32 else x0, n_seq, T, cu)      # the residual rows (res32: from the fp32 stream)
     a = ops.gemm_nt(ctx_c, w["o"].w)
-    x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
-                                             p_in=ph, seed_in=s1)
+    if cfg.res32:
+        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, p_in=ph, seed_in=s1)
+    else:
+        x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
+                                                 p_in=ph, seed_in=s1)
     u = torch.empty((n_seq, w["f1"].w.shape[0]), device=x0.device, dtype=x0.dtype) if need_grad else None
     g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
-    x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
-                                             p_in=ph, seed_in=s2)
+    if cfg.res32:      # (the [CLS] vectors feed the projection head's GEMM: only the 16-bit copy is consumed)
+        x2, _, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2)
+    else:
+        x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
+                                                 p_in=ph, seed_in=s2)
     saved = (desc, x0, qkv, ctx_c, z1, mean1, rstd1, x1, u, g, z2, mean2, rstd2, key_keep, ph, s1, s2, n_seq, cu) if need_grad else None
     return x2, saved
 
@@ -284,7 +309,10 @@ def layer_backward_cls(cfg: LayerCfg, w: dict, saved, dx2_c: torch.Tensor, g: di
     if not need_dx:
         return None, None
     dx0 = ops.gemm_nt(dqkv, w["qkv"].wt, K=dqkv.shape[1], N=H)
-    dres = dctx.zero_()                      # reuse: residual-branch gradient, [CLS] rows only
+    if dz1.dtype == dctx.dtype:
+        dres = dctx.zero_()                  # reuse: residual-branch gradient, [CLS] rows only
+    else:                                    # res32: the residual stream's gradient is fp32
+        dres = torch.zeros((x0.shape[0], H), device=dz1.device, dtype=dz1.dtype)
     scatter_cls(dz1, dres, n_seq, T, cu)
     return dx0, dres
 
@@ -319,18 +347,28 @@ def sasrec_prepare(p: dict, n_layers: int, dtype, prefix: str = UE, shadow: dict
 
 
 def sasrec_forward(p: dict, prep, x_in: torch.Tensor, log_mask: torch.Tensor, heads: int, need_grad: bool,
-                   prefix: str = UE, drop: DropCfg = NO_DROP):
-    """x_in [B, S, D] compute dtype (contiguous), log_mask float [B, S] -> [B*S, D]."""
+                   prefix: str = UE, drop: DropCfg = NO_DROP, res32: bool = False):
+    """x_in [B, S, D] compute dtype (contiguous), log_mask float [B, S] -> [B*S, D].  ``res32`` (16-bit compute dtypes): the autocast
+    data flow -- fp32 residual stream, see ``LayerCfg.res32``."""
     B, S, D = x_in.shape
-    cfg = LayerCfg(H=D, heads=heads, T=S, act=ACT_RELU, eps=1e-6, causal=True, mask_value=-1e9)
+    res32 = bool(res32) and ops.is16(x_in.dtype)
+    cfg = LayerCfg(H=D, heads=heads, T=S, act=ACT_RELU, eps=1e-6, causal=True, mask_value=-1e9, res32=res32)
     keep = log_mask.to(torch.float32).contiguous()
-    x, z0, mean0, rstd0 = ops.layernorm_fwd(x_in.view(B * S, D), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"],
-                                            1e-6, pos=p[prefix + "position_embedding.weight"], pos_period=S,
-                                            p_out=drop.p_hidden, seed_out=drop.site(0))
+    if res32:
+        xh, xr, z0, mean0, rstd0 = ops.layernorm_fwd_res32(x_in.view(B * S, D), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"], 1e-6,
+                                                           pos=p[prefix + "position_embedding.weight"], pos_period=S,
+                                                           p_out=drop.p_hidden, seed_out=drop.site(0))
+        x = (xh, xr)
+    else:
+        x, z0, mean0, rstd0 = ops.layernorm_fwd(x_in.view(B * S, D), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"],
+                                                1e-6, pos=p[prefix + "position_embedding.weight"], pos_period=S,
+                                                p_out=drop.p_hidden, seed_out=drop.site(0))
     saved_layers = []
     for l, w in enumerate(prep):
         x, sv = layer_forward(cfg, w, x, keep, B, need_grad, drop, 1 + 3 * l)
         saved_layers.append(sv)
+    if res32:
+        x = x[0]      # the user states feed the scoring GEMM: the 16-bit copy
     saved = (cfg, z0, mean0, rstd0, saved_layers, S, drop) if need_grad else None
     return x, saved
 
@@ -354,9 +392,9 @@ def sasrec_backward(p: dict, prep, saved, dout: torch.Tensor, grads: dict, prefi
         if not fused:   # hand the three row blocks out as the parameters' gradients (views, no arithmetic)
             grads[a + "w_Q.weight"], grads[a + "w_K.weight"], grads[a + "w_V.weight"] = dqkv[:D], dqkv[D:2 * D], dqkv[2 * D:]
     dz0, _ = ops.layernorm_bwd(da, db, z0, mean0, rstd0, p[prefix + "layer_norm.weight"], grads[prefix + "layer_norm.weight"],
-                               grads[prefix + "layer_norm.bias"], p_out=drop.p_hidden, seed_out=drop.site(0))
+                               grads[prefix + "layer_norm.bias"], p_out=drop.p_hidden, seed_out=drop.site(0), sub16=False)
     ops.pos_grad_(dz0, grads[prefix + "position_embedding.weight"], S)
-    return dz0
+    return dz0      # (res32: fp32 -- the callers add it to / cast it into the item vectors' gradient)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -478,7 +516,7 @@ def bert_needs_grad_buffer(name: str, grad_from: int, prefix: str = TE) -> bool:
 
 def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad: bool, eps: float = 1e-12,
                  mask_value: float = ops.FLT_MIN_MASK, prefix: str = TE, drop: DropCfg = NO_DROP, unpad: bool | None = None,
-                 grad_from: int = -1, packing=None, on_use=None):
+                 grad_from: int = -1, packing=None, on_use=None, res32: bool = False):
     """text int64 [Nc, 2T] = [input_ids | attention_mask] (T/model/encoders.py:63-67) -> item vectors [Nc, D].
 
     ``unpad``: run the encoder layers on the REAL tokens only (packed rows + ``cu_seqlens``) instead of all T positions of
@@ -498,12 +536,18 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
     ids32 = text[:, :T].to(torch.int32).contiguous().view(-1)
     keep = text[:, T:].to(torch.float32).contiguous()
     H = p[bm + "embeddings.word_embeddings.weight"].shape[1]
-    cfg = LayerCfg(H=H, heads=heads, T=T, act=ACT_GELU, eps=eps, causal=False, mask_value=mask_value)
+    res32 = bool(res32) and ops.is16(dtype)      # the autocast data flow: fp32 residual stream (``LayerCfg.res32``)
+    cfg = LayerCfg(H=H, heads=heads, T=T, act=ACT_GELU, eps=eps, causal=False, mask_value=mask_value, res32=res32)
     type0 = p[bm + "embeddings.token_type_embeddings.weight"][0].contiguous()
+    # (res32: the embedding stage runs in fp32 -- embeddings and their LayerNorm are not autocast operators -- and the first GEMM's operand
+    # is its rounded copy)
     x, z_e, mean_e, rstd_e = ops.bert_embed_fwd(ids32, p[bm + "embeddings.word_embeddings.weight"],
                                                 p[bm + "embeddings.position_embeddings.weight"], type0,
                                                 p[bm + "embeddings.LayerNorm.weight"], p[bm + "embeddings.LayerNorm.bias"],
-                                                eps, T, dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
+                                                eps, T, torch.float32 if res32 else dtype, p_out=drop.p_hidden, seed_out=drop.site(0))
+    xr = None
+    if res32:
+        xr, x = x, ops.cast(x, dtype)
     cu, tok_idx = None, None
     n_layers = len(prep["layers"])
     order = packing[2] if packing is not None and len(packing) > 2 else None     # rows in token-id order, for the backward's word scatter
@@ -516,6 +560,8 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
             cu, tok_idx = None, None
         else:
             x = ops.indexed_rows_copy(x, torch.empty((tok_idx.numel(), H), device=x.device, dtype=dtype), in_idx=tok_idx)
+            if xr is not None:
+                xr = ops.indexed_rows_copy(xr, torch.empty((tok_idx.numel(), H), device=x.device, dtype=torch.float32), in_idx=tok_idx)
             keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
     elif (UNPAD_DEFAULT if unpad is None else unpad) and n_layers > 0:
         mask = text[:, T:]
@@ -525,7 +571,11 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
             cu, tok_idx = None, None          # nothing to drop
         else:
             x = ops.indexed_rows_copy(x, torch.empty((tok_idx.numel(), H), device=x.device, dtype=dtype), in_idx=tok_idx)
+            if xr is not None:
+                xr = ops.indexed_rows_copy(xr, torch.empty((tok_idx.numel(), H), device=x.device, dtype=torch.float32), in_idx=tok_idx)
             keep = torch.ones(tok_idx.numel(), device=x.device, dtype=torch.float32)
+    if res32:
+        x = (x, xr)
     saved_layers = []
     for l, w in enumerate(prep["layers"]):
         if on_use is not None:
@@ -537,11 +587,12 @@ def bert_forward(p: dict, prep, text: torch.Tensor, heads: int, dtype, need_grad
             x, sv = layer_forward(cfg, w, x, keep, Nc, ng, drop, 1 + 3 * l, cu)
         saved_layers.append(sv)
     if n_layers == 0:
-        cls = ops.strided_rows_copy(x, torch.empty((Nc, H), device=x.device, dtype=dtype), Nc, H, T, 1)
+        x16 = x[0] if res32 else x
+        cls = ops.strided_rows_copy(x16, torch.empty((Nc, H), device=x16.device, dtype=dtype), Nc, H, T, 1)
     if on_use is not None:
         on_use("head")
     D = prep["fc"].w.shape[0]
-    pre = torch.empty((Nc, D), device=x.device, dtype=dtype) if need_grad else None
+    pre = torch.empty((Nc, D), device=cls.device, dtype=dtype) if need_grad else None
     item = ops.gemm_nt(cls, prep["fc"].w, bias=p[prefix + "fc.bias"], act=ACT_GELU, aux_out=pre)
     saved = (cfg, ids32, z_e, mean_e, rstd_e, saved_layers, cls, pre, Nc, T, H, drop, tok_idx, grad_from, order, inv) if need_grad else None
     return item, saved
@@ -596,19 +647,19 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
     if tok_idx is not None:   # back to the padded layout the embedding stage (and its dropout stream) lives in: [PAD] rows get zero
         if inv is not None:     # one gather per tensor, [PAD] rows written as zeros (no fill)
             da = ops.indexed_rows_copy(da, torch.empty((Nc * T, H), device=da.device, dtype=da.dtype), in_idx=inv)
-            if db is not None:
-                db = ops.indexed_rows_copy(db, torch.empty((Nc * T, H), device=da.device, dtype=da.dtype), in_idx=inv)
+            if db is not None:      # (res32: the residual stream's gradient is fp32, da 16-bit)
+                db = ops.indexed_rows_copy(db, torch.empty((Nc * T, H), device=da.device, dtype=db.dtype), in_idx=inv)
         else:
             pa = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
             ops.indexed_rows_copy(da, pa, out_idx=tok_idx)
             if db is not None:
-                pb = torch.zeros((Nc * T, H), device=da.device, dtype=da.dtype)
+                pb = torch.zeros((Nc * T, H), device=da.device, dtype=db.dtype)
                 ops.indexed_rows_copy(db, pb, out_idx=tok_idx)
                 db = pb
             da = pa
     dz_e, _ = ops.layernorm_bwd(da, db, z_e, mean_e, rstd_e, p[bm + "embeddings.LayerNorm.weight"],
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
-                                p_out=drop.p_hidden, seed_out=drop.site(0))
+                                p_out=drop.p_hidden, seed_out=drop.site(0), sub16=False)
     if order is None:      # integer bookkeeping: rows in token-id order for the run-length scatter (the collate can supply it: token_packing_host)
         order = torch.argsort(ids32).to(torch.int32)
     ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],

@@ -20,14 +20,15 @@ class SasrecFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_in, log_mask, cfg, *params):
-        names, heads, n_layers, dtype, prefix, drop = cfg
+        names, heads, n_layers, dtype, prefix, drop = cfg[:6]
+        res32 = bool(cfg[6]) if len(cfg) > 6 else False      # the autocast data flow: fp32 residual stream (engine.LayerCfg.res32)
         p = dict(zip(names, params))
         need = any(ctx.needs_input_grad)
         x = x_in.contiguous()
         if x.dtype != dtype:
             x = ops.cast(x, dtype)
         prep = engine.sasrec_prepare(p, n_layers, dtype, prefix)
-        out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix, drop)
+        out, saved = engine.sasrec_forward(p, prep, x, log_mask, heads, need, prefix, drop, res32=res32)
         ctx.stuff = (p, prep, saved, names, prefix, x_in.dtype, tuple(x_in.shape))
         ctx.fp32_gemm = ops.FP32_GEMM
         return out.view(x_in.shape)
@@ -53,13 +54,14 @@ class BertEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, text, cfg, *params):
-        names, heads, n_layers, dtype, prefix, eps, mask_value, drop = cfg
+        names, heads, n_layers, dtype, prefix, eps, mask_value, drop = cfg[:8]
+        res32 = bool(cfg[8]) if len(cfg) > 8 else False
         p = dict(zip(names, params))
         need = any(ctx.needs_input_grad)
         prep = engine.bert_prepare(p, n_layers, dtype, prefix)
         # the backward stops at the lowest trainable point of the tower (T/run.py:73-75 freezes a prefix by parameter index)
         grad_from = engine.bert_grad_from([n for n, nd in zip(names, ctx.needs_input_grad[2:]) if nd], n_layers, prefix)
-        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop, grad_from=grad_from)
+        item, saved = engine.bert_forward(p, prep, text, heads, dtype, need, eps, mask_value, prefix, drop, grad_from=grad_from, res32=res32)
         ctx.stuff = (p, prep, saved, names, prefix, grad_from)
         ctx.needs = ctx.needs_input_grad
         ctx.fp32_gemm = ops.FP32_GEMM

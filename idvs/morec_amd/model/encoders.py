@@ -19,7 +19,16 @@ def resolve_dtype(args=None) -> torch.dtype:
     tensors everywhere, the GEMMs as three bf16 MFMA passes over hi / lo splits of both operands (``resolve_fp32_gemm``)."""
     name = getattr(args, "compute_dtype", None) or os.environ.get("MOREC_DTYPE", "bf16")
     return {"fp32": torch.float32, "float32": torch.float32, "fp32x3": torch.float32, "bf16": torch.bfloat16,
-            "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}[str(name)]
+            "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+            "fp16_res32": torch.float16, "bf16_res32": torch.bfloat16}[str(name)]
+
+
+def resolve_res32(args=None) -> bool:
+    """``compute_dtype`` "fp16_res32" / "bf16_res32": 16-bit GEMM operands and outputs with an fp32 RESIDUAL STREAM (LayerNorm takes the
+    fp32 residual, returns fp32 and a rounded copy for the next GEMM) -- the data flow of the reference's ``torch.cuda.amp.autocast()``
+    step (``T/run.py:242``; autocast runs layer_norm and softmax in fp32).  Text / ID towers; the Swin tower keeps 16-bit residuals."""
+    name = getattr(args, "compute_dtype", None) or os.environ.get("MOREC_DTYPE", "bf16")
+    return str(name).endswith("_res32")
 
 
 def resolve_fp32_gemm(args=None) -> str:
@@ -29,11 +38,12 @@ def resolve_fp32_gemm(args=None) -> str:
 
 
 class User_Encoder(nn.Module):
-    def __init__(self, item_num, max_seq_len, item_dim, num_attention_heads, dropout, n_layers, compute_dtype=None):
+    def __init__(self, item_num, max_seq_len, item_dim, num_attention_heads, dropout, n_layers, compute_dtype=None, res32=None):
         super().__init__()
         self.transformer_encoder = TransformerEncoder(n_vocab=item_num, n_position=max_seq_len, d_model=item_dim,
                                                       n_heads=num_attention_heads, dropout=dropout, n_layers=n_layers)
         self.compute_dtype = compute_dtype or resolve_dtype()
+        self.res32 = resolve_res32() if res32 is None else bool(res32)
         self.apply(self._init_weights)
 
     def _init_weights(self, module):   # T/model/encoders.py:15-21
@@ -48,7 +58,7 @@ class User_Encoder(nn.Module):
         """[B, S, D] -> [B, S, D] in the compute dtype (internal path of ``Model.forward``)."""
         names, params = zip(*self.named_parameters())
         te = self.transformer_encoder
-        cfg = (names, te.n_heads, te.n_layers, self.compute_dtype, "transformer_encoder.", drop)
+        cfg = (names, te.n_heads, te.n_layers, self.compute_dtype, "transformer_encoder.", drop, self.res32)
         return F_.SasrecFn.apply(input_embs, log_mask, cfg, *params)
 
     def forward(self, input_embs, log_mask, local_rank=None):
@@ -57,11 +67,12 @@ class User_Encoder(nn.Module):
 
 
 class Text_Encoder(nn.Module):
-    def __init__(self, bert_model, item_embedding_dim, word_embedding_dim, compute_dtype=None):
+    def __init__(self, bert_model, item_embedding_dim, word_embedding_dim, compute_dtype=None, res32=None):
         super().__init__()
         self.bert_model = bert_model if isinstance(bert_model, HipBertModel) else HipBertModel.from_hf(bert_model)
         self.fc = nn.Linear(word_embedding_dim, item_embedding_dim)
         self.compute_dtype = compute_dtype or resolve_dtype()
+        self.res32 = resolve_res32() if res32 is None else bool(res32)
         self.mask_value = FLT_MIN_MASK   # transformers >= 4.3x eager; set to -10000.0 for 4.20.1 behaviour
 
     def encode(self, text, drop: DropCfg = NO_DROP):
@@ -69,7 +80,7 @@ class Text_Encoder(nn.Module):
         named = [(n, p) for n, p in self.named_parameters() if ".pooler." not in n]
         names, params = zip(*named)
         cfg = (names, c.num_attention_heads, c.num_hidden_layers, self.compute_dtype, "", c.layer_norm_eps, self.mask_value,
-               drop)
+               drop, self.res32)
         return F_.BertEncoderFn.apply(text, cfg, *params)
 
     def forward(self, text):
@@ -91,7 +102,7 @@ class Bert_Encoder(nn.Module):
         if 'opt' in args.bert_model_load:
             raise NotImplementedError("OPT mean-pooling encoder (T/model/encoders.py:31-50) is outside the hot path")
         self.text_encoders = nn.ModuleDict({
-            'title': Text_Encoder(bert_model, args.embedding_dim, args.word_embedding_dim, resolve_dtype(args))})
+            'title': Text_Encoder(bert_model, args.embedding_dim, args.word_embedding_dim, resolve_dtype(args), resolve_res32(args))})
         # (the reference iterates a set intersection, i.e. in hash order; the mean over attributes does not depend on it -- a fixed order
         # keeps the fp32 sum of three passes identical across processes)
         self.newsname = [name for name in ('title', 'abstract', 'body') if name in set(args.news_attributes)]

@@ -10,7 +10,7 @@ from torch.nn.init import xavier_normal_
 
 from .. import engine, ops
 from .. import functional as F_
-from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, Vit_Encoder, resolve_dtype, resolve_fp32_gemm
+from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, Vit_Encoder, resolve_dtype, resolve_fp32_gemm, resolve_res32
 
 
 class Model(nn.Module):
@@ -21,6 +21,7 @@ class Model(nn.Module):
         self.max_seq_len = args.max_seq_len
         self.compute_dtype = resolve_dtype(args)
         self.fp32_gemm = resolve_fp32_gemm(args)                      # "exact" | "bf16x3": how fp32 GEMMs run (ops.FP32_GEMM)
+        self.res32 = resolve_res32(args) and not hasattr(args, "CV_model_load")      # fp32 residual stream (autocast data flow): text / ID towers
         self.pop_prob_list = torch.FloatTensor(pop_prob_list)        # plain attribute, as in T/model/model.py:14
         self._log_pop = None                                          # log(pop) table, built once per device
         # pooled negatives across ranks; off = the reference's rank-local negatives
@@ -29,7 +30,7 @@ class Model(nn.Module):
         self.pool_loss_mult = None
         self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
                                          num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
-                                         n_layers=args.transformer_block, compute_dtype=self.compute_dtype)
+                                         n_layers=args.transformer_block, compute_dtype=self.compute_dtype, res32=self.res32)
         self.vision = hasattr(args, "CV_model_load")
         if self.use_modal and self.vision:
             if "swin" not in args.CV_model_load:

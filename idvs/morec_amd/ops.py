@@ -15,6 +15,19 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F16, F32, AttnDesc, CeDesc
 FLT_MIN_MASK = -3.4028234663852886e38  # torch.finfo(torch.float32).min: HF eager additive key mask
 
 
+# Deterministic mode (``MOREC_DETERMINISTIC=1`` in the environment, or ``set_deterministic(True)``): the library's kernels that end in
+# fp32 atomics (LayerNorm / bias column sums, the embedding-table scatters) fold per-block partials in a fixed order instead, and the
+# engines keep the split-K of the exact-fp32 weight-gradient GEMMs at one -- two runs of the same step give the same bits.  The
+# reference sets torch's deterministic flags (``T/run.py:313-314``).  Covers the text / ID towers; see DESIGN.md §3.
+DETERMINISTIC = os.environ.get("MOREC_DETERMINISTIC", "0") not in ("", "0")
+
+
+def set_deterministic(on: bool = True):
+    global DETERMINISTIC
+    check(_lib.lib().morec_tuning_set(b"deterministic", int(bool(on))), "morec_tuning_set(deterministic)")
+    DETERMINISTIC = bool(on)
+
+
 def code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return F32
@@ -318,11 +331,44 @@ def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_per
     return y, (z if need_z else x), mean, rstd
 
 
+def layernorm_fwd_res32(x16, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+    """LayerNorm of the autocast data flow (``morec_layernorm_fwd_res32``; ``*_res32`` compute modes): ``x16`` is the 16-bit output of the
+    sub-layer's GEMM, ``res`` the fp32 residual stream.  Returns (y16, y32, z32, mean, rstd): the next GEMM's operand, the fp32 residual
+    stream, and what the backward needs."""
+    _dev(x16)
+    M, N = x16.shape
+    z = torch.empty((M, N), device=x16.device, dtype=torch.float32)
+    y32 = torch.empty((M, N), device=x16.device, dtype=torch.float32)
+    y16 = torch.empty_like(x16)
+    mean = torch.empty(M, device=x16.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=x16.device, dtype=torch.float32)
+    check(_lib.lib().morec_layernorm_fwd_res32(_p(x16), _p(bias), _p(res), _p(pos), pos_period, _p(gamma), _p(beta), eps, _p(z), _p(y32), _p(y16),
+                                               _p(mean), _p(rstd), M, N, code(x16.dtype), p_in, seed_in, p_out, seed_out, _stream()),
+          "morec_layernorm_fwd_res32")
+    return y16, y32, z, mean, rstd
+
+
+def layernorm_bwd_res32(dy16, dy32, z, mean, rstd, gamma, dgamma, dbeta, dtype16, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None, sub16=True):
+    """Backward of ``layernorm_fwd_res32``: returns (dz32, dzd16) -- the fp32 gradient along the residual stream and the 16-bit gradient of
+    the sub-layer output (None with ``sub16=False``: embedding stages, where nothing 16-bit sits below the LayerNorm)."""
+    M, N = z.shape
+    dz = torch.empty((M, N), device=z.device, dtype=torch.float32)
+    dzd = torch.empty((M, N), device=z.device, dtype=dtype16) if sub16 else None
+    check(_lib.lib().morec_layernorm_bwd_res32(_p(dy16), _p(dy32), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dzd), _p(dgamma), _p(dbeta),
+                                               _p(dbias), M, N, code(dtype16), p_in, seed_in, p_out, seed_out, _stream()), "morec_layernorm_bwd_res32")
+    return dz, dzd
+
+
 def layernorm_bwd(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None,
-                  dres=None, rowscale=None, rows_per_scale=0):
+                  dres=None, rowscale=None, rows_per_scale=0, sub16=True):
     """Returns (dz, dzd): dz feeds the residual branch, dzd = dropout / DropPath backward of dz feeds the sub-layer (dzd is
-    dz when p_in = 0 and there is no rowscale).  ``dres``: gradient arriving at z along a pre-LN residual stream."""
+    dz when p_in = 0 and there is no rowscale).  ``dres``: gradient arriving at z along a pre-LN residual stream.
+    An fp32 ``z`` with a 16-bit ``dy_a`` is the autocast data flow (``layernorm_fwd_res32``): dz is then the fp32 residual-stream gradient
+    (``dy_b`` is fp32 too) and dzd the 16-bit sub-layer gradient (``sub16=False``: not wanted, None)."""
     _dev(dy_a)
+    if z.dtype == torch.float32 and is16(dy_a.dtype):
+        assert dres is None and rowscale is None and (dy_b is None or dy_b.dtype == torch.float32)
+        return layernorm_bwd_res32(dy_a, dy_b, z, mean, rstd, gamma, dgamma, dbeta, dy_a.dtype, p_in, seed_in, p_out, seed_out, dbias, sub16)
     M, N = z.shape
     dz = torch.empty_like(z)
     dzd = torch.empty_like(z) if (p_in > 0 or rowscale is not None) else None

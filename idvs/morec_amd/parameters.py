@@ -52,11 +52,12 @@ def build_parser():
                    help="uint8 array [item_num + 1, R, R, 3] of decoded, resized item images (row 0 = padding item); stands in for the "
                         "LMDB reader of V/data_utils/dataset.py, whose lmdb / torchvision dependencies are not part of this package")
     # ============== MI355X path ==============
-    p.add_argument("--compute_dtype", type=str, default="fp16", choices=["bf16", "fp16", "fp32", "fp32x3"],
+    p.add_argument("--compute_dtype", type=str, default="fp16", choices=["bf16", "fp16", "fp32", "fp32x3", "fp16_res32", "bf16_res32"],
                    help="fp16 (default) = IEEE half operands on the MFMA, fp32 accumulate, with the reference's GradScaler loss scaling -- the arithmetic of "
                         "its own autocast step (T/run.py:210,242-247; V/run.py likewise) and what bench.py times; bf16 = the same kernels on bf16 operands, no "
                         "loss scaling; fp32 = exact-fp32 MFMA parity mode; fp32x3 = fp32 tensors with every GEMM as three bf16 MFMA passes over hi / lo "
-                        "operand splits (fp32 nn.Linear numerics to ~1e-5)")
+                        "operand splits (fp32 nn.Linear numerics to ~1e-5); fp16_res32 / bf16_res32 = 16-bit GEMMs with an fp32 residual stream "
+                        "(LayerNorm in and out fp32): the data flow of torch.cuda.amp.autocast itself, text / ID towers")
     p.add_argument("--pool_negatives", action="store_true", help="pool in-batch negatives over ranks (RCCL all-gather)")
     p.add_argument("--fused_step", action="store_true",
                    help="flat-arena TrainStep (fused AdamW, one gradient all-reduce) instead of DDP + torch.optim.AdamW")

@@ -425,7 +425,7 @@ def train(args, use_modal, local_rank):
             optimizer.load_state_dict(ckpt["optimizer"])
     # T/run.py:210: `scaler = torch.cuda.amp.GradScaler()` -- engaged for the fp16 compute dtype (bf16 / fp32 gradients need no scaling);
     # the fused step keeps the same protocol in its device block (TrainStep.sp)
-    scaler = torch.amp.GradScaler("cuda", enabled=True) if (optimizer is not None and args.compute_dtype == "fp16") else None
+    scaler = torch.amp.GradScaler("cuda", enabled=True) if (optimizer is not None and args.compute_dtype in ("fp16", "fp16_res32")) else None
     if scaler is not None and ckpt is not None and ckpt.get("scaler_state"):
         scaler.load_state_dict(ckpt["scaler_state"])
     best, step = 0.0, 0

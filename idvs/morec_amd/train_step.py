@@ -156,6 +156,7 @@ class TrainStep:
         # share one mask instead of drawing independent ones (documented deviation, hence opt-in).
         self.dedup_items = bool(dedup_items)
         self.dtype = model.compute_dtype
+        self.res32 = bool(getattr(model, "res32", False))      # 16-bit GEMMs with an fp32 residual stream: the reference autocast's data flow
         self.device = next(model.parameters()).device
         self.betas, self.eps = betas, eps
         self.pool = pool_negatives
@@ -243,9 +244,10 @@ class TrainStep:
         # backward pass as it does without a block.  With scaling the decision needs the whole step's gradients and comes last.
         self._decide_first = self.sp is not None and not self.sp.dynamic and init == 1.0
         self._decided = False
-        self._graphs, self._graph_pool = {}, None
-        if self.graph:
-            self.sp.use_as_seed_source(True)
+        # one captured graph (+ its static inputs and its share of the graph memory pool) per input shape, at most ``graph_max`` of them
+        # (MOREC_GRAPH_MAX, default 8): shapes beyond that run as plain eager steps instead of growing the pool without bound
+        self._graphs, self._graph_pool = OrderedDict(), None
+        self.graph_max = max(1, int(os.environ.get("MOREC_GRAPH_MAX", "8")))
         self.buckets = self._bucket_plan()
         if defer_update is None:
             defer_update = os.environ.get("MOREC_DEFER_UPDATE", "0") == "1"
@@ -447,7 +449,8 @@ class TrainStep:
                 sub = sample_items if n_attr == 1 else sample_items[:, a0:a0 + aw].contiguous()
                 passes.append(engine.bert_forward(p, prep_b, sub, self.bert_heads, self.dtype, True, self.bert_eps,
                                                   self.bert_mask_value, engine.TE, d_item.stream(ai), grad_from=self.bert_grad_from,
-                                                  packing=packs[ai], on_use=self._await_params if (self._param_ready and ai == 0) else None))
+                                                  packing=packs[ai], on_use=self._await_params if (self._param_ready and ai == 0) else None,
+                                                  res32=self.res32))
             E = passes[0][0] if n_attr == 1 else ops.scaled_sum([e for e, _ in passes], 1.0 / n_attr)      # encoders.py:113-116: the mean
             self._await_params(None)      # whatever the tower did not ask for (the recommender group's slice) before SASRec reads it
         else:
@@ -459,7 +462,7 @@ class TrainStep:
         B = log_mask.shape[0]
         x_in = E.view(B, S + 1, D)[:, :-1, :].contiguous()
         prep_s = engine.sasrec_prepare(p, m.args.transformer_block, self.dtype, engine.UE, self.sh)
-        P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE, d_user)
+        P, saved_s = engine.sasrec_forward(p, prep_s, x_in, log_mask, m.args.num_attention_heads, True, engine.UE, d_user, res32=self.res32)
         if side is not None:       # scoring bookkeeping done, gradient arenas zeroed, W^T copies in place
             torch.cuda.current_stream(self.device).wait_stream(side)
         Epool = E
@@ -838,17 +841,37 @@ class TrainStep:
 
     def _step_body(self, sample_items_id, sample_items, log_mask, token_packing, defer: bool):
         self._fused_update = os.environ.get("MOREC_EARLY_ADAMW", "1") != "0"     # only here: forward_backward alone must leave the parameters untouched
+        # graph mode: the dropout / DropPath kernels of THIS step fold the step block's seed word into their seeds (a captured launch keeps
+        # the pointer in its arguments, so replays keep drawing fresh masks).  The registration is process-wide state of the library, so
+        # it lasts exactly as long as the step: other models / steppers of the process draw the masks their own seed arguments name.
+        if self.graph:
+            self.sp.use_as_seed_source(True)
         try:
-            loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
+            try:
+                loss = self.forward_backward(sample_items_id, sample_items, log_mask, token_packing)
+            finally:
+                self._fused_update = False
+            self.reduce_gradients()
+            self._in_step = defer
+            try:
+                self.optimizer_step()
+            finally:
+                self._in_step = False
         finally:
-            self._fused_update = False
-        self.reduce_gradients()
-        self._in_step = defer
-        try:
-            self.optimizer_step()
-        finally:
-            self._in_step = False
+            if self.graph:
+                self.sp.use_as_seed_source(False)
         return loss
+
+    def close(self):
+        """Drop the captured graphs (and with them the static inputs and the graph memory pool) and make sure the library holds no
+        pointer into this stepper's step block.  The stepper stays usable: later steps run eagerly / re-capture."""
+        self.flush()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._graphs.clear()
+        self._graph_pool = None
+        if self.sp is not None:
+            self.sp.use_as_seed_source(False)
 
     def _throttle(self):
         """Two steps in flight keep the device queue full; the host waits for the step before the previous one (see ``step``)."""
@@ -873,7 +896,14 @@ class TrainStep:
         key = tuple((tuple(t.shape), t.dtype) for t in ins)
         ent = self._graphs.get(key)
         if ent is None:            # first sight of this shape: eager
+            if sum(1 for v in self._graphs.values() if v != "seen") >= self.graph_max:      # the cache is full: this shape stays eager
+                return self.step(sample_items_id, sample_items, log_mask, token_packing)
+            if len(self._graphs) >= 8 * self.graph_max:      # "seen" markers of shapes that never came back
+                for k in [k for k, v in self._graphs.items() if v == "seen"][: len(self._graphs) // 2]:
+                    del self._graphs[k]
             self._graphs[key] = "seen"
+            return self.step(sample_items_id, sample_items, log_mask, token_packing)
+        if ent == "seen" and sum(1 for v in self._graphs.values() if v != "seen") >= self.graph_max:
             return self.step(sample_items_id, sample_items, log_mask, token_packing)
         if ent == "seen":
             self.flush()

@@ -131,7 +131,11 @@ int morec_mlp_dact_recompute(const void* dY, const void* W2t, const void* X, con
 /* Weight-gradient GEMM without transposed copies (16-bit operands only; MOREC_E_UNSUPPORTED otherwise):
  * C[N, K] (+)= sum_m DY[m, n] * X[m, k], fp32 C.  split_m > 1 cuts the token range over blockIdx.z; without a workspace that
  * requires accumulate != 0 (fp32 atomicAdd into a caller-zeroed C), with one the partial tiles are folded by a second kernel and
- * accumulate == 0 overwrites C.  Autograd backward of nn.Linear: dW = dY^T X. */
+ * accumulate == 0 overwrites C.  Autograd backward of nn.Linear: dW = dY^T X.
+ * SINGLE WRITER: with accumulate != 0 the update of C is a plain read-modify-write (the slab fold; with one token chunk the GEMM's own
+ * 16-byte lanes), not an atomic.  Every kernel that adds into the same C must therefore be ordered with this call -- the same stream, or
+ * an event between the streams.  (The engines issue all weight-gradient GEMMs of a step on ONE stream, engine.WgradStream; a tied weight
+ * accumulated from two streams at once would lose updates.) */
 int morec_gemm_tn(const void* DY, const void* X, float* C, int M, int N, int K, int ldy, int ldx, int ldc, int dtype,
                   int split_m, int accumulate, float* workspace, void* stream);
 /* workspace (optional, fp32): morec_gemm_tn_workspace_bytes(N, K, split_m).  With it the split-m partial tiles are written
@@ -198,6 +202,24 @@ int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const
                         const float* gamma, void* dz, void* dzd, float* dgamma, float* dbeta, float* dbias, int M, int N,
                         int dtype, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, const void* dres,
                         const float* rowscale, int rows_per_scale, void* stream);
+
+/* LayerNorm of the reference's AUTOCAST data flow -- the `*_res32` compute modes.  Under `torch.cuda.amp.autocast()` (T/run.py:242) nn.Linear
+ * takes and returns 16-bit tensors while LayerNorm runs and RETURNS fp32 (HF modeling_bert.py BertSelfOutput / BertOutput: LayerNorm(dropout(
+ * dense(h)) + input_tensor); T/model/modules.py:14-17,61-63,93-94): the residual stream is fp32, only GEMM operands are rounded.
+ *   forward:  z32 = drop_in(x16 (+ bias)) (+ res32) (+ pos[m % pos_period]);  y32 = drop_out(LN(z32) * gamma + beta);  y16 = round(y32).
+ *             x16: 16-bit output of the sub-layer's GEMM (dtype16 = MOREC_BF16 | MOREC_F16); z32 (saved for the backward), y32 (the residual
+ *             stream: the next LayerNorm's res32) and y16 (the next GEMM's operand) may each be NULL, not all of y32 / y16.
+ *   backward: dz32 = LN'(drop_out'(dy16 + dy32); z32)  (dy16: gradient through the GEMM that read y16; dy32: gradient along the residual
+ *             stream; either may be NULL);  dzd16 = round(drop_in'(dz32)): the 16-bit gradient of the sub-layer output, what its weight- /
+ *             input-gradient GEMMs read.  dgamma / dbeta / dbias (= column sums of dzd16 as stored) are accumulated into, as in
+ *             morec_layernorm_bwd.  dz32 or dzd16 may be NULL.
+ * N % 8 == 0, N <= 4096, all tensors contiguous and 16-byte aligned.  Dropout streams: as morec_layernorm_fwd. */
+int morec_layernorm_fwd_res32(const void* x16, const float* bias, const float* res32, const float* pos, int pos_period, const float* gamma,
+                              const float* beta, float eps, float* z32, float* y32, void* y16, float* mean, float* rstd, int M, int N,
+                              int dtype16, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
+int morec_layernorm_bwd_res32(const void* dy16, const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
+                              float* dz32, void* dzd16, float* dgamma, float* dbeta, float* dbias, int M, int N, int dtype16, float p_in,
+                              uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
 /* dpos[m % period, n] += dz[m, n]  (position-embedding gradient, fp32 atomics) */
 int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream);
 

@@ -299,7 +299,7 @@ def test_g19_two_text_attributes_golden(golden_dir, dtype):
         print(f"g19 {dtype} fused step (packed={packed}): loss {loss2.item():.6f}, worst grad-norm rel err {worst2:.2e}")
 
 
-@pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16")])
+@pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16"), (10, 30, "fp16_res32"), (40, 50, "fp16_res32")])
 def test_oracle_midsize_all_grads(S, T, dt):
     """Every parameter gradient of a mid-size modal model against the CPU oracle (autograd over the restatement).  (40, 50): behaviour
     sequences and texts longer than the 32-row attention tile -- abstracts / bodies of 50 tokens (T/parameters.py:43-44) -- run on the
@@ -330,7 +330,7 @@ def test_oracle_midsize_all_grads(S, T, dt):
         lm[b, S + 1 - L:] = 1
     items = content[ids.reshape(-1)]
     loss = m(torch.from_numpy(ids).to(DEV).view(-1), torch.from_numpy(items).to(DEV), torch.from_numpy(lm).to(DEV), DEV)
-    gs = 256.0 if dt == "fp16" else 1.0        # fp16: a fixed loss scale (the training step's GradScaler does it dynamically)
+    gs = 256.0 if dt.startswith("fp16") else 1.0        # fp16: a fixed loss scale (the training step's GradScaler does it dynamically)
     (loss * gs).backward()
     tol_l, tol_g = (5e-5, 5e-4) if dt == "fp32" else (2e-3, 2e-2)
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
