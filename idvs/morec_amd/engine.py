@@ -186,12 +186,12 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     The FFN's first GEMM leaves the activation's DERIVATIVE act'(x1 W1^T + b1) beside its output (one erf / exp evaluation serves
     both), so the backward's dU = (dZ W2) * act' is a plain multiply in that GEMM's epilogue."""
     dh = cfg.H // cfg.heads
+    x0r = None
+    if cfg.res32:      # (x16, x32): the GEMM operand and the fp32 residual stream
+        x0, x0r = x0
     desc = ops.attn_desc(n_seq, cfg.T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
                          drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
     ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
-    x0r = None
-    if cfg.res32:
-        x0, x0r = x0
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     a = ops.gemm_nt(ctx, w["o"].w)
@@ -259,12 +259,12 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     same arithmetic.  Returns x2 restricted to the [CLS] rows: [n_seq, H]."""
     dh = cfg.H // cfg.heads
     H, T = cfg.H, cfg.T
-    desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
-                         drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
-    ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     x0r = None
     if cfg.res32:
         x0, x0r = x0
+    desc = ops.attn_desc(n_seq, T, cfg.heads, dh, cfg.causal, 1.0 / math.sqrt(dh), cfg.mask_value, x0.dtype,
+                         drop.p_attn, drop.site(site0), cu, total_rows=x0.shape[0])
+    ph, s1, s2 = drop.p_hidden, drop.site(site0 + 1), drop.site(site0 + 2)
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     ctx_c = gather_cls(ctx, n_seq, T, cu)

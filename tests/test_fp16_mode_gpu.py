@@ -41,7 +41,18 @@ def test_g6_reference_golden_in_fp16(golden_dir, name, mode):
     ref = float(gd[f"{name}.loss"])
     print(f"g6 {name} {mode}: loss {loss.item():.6f} ref {ref:.6f} (|d| {abs(loss.item() - ref):.2e}, rel {abs(loss.item() - ref) / ref:.2e})")
     assert abs(loss.item() - ref) / ref < 1e-3                # north_star: loss within 1e-3 (relative)
-    assert abs(loss.item() - ref) < 5e-3                      # absolute: an eighth of the bf16 mode's bound (5e-2, test_model_gpu.py)
+    # Absolute: these goldens average only 86 (tiny) / 35 (base) loss rows, so the per-row rounding noise of 16-bit GEMM operands does not
+    # average out (at the bench configuration, 2 560 rows, the res32 mode is at 2.9e-4: the test below).  The yardstick is what the
+    # REFERENCE's own autocast arithmetic does to the same loss: g20 (tests/golden/make_autocast_floor.py: the imported reference under
+    # torch.autocast('cpu', fp16)) -- tiny 7.9e-3, base 5.0e-3 away from its fp32 value.  The HIP modes must be inside that.
+    import json
+    with open(os.path.join(golden_dir, "g20_autocast_floor.json")) as fh:
+        floor = json.load(fh)[name]
+    assert abs(floor["fp32"] - ref) < 1e-6                    # the same fp32 number as golden g6
+    ref_gap = abs(floor["autocast_fp16"] - floor["fp32"])
+    print(f"g6 {name} {mode}: |loss - fp32 reference| {abs(loss.item() - ref):.2e}; the reference's own fp16 autocast: {ref_gap:.2e}")
+    assert abs(loss.item() - ref) < ref_gap
+    assert abs(loss.item() - ref) < 4e-3
     S = 1024.0
     (loss * S).backward()                                     # T/run.py:243: scaler.scale(loss).backward()
     named = dict(m.named_parameters())
@@ -61,8 +72,9 @@ def test_g6_reference_golden_in_fp16(golden_dir, name, mode):
     assert worst < 3e-2
 
 
-# step-0 loss of the fp16_res32 mode against the exact-fp32 mode at the bench configuration, ABSOLUTE (north_star: "loss within 1e-3")
-RES32_ABS_BOUND = 5e-3
+# step-0 loss of the fp16_res32 mode against the exact-fp32 mode at the bench configuration, ABSOLUTE (north_star: "loss within 1e-3";
+# measured on MI355X: 2.9e-4, gradient norms 8.7e-4, 20-step curve 3.8e-4 relative)
+RES32_ABS_BOUND = 1e-3
 
 
 def _build(dtype, shape, item_num, pop, S, T, D, state=None):
@@ -140,7 +152,7 @@ def test_fp16_bench_mode_is_inside_1e3_of_the_fp32_parity_mode_at_bench_config()
           f"gradient-norm rel. diff tower {gnr[0]:.2e}, recommender {gnr[1]:.2e}; {steps}-step loss curve max rel. diff {dcurve_r:.2e}")
     assert np.isfinite(cr).all()
     assert d0r < RES32_ABS_BOUND, d0r
-    assert max(gnr) < 1.5e-2 and dcurve_r < 1e-2, (gnr, dcurve_r)
+    assert max(gnr) < 5e-3 and dcurve_r < 2e-3, (gnr, dcurve_r)
     c32, c16 = np.array(curves["fp32"]), np.array(curves["fp16"])
     d0 = abs(c16[0] - c32[0])
     gn = [abs(a - b) / b for a, b in zip(gnorms["fp16"], gnorms["fp32"])]
