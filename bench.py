@@ -337,25 +337,52 @@ def main():
     ops.inbatch_ce_fwd, ops.inbatch_ce_bwd = timed_ce(real_ce_f, "fwd"), timed_ce(real_ce_b, "bwd")
 
     n_run = {"v": 0}
+    # --vision-input u8: the device half of the input pipeline runs on its OWN stream, one batch ahead (data_utils.images.DeviceImageFeed):
+    # H2D of the packed uint8 bytes + Pillow-exact resize + normalising patch im2col of batch k + 1 under the train step of batch k -- the
+    # overlap the reference gets from its DataLoader workers (V/run.py:93-94).  MOREC_BENCH_INLINE_INPUT=1: the round-4 arrangement (all of it
+    # on the step's stream, in front of the encoder) for an A/B.
+    dev_feed, ahead = None, {"v": None}
+    if u8_stats is not None and os.environ.get("MOREC_BENCH_INLINE_INPUT", "0") != "1":
+        from idvs.morec_amd.data_utils.images import DeviceImageFeed
+        dev_feed = DeviceImageFeed(dev, vshape.image_size, vshape.patch_size, model.compute_dtype)
+
+    def host_u8(i):
+        """the packed host batch of step i: from the collate thread when i is next in its order, else packed inline"""
+        if u8_feed is not None and u8_feed["pos"] < len(u8_feed["order"]) and u8_feed["order"][u8_feed["pos"]] == i:
+            _, hb = next(u8_feed["it"])          # built ahead by the collate thread (warm-up + headline region)
+            u8_feed["pos"] += 1
+            return hb
+        return tuple(t_.pin_memory() for t_ in make_u8(i))      # the passes after the headline
 
     def run_step(i):
         n_run["v"] += 1
         ids, items, lm, pack = host[i]
         ids_d = ids.to(dev, non_blocking=True)
-        if u8_stats is not None:     # host uint8 batch -> H2D -> Pillow-exact resize on the GPU -> uint8 [n, R, R, 3]
-            if u8_feed is not None and u8_feed["pos"] < len(u8_feed["order"]) and u8_feed["order"][u8_feed["pos"]] == i:
-                _, (flat, meta, tabs) = next(u8_feed["it"])          # built ahead by the collate thread (warm-up + headline region)
-                u8_feed["pos"] += 1
-            else:                                                        # the passes after the headline: packed inline
-                flat, meta, tabs = (t_.pin_memory() for t_ in make_u8(i))
+        slot = None
+        if u8_stats is not None and dev_feed is not None:
+            if ahead["v"] is not None and ahead["v"][0] == i:
+                slot = ahead["v"][1]
+            else:                                   # nothing queued for this batch (first step, or a pass that jumps around): queue it now
+                slot = dev_feed.submit(*host_u8(i))
+            ahead["v"] = None
+            if u8_feed is not None and u8_feed["pos"] < len(u8_feed["order"]):      # the NEXT batch: queued before this step's launches
+                j = u8_feed["order"][u8_feed["pos"]]
+                ahead["v"] = (j, dev_feed.submit(*host_u8(j)))
+            items_d = dev_feed.take(slot)
+        elif u8_stats is not None:     # host uint8 batch -> H2D -> Pillow-exact resize on the GPU -> uint8 [n, R, R, 3], on the step's stream
+            flat, meta, tabs = host_u8(i)
             items_d = ops.image_resize_u8_packed(flat, meta, tabs, vshape.image_size, dev)
         else:
             items_d = catalog[ids_d.view(-1)] if vision else items.to(dev, non_blocking=True)
         lm_d = lm.to(dev, non_blocking=True)
         pack_d = None if pack is None else tuple(t.to(dev, non_blocking=True) for t in pack)
         if use_graph["v"]:
-            return ts.step_graphed(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
-        return ts.step(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
+            loss = ts.step_graphed(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
+        else:
+            loss = ts.step(ids_d.view(-1), items_d, lm_d, token_packing=pack_d)
+        if slot is not None:
+            dev_feed.release(slot)
+        return loss
 
     def start_feed(order):
         """(u8 input) a collate thread that builds the batches `order` names, two ahead of the device"""
@@ -406,7 +433,9 @@ def main():
         u8_line = {"native_size": a.native_size, "uint8_bytes_per_step": u8_stats["bytes"],
                    "host_pack_ms_per_batch": round(u8_stats["pack_s"] / max(1, u8_stats["batches"]) * 1e3, 2),
                    "collate": "one thread, two batches ahead (run.BatchPrefetcher), page-locked",
-                   "in_timed_region": "H2D of the packed uint8 batch + morec_image_resize_u8 + morec_swin_patchify_u8 (ToTensor + Normalize fused) + the train step"}
+                   "in_timed_region": "H2D of the packed uint8 batch + morec_image_resize_u8 + morec_swin_patchify_u8 (ToTensor + Normalize fused) + the train step",
+                   "device_side": ("own HIP stream, one batch ahead of the step (data_utils.images.DeviceImageFeed: double-buffered, one event per batch)"
+                                   if dev_feed is not None else "on the step's stream, in front of the encoder (MOREC_BENCH_INLINE_INPUT=1)")}
         if u8_feed is not None:
             u8_feed["feeder"].close()
             u8_feed = None

@@ -176,3 +176,79 @@ class LmdbItemImages:
         imgs = self.store.batch([self.keys[int(i)] if int(i) != 0 else None for i in flat])
         out = ops.image_resize_u8(imgs, self.R, device)
         return out.view(*np.asarray(ids).shape, self.R, self.R, 3)
+
+
+class PatchRows:
+    """A batch of images that has already been through the normalising patch im2col (``morec_swin_patchify_u8``): what
+    ``swin_engine.swin_forward`` accepts in place of the pixel tensor.  ``patches`` [n_img (R / p)^2, 3 p^2] in the compute dtype."""
+
+    def __init__(self, patches, n_img):
+        self.patches, self.n_img = patches, int(n_img)
+        self.device, self.shape = patches.device, (int(n_img),)
+
+
+class DeviceImageFeed:
+    """Device half of the vision input pipeline, off the training step's stream.  The reference's DataLoader workers decode + resize
+    the NEXT batch's images while the GPU trains on the current one, and the main loop only uploads tensors (``V/run.py:93-94,201-204``,
+    ``V/data_utils/dataset.py:61-99``).  Here the decoded uint8 images cross PCIe and are resampled / normalised on the GPU, so the same
+    overlap is a second HIP stream: ``submit`` queues, for batch k + 1, the H2D copy of the packed bytes, ``morec_image_resize_u8`` and
+    ``morec_swin_patchify_u8`` on the feed's own stream into one of ``depth`` buffer sets, all under step k; ``take`` makes the step's
+    stream wait for that set (one event) and hands out ``PatchRows``; ``release`` (after the step's launches) marks the set reusable.
+    Buffers are allocated once per size on the caller's stream and reused -- nothing crosses between the streams' allocator pools."""
+
+    def __init__(self, device, R: int, patch: int, dtype, depth: int = 2):
+        import torch
+        self.dev, self.R, self.patch, self.dtype = torch.device(device), int(R), int(patch), dtype
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.slots = [dict(src=None, imgs=None, patches=None, ready=None, free=None, n=0) for _ in range(max(2, depth))]
+        self.k = 0
+
+    def _buf(self, slot, key, shape, dtype):
+        import torch
+        need = 1
+        for v in shape:
+            need *= int(v)
+        t = slot[key]
+        if t is None or t.numel() < need or t.dtype != dtype:
+            t = slot[key] = torch.empty(need + need // 8, device=self.dev, dtype=dtype)
+        return t[:need].view(*shape)
+
+    def submit(self, flat, meta, tabs=None):
+        """Queue one batch on the feed's stream.  ``flat, meta, tabs`` = ``pack_images`` output as (page-locked) CPU tensors; with
+        ``tabs=None``, ``flat`` is a uint8 [n, R, R, 3] CPU tensor of images that are already R x R (no resize: upload + im2col only)."""
+        import torch
+        from .. import ops
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        n = int(flat.shape[0]) if tabs is None else int(meta.shape[0])
+        G = self.R // self.patch
+        # buffers first, on the CALLER's stream (allocator pool of the step), then the work on the feed's stream
+        imgs = self._buf(slot, "imgs", (n, self.R, self.R, 3), torch.uint8)
+        patches = self._buf(slot, "patches", (n * G * G, 3 * self.patch * self.patch), self.dtype)
+        src = None if tabs is None else self._buf(slot, "src", (int(flat.numel()),), torch.uint8)
+        if slot["free"] is not None:      # the step that read this set last must be done with it
+            self.stream.wait_event(slot["free"])
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # (first use: the allocations above)
+        with torch.cuda.stream(self.stream):
+            if tabs is None:
+                imgs.copy_(flat, non_blocking=True)
+            else:
+                ops.image_resize_u8_packed(flat, meta, tabs, self.R, self.dev, out=imgs, src_buf=src)
+            ops.swin_patchify_u8(imgs, self.patch, self.dtype, out=patches)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        slot["ready"], slot["n"], slot["host"] = ev, n, (flat, meta, tabs)      # (the host tensors stay referenced until the set is reused)
+        slot["cur"] = (imgs, patches)
+        return slot
+
+    def take(self, slot) -> PatchRows:
+        import torch
+        torch.cuda.current_stream(self.dev).wait_event(slot["ready"])
+        return PatchRows(slot["cur"][1], slot["n"])
+
+    def release(self, slot):
+        import torch
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        slot["free"] = ev

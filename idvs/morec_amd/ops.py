@@ -666,14 +666,18 @@ def swin_patchify(pixels, patch, dtype):
     return out
 
 
-def swin_patchify_u8(pixels_hwc, patch, dtype, mean=0.5, std=0.5):
-    """uint8 [n, R, R, 3] decoded images -> normalised patch rows (ToTensor + Normalize(0.5, 0.5), V/data_utils/dataset.py:69-73)."""
+def swin_patchify_u8(pixels_hwc, patch, dtype, mean=0.5, std=0.5, out=None):
+    """uint8 [n, R, R, 3] decoded images -> normalised patch rows (ToTensor + Normalize(0.5, 0.5), V/data_utils/dataset.py:69-73).
+    ``out``: a caller-owned [n G G, 3 patch^2] buffer of ``dtype`` (the double-buffered input feed, ``data_utils.images.DeviceImageFeed``)."""
     _dev(pixels_hwc)
     if pixels_hwc.dtype != torch.uint8:
         raise _lib.MorecError("expected uint8 HWC images")
     n, R, _, c = pixels_hwc.shape
     G = R // patch
-    out = torch.empty((n * G * G, c * patch * patch), device=pixels_hwc.device, dtype=dtype)
+    if out is None:
+        out = torch.empty((n * G * G, c * patch * patch), device=pixels_hwc.device, dtype=dtype)
+    else:
+        assert out.shape == (n * G * G, c * patch * patch) and out.dtype == dtype and out.is_contiguous()
     check(_lib.lib().morec_swin_patchify_u8(_p(pixels_hwc), _p(out), n, c, R, patch, out.stride(0), mean, std, code(dtype), _stream()),
           "morec_swin_patchify_u8")
     return out
@@ -725,17 +729,26 @@ def probe(device="cuda"):
     return out
 
 
-def image_resize_u8_packed(flat, meta, tabs, R: int, device):
+def image_resize_u8_packed(flat, meta, tabs, R: int, device, out=None, src_buf=None):
     """``morec_image_resize_u8`` over a batch the HOST has already packed (``data_utils.images.pack_images``; CPU tensors, ideally
-    page-locked by a collate thread): three asynchronous H2D copies + the resize kernel on the current stream -> uint8 [n, R, R, 3]."""
+    page-locked by a collate thread): three asynchronous H2D copies + the resize kernel on the current stream -> uint8 [n, R, R, 3].
+    ``out`` / ``src_buf``: caller-owned device buffers for the result and for the packed source bytes (``DeviceImageFeed``)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise _lib.MorecError("libmorec_hip needs device tensors (no CPU fallback)")
     n = meta.shape[0]
-    src = flat.to(device, non_blocking=True)
+    if src_buf is not None:
+        assert src_buf.numel() >= flat.numel() and src_buf.dtype == torch.uint8
+        src = src_buf[:flat.numel()]
+        src.copy_(flat, non_blocking=True)
+    else:
+        src = flat.to(device, non_blocking=True)
     meta_d = meta.to(device, non_blocking=True)
     tabs_d = tabs.to(device, non_blocking=True)
-    out = torch.empty((n, R, R, 3), device=device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((n, R, R, 3), device=device, dtype=torch.uint8)
+    else:
+        assert out.shape == (n, R, R, 3) and out.dtype == torch.uint8 and out.is_contiguous()
     check(_lib.lib().morec_image_resize_u8(_p(src), _p(meta_d), _p(tabs_d), _p(out), n, R, _stream()), "morec_image_resize_u8")
     return out
 

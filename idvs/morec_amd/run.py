@@ -161,6 +161,16 @@ class _EpochSampler:
         return len(self.keys)
 
 
+def _with_next(it):
+    """(item, next item or None) pairs: one element of look-ahead over any iterator."""
+    it = iter(it)
+    cur = next(it, None)
+    while cur is not None:
+        nxt = next(it, None)
+        yield cur, nxt
+        cur = nxt
+
+
 def _to_device(t, dev):
     """Tensors of a (possibly nested) tuple to the device, asynchronously; None entries stay."""
     if t is None:
@@ -463,7 +473,14 @@ def train(args, use_modal, local_rank):
             source = feeder if feeder is not None else ((b_, make_batch(idx_)) for b_, idx_ in enumerate(batches))
         t0, loss_acc, t_mark, n_mark = time.time(), None, None, 0
         b = -1
-        for b, (ids, items, log_mask, pack) in source:
+        # Vision catalogue held as uint8 arrays on the host (--images_npy / synthetic; not the LMDB, whose collate does device work itself):
+        # the upload of the NEXT batch's images and their normalising patch im2col run on a second stream under the current step
+        # (data_utils.images.DeviceImageFeed: what the reference's DataLoader workers + pin thread overlap, V/run.py:93-94,201-204)
+        img_feed, img_ahead = None, None
+        if vision and args.fused_step and not on_device and stepper is not None and not stepper.graph and not stepper.dedup_items:
+            from .data_utils.images import DeviceImageFeed
+            img_feed = DeviceImageFeed(local_rank, args.CV_resize, stepper.swin_shape.patch_size, stepper.dtype)
+        for (b, (ids, items, log_mask, pack)), nxt in _with_next(source):
             if b == int(getattr(args, "steady_after", 10)):       # steady-state clock: starts once the first steps are behind us
                 torch.cuda.synchronize()
                 t_mark, n_mark = time.time(), 0
@@ -486,14 +503,28 @@ def train(args, use_modal, local_rank):
                     break
                 continue
             pack = _to_device(pack, local_rank)
-            ids, items, log_mask = (ids.to(local_rank, non_blocking=True), items.to(local_rank, non_blocking=True),
-                                    log_mask.to(local_rank, non_blocking=True))
-            if vision:
-                items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)
+            img_slot = None
+            if img_feed is not None and items.dtype == torch.uint8 and not items.is_cuda:
+                if img_ahead is not None and img_ahead[0] == b:
+                    img_slot = img_ahead[1]
+                else:
+                    img_slot = img_feed.submit(items.view(-1, *items.shape[-3:]), None, None)
+                img_ahead = None
+                if nxt is not None and nxt[1][1] is not None and nxt[1][1].dtype == torch.uint8:      # the next batch: queued before this step's launches
+                    img_ahead = (nxt[0], img_feed.submit(nxt[1][1].view(-1, *nxt[1][1].shape[-3:]), None, None))
+                items = img_feed.take(img_slot)
+                ids, log_mask = ids.to(local_rank, non_blocking=True), log_mask.to(local_rank, non_blocking=True)
             else:
-                items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
+                ids, items, log_mask = (ids.to(local_rank, non_blocking=True), items.to(local_rank, non_blocking=True),
+                                        log_mask.to(local_rank, non_blocking=True))
+                if vision:
+                    items = items.view(-1, *items.shape[-3:])                # [B*(S+1), R, R, 3] uint8 (V/run.py:203 views to NCHW floats)
+                else:
+                    items = items.view(-1, items.size(-1)) if use_modal else items.view(-1)
             if args.fused_step:
                 loss = stepper.global_loss(stepper.step_graphed(ids.view(-1), items, log_mask, token_packing=pack))    # pooled negatives: a rank's step returns its SHARE; one rank: hipGraph replay per input shape
+                if img_slot is not None:
+                    img_feed.release(img_slot)
             else:
                 optimizer.zero_grad()
                 loss = wrapped(ids.view(-1), items, log_mask, local_rank)

@@ -137,7 +137,10 @@ def swin_forward(p: dict, prep, shape: SwinShape, pixels: torch.Tensor, dtype, n
     sw = prefix + "swin."
     n_img = pixels.shape[0]
     eps = shape.layer_norm_eps
-    if pixels.dtype == torch.uint8:   # decoded HWC images: ToTensor + Normalize(0.5, 0.5) fused into the im2col (§8(f)-3)
+    if hasattr(pixels, "patches"):    # data_utils.images.PatchRows: the normalising im2col already ran (on the input feed's stream, under the previous step)
+        patches = pixels.patches
+        assert patches.dtype == dtype and patches.shape[0] == n_img * (shape.image_size // shape.patch_size) ** 2
+    elif pixels.dtype == torch.uint8:   # decoded HWC images: ToTensor + Normalize(0.5, 0.5) fused into the im2col (§8(f)-3)
         patches = ops.swin_patchify_u8(pixels.contiguous(), shape.patch_size, dtype)
     else:
         patches = ops.swin_patchify(pixels.contiguous(), shape.patch_size, dtype)

@@ -115,3 +115,59 @@ def test_device_resize_random_sizes_vs_oracle_and_into_the_encoder():
     a = ops.swin_patchify_u8(out, 4, torch.float32)
     b = ops.swin_patchify(host.contiguous().cuda(), 4, torch.float32)
     np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_device_image_feed_equals_the_inline_pipeline():
+    """``DeviceImageFeed`` (H2D + resize + normalising im2col of the NEXT batch on its own stream, double-buffered) hands the step bit for
+    bit the patch rows the inline path computes on the step's stream, batch after batch (buffer sets reused, sizes changing), and a
+    fused train step fed through it returns the inline step's loss."""
+    import types
+    from idvs.morec_amd import ops
+    from idvs.morec_amd.data_utils.images import DeviceImageFeed, pack_images
+    rng = np.random.default_rng(9)
+    feed = DeviceImageFeed("cuda", 56, 4, torch.float16)
+    batches = [[rng.integers(0, 256, (int(rng.integers(40, 120)), int(rng.integers(40, 120)), 3), dtype=np.uint8) for _ in range(n)]
+               for n in (5, 9, 5, 3, 9)]
+    packed = [tuple(torch.from_numpy(x).pin_memory() for x in pack_images(b, 56)) for b in batches]
+    slot = feed.submit(*packed[0])
+    for k in range(len(batches)):
+        nxt = feed.submit(*packed[k + 1]) if k + 1 < len(batches) else None      # queued before batch k is consumed, as in the training loop
+        rows = feed.take(slot)
+        ref = ops.swin_patchify_u8(ops.image_resize_u8_packed(*packed[k], 56, "cuda"), 4, torch.float16)
+        assert rows.n_img == len(batches[k]) and torch.equal(rows.patches, ref)
+        feed.release(slot)
+        slot = nxt
+    # images that are already R x R (run.py's catalogue arrays): upload + im2col only
+    arr = torch.from_numpy(rng.integers(0, 256, (7, 56, 56, 3), dtype=np.uint8)).pin_memory()
+    s2 = feed.submit(arr, None, None)
+    rows = feed.take(s2)
+    assert torch.equal(rows.patches, ops.swin_patchify_u8(arr.cuda(), 4, torch.float16))
+    feed.release(s2)
+    # through a fused step
+    from idvs.morec_amd.model import Model
+    from idvs.morec_amd.model.swin import HipSwinForImageClassification
+    from idvs.morec_amd.swin_engine import SwinShape
+    from idvs.morec_amd.train_step import TrainStep
+    S, D, item_num, B = 4, 64, 30, 3
+    vshape = SwinShape.named("swin_micro")
+    args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.0, transformer_block=2,
+                                 CV_model_load="swin_micro", compute_dtype="fp16")
+    pop = np.full(item_num + 1, 1.0 / item_num)
+    pop[0] = 1.0
+    ids = torch.from_numpy(rng.integers(1, item_num + 1, (B, S + 1))).cuda()
+    imgs = torch.from_numpy(rng.integers(0, 256, (B * (S + 1), vshape.image_size, vshape.image_size, 3), dtype=np.uint8)).pin_memory()
+    losses = []
+    for fed in (False, True):
+        torch.manual_seed(3)
+        m = Model(args, item_num, True, HipSwinForImageClassification(vshape, D), pop).cuda().eval()
+        ts = TrainStep(m, lr=1e-3, fine_tune_lr=1e-3, l2_weight=0.0, fine_tune_l2_weight=0.0, pool_negatives=False, loss_scale=256.0)
+        if fed:
+            f2 = DeviceImageFeed("cuda", vshape.image_size, vshape.patch_size, torch.float16)
+            sl = f2.submit(imgs, None, None)
+            loss = ts.step(ids.view(-1), f2.take(sl), torch.ones(B, S, device="cuda"))
+            f2.release(sl)
+        else:
+            loss = ts.step(ids.view(-1), imgs.cuda(), torch.ones(B, S, device="cuda"))
+        losses.append(float(loss))
+    assert losses[0] == losses[1], losses
