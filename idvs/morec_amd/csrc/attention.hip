@@ -406,7 +406,7 @@ static void warn_valu_fallback(const morec_attn_desc* d) {
     static const bool once = [](const morec_attn_desc* q) {
         const char* e = getenv("MOREC_QUIET");
         if (!(e && e[0] == '1'))
-            fprintf(stderr, "libmorec_hip: attention with T = %d, head width %d is outside the MFMA path (T <= 32, head width %% 32 == 0): "
+            fprintf(stderr, "libmorec_hip: attention with T = %d, head width %d is outside the MFMA path (T <= 64, head width %% 32 == 0): "
                             "running the VALU kernels for this and every later such call\n", q->T, q->dh);
         return true;
     }(d);

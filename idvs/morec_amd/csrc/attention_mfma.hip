@@ -13,6 +13,7 @@
 //     element (c & 3) of the 8-byte words addressed by lanes 4j + (c >> 2), j = 0..3).  The k-slot <-> key
 //     permutation this induces is the same one the packed P / dS register fragments use, so nothing is shuffled.
 // LDS rows carry a 32-byte pad (pitch / 32 odd) which makes both the b128 and the transpose reads conflict-free.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -516,9 +517,15 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnMArgs a) {
 }  // namespace
 
 int attn_spare_blocks(const morec_attn_desc* d);      // attention.hip
+int morec_attn_mfma64_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx, void* dqkv, bool backward,
+                             hipStream_t s, float* csum);      // attention_mfma64.hip: 32 < T <= 64
 // returns MOREC_E_UNSUPPORTED when the shape is outside this fast path (caller falls back to attention.hip)
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
                            void* dqkv, bool backward, hipStream_t s, float* csum) {
+    if (is_h16(d->dtype) && d->dh % 32 == 0 && d->T > 32 && d->T <= 64) {
+        static const bool off = [] { const char* e = getenv("MOREC_ATTN_MFMA64"); return e && e[0] == '0'; }();      // MOREC_ATTN_MFMA64=0: the VALU kernels (A/B)
+        if (!off) return morec_attn_mfma64_launch(d, qkv, key_keep, ctx_or_dctx, dqkv, backward, s, csum);
+    }
     if (!is_h16(d->dtype) || d->dh % 32 != 0 || d->T > 32) return MOREC_E_UNSUPPORTED;
     AttnMArgs a{reinterpret_cast<const bf16*>(qkv), key_keep, reinterpret_cast<bf16*>(ctx_or_dctx),
                 reinterpret_cast<bf16*>(dqkv), csum, d->n_seq, d->T, d->n_heads, d->dh, d->causal, d->scale, d->mask_value,

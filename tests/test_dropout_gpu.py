@@ -60,9 +60,13 @@ def test_layernorm_dropout(dt):
     assert rel(dzd, zs.grad * m_in) < tol
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_attention_dropout(dt):
-    n_seq, T, nh, dh, p, seed = 4, 30, 3, 64, 0.2, 777
+@pytest.mark.parametrize("T", [30, 50])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_attention_dropout(dt, T):
+    """T = 50: the 64 x 64 tile (abstracts / bodies, T/parameters.py:43-44) -- exact VALU kernels in fp32, attention_mfma64.hip in the 16-bit
+    modes -- whose mask stream is indexed with a row pitch of 64."""
+    n_seq, nh, dh, p, seed = 4, 3, 64, 0.2, 777
+    TP = 32 if T <= 32 else 64
     H = nh * dh
     g = torch.Generator().manual_seed(1)
     qkv = (0.7 * torch.randn(n_seq * T, 3 * H, generator=g)).to(DEV).to(dt)
@@ -71,7 +75,8 @@ def test_attention_dropout(dt):
     scale = 1 / math.sqrt(dh)
     desc = ops.attn_desc(n_seq, T, nh, dh, False, scale, ops.FLT_MIN_MASK, dt, p, seed)
     ctx = ops.attn_fwd(desc, qkv, keep)
-    mask = ops.dropout_keep_mask(n_seq * nh * 32 * 32, p, seed).view(n_seq, nh, 32, 32)[:, :, :T, :T].double() / (1 - p)
+    thr = int(p * 65536)
+    mask = ops.dropout_keep_mask(n_seq * nh * TP * TP, p, seed).view(n_seq, nh, TP, TP)[:, :, :T, :T].double() / (1 - thr / 65536.0)
     qd = qkv.double().requires_grad_(True)
     q, k, v = (qd[:, i * H:(i + 1) * H].reshape(n_seq, T, nh, dh).transpose(1, 2) for i in range(3))
     att = q @ k.transpose(-1, -2) * scale + torch.where(keep[:, None, None, :] != 0, 0.0, -1e30)

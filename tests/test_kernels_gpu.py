@@ -313,9 +313,10 @@ def attn_ref(qkv, keep, n_heads, causal, scale, mask_value):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("cfg", [(5, 30, 12, 64, False, ops.FLT_MIN_MASK), (4, 20, 2, 256, True, -1e9),
                                  (3, 7, 2, 32, True, -1e9), (6, 32, 2, 64, False, -10000.0), (2, 10, 2, 1024, True, -1e9),
-                                 # T > 32 (abstracts / bodies of 50 tokens, T/parameters.py:43-44; longer behaviour sequences): outside the MFMA
-                                 # attention's tile -- the 16-bit call falls back to the exact VALU kernels (one stderr line says so)
-                                 (3, 50, 12, 64, False, ops.FLT_MIN_MASK), (2, 48, 2, 256, True, -1e9)])
+                                 # 32 < T <= 64 (abstracts / bodies of 50 tokens, T/parameters.py:43-44; longer behaviour sequences): the 64 x 64
+                                 # tile -- exact VALU kernels in fp32, attention_mfma64.hip (two k-steps over keys / queries) in the 16-bit modes
+                                 (3, 50, 12, 64, False, ops.FLT_MIN_MASK), (2, 48, 2, 256, True, -1e9), (4, 64, 4, 64, True, -1e9),
+                                 (5, 33, 2, 32, False, ops.FLT_MIN_MASK), (3, 40, 2, 128, True, -1e9), (130, 50, 12, 64, False, ops.FLT_MIN_MASK)])
 def test_attention(dt, cfg):
     n_seq, T, nh, dh, causal, mv = cfg
     H = nh * dh
