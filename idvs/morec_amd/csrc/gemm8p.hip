@@ -66,10 +66,14 @@ struct TileXY {
     int krem;      // elements of K inside the unit's last K-tile (64 unless the unit ends at a K that is not a multiple of 64)
 };
 
-template <typename TI, typename TO, int ACT, bool CS>
+// TMR: rows of a tile -- 256, or 224 / 192 (wave row 1 owns three / two 32-row blocks instead of four): "tile height", below, at launch8p.
+template <typename TI, typename TO, int ACT, bool CS, int TMR = 256>
 __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const bf16* __restrict__ Acur, const bf16* __restrict__ Bcur,
                                           const bf16* __restrict__ Anext, const bf16* __restrict__ Bnext, const TileXY cur, const TileXY nxt,
                                           const bool first) {
+    constexpr bool PART = TMR != TM;
+    constexpr int tmr = TMR;                                  // rows of a tile
+    constexpr int nb1 = (TMR - 128) / 32;                     // 32-row blocks of wave row 1 (wave row 0 always owns four)
     constexpr int ES = (int)sizeof(TO);
     constexpr int EPV = 16 / ES;                 // elements per 16-byte vector
     constexpr int PC = 128 / ES;                 // columns per pass: 64 (bf16) / 32 (f32)
@@ -88,12 +92,20 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
             bias_l = bp[min(n0 + ((tid_m >> 6) & 3) * 64 + (tid_m & 63), p.N - 1)];
         }
         Ctx c;
-        make_ctx(c, tid_m, Acur, Bcur, p.M - m0, p.N - n0, p.lda, p.ldb, cur.krem);
+        make_ctx(c, tid_m, Acur, Bcur, min(p.M - m0, tmr), p.N - n0, p.lda, p.ldb, cur.krem);
         if (first) issue_prologue(c, smem, cur.nkt);      // later tiles: issued by the previous tile's body, ahead of its epilogue
         // global stores of the previous tile's epilogue (issued behind this tile's prologue): 4 per pass and output
         constexpr int NST = 16 * (int)sizeof(TO) / 2;
         const int younger = (first || (p.debug & 3) || (p.debug & 64)) ? 0 : (p.aux_out ? 2 * NST : NST);
-        mainloop8p<TI>(c, __builtin_amdgcn_readfirstlane(tid_m >> 8), cur.nkt, younger, smem, acc, p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr);
+        const int wr_m = __builtin_amdgcn_readfirstlane(tid_m >> 8);
+        unsigned long long* st_m = p.stamps ? p.stamps + (size_t)cur.wg * 16 : nullptr;
+        if constexpr (!PART) {
+            mainloop8p<TI>(c, wr_m, cur.nkt, younger, smem, acc, st_m);
+        } else {      // ONE branch, outside the loop: wave row 0 runs the full wave tile, wave row 1 the instantiation without its absent blocks
+            (void)younger;
+            if (wr_m == 0) mainloop8p_s<TI, 0, 0, 4>(c, 0, cur.nkt, smem, acc, st_m);
+            else mainloop8p_s<TI, 0, 0, nb1>(c, 1, cur.nkt, smem, acc, st_m);
+        }
     }
     G8_STAMPW(1, cur.wg);
     if (cur.tail >= 0) {
@@ -172,12 +184,14 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         const int slot = ES == 2 ? q : 2 * q + h;
         return reinterpret_cast<TO*>(ws + r5 * 128 + ((slot ^ (r5 & 7)) << 4) + (ES == 2 ? 8 * h : 0));
     };
-    const int cur_tm = m0 / TM;
+    const int cur_tm = m0 / tmr;
     const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+    const int m_end = min(p.M, m0 + tmr);                     // first row past this tile
+    const int nblk = (PART && wr) ? nb1 : 4;                  // this wave's 32-row blocks
     // Row side of the global traffic through buffer descriptors based at the tile's first row: ONE per-lane offset register
     // for every access of the tile (+ a wave-uniform term), and the hardware range check drops rows >= M (the extent is
     // the tile's valid rows); lanes whose 16-byte column lies past N carry an out-of-range offset instead of a branch.
-    const long tile_bytes = (long)min(256, p.M - m0) * p.ldc * ES;
+    const long tile_bytes = (long)min(tmr, p.M - m0) * p.ldc * ES;
     const int ext = (int)min(tile_bytes, 0x7fffffffL);
     const size_t tile_off = (size_t)m0 * p.ldc;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(C + tile_off), 0, ext, 0x00020000);
@@ -259,7 +273,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
         int tid_n = threadIdx.x;
         asm volatile("" : "+v"(tid_n));
         Ctx cn;
-        make_ctx(cn, tid_n, Anext, Bnext, p.M - nxt.m0, p.N - nxt.n0, p.lda, p.ldb, nxt.krem);
+        make_ctx(cn, tid_n, Anext, Bnext, min(p.M - nxt.m0, tmr), p.N - nxt.n0, p.lda, p.ldb, nxt.krem);
         issue_prologue(cn, smem, nxt.nkt);
     }
     if (p.debug & 2) {      // ablation: no epilogue (the store keeps the accumulators alive)
@@ -270,7 +284,10 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
     [[maybe_unused]] float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int Mi = 0; Mi < 4; ++Mi) {
-        [[maybe_unused]] const bool row_ok = (mw + Mi * 32 + r5) < p.M;
+        if constexpr (PART) {
+            if (Mi >= nblk) break;      // (wave-uniform) blocks past the tile's rows: never computed
+        }
+        [[maybe_unused]] const bool row_ok = (mw + Mi * 32 + r5) < m_end;
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             pin();      // nothing of this pass may be computed ahead of the previous one (128 fresh values on top of the accumulators)
@@ -446,7 +463,7 @@ __device__ __forceinline__ void tile_body(const GemmArgs& p, char* smem, const b
     }
 }
 
-template <typename TI, typename TO, int ACT, bool CS>
+template <typename TI, typename TO, int ACT, bool CS, int TMR = 256>
 __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_m * p.tiles_n;
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
             tm = r / w;
             tn = g * p.ngroup + r % w;
         }
-        t.m0 = tm * TM;
+        t.m0 = tm * TMR;
         t.n0 = tn * TN;
         return t;
     };
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(THREADS) void gemm8p_kernel(GemmArgs p) {
     for (int i = 0; i < n_units; ++i) {
         const bool more = i + 1 < n_units;
         const TileXY nxt = more ? unit_at(i + 1) : cur;
-        tile_body<TI, TO, ACT, CS>(p, smem, A + (size_t)cur.m0 * p.lda + cur.k0 * KE, B + (size_t)cur.n0 * p.ldb + cur.k0 * KE,
+        tile_body<TI, TO, ACT, CS, TMR>(p, smem, A + (size_t)cur.m0 * p.lda + cur.k0 * KE, B + (size_t)cur.n0 * p.ldb + cur.k0 * KE,
                                A + (size_t)nxt.m0 * p.lda + nxt.k0 * KE, B + (size_t)nxt.n0 * p.ldb + nxt.k0 * KE, cur, nxt, i == 0);
         cur = nxt;
     }
@@ -539,16 +556,57 @@ static void tail_workspace(hipStream_t s, int n_cu, GemmArgs& a) {
 }
 
 int g_reserve_cus = 0;      // tuning key "gemm8p_reserve_cus"
+int gemm8p_cu_count() {     // CUs the persistent grid uses right now (device count rounded to the 8 XCDs, minus the reserved ones)
+    static const int n_dev = [] {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n &= ~7;
+        return n < 8 ? 8 : n;
+    }();
+    const int n = n_dev - (g_reserve_cus & ~7);
+    return n < 8 ? 8 : n;
+}
 // tuning key "gemm8p_ngroup": 0 = row-major tile order, -1 = automatic column groups (default: FETCH_SIZE per launch -20 % on the QKV
 // projection, -24 % on FFN-up + GELU, -23 % on its backward at equal launch times; profiles/r03_gemm8p_tile_order_pmc.txt), n = groups of n N-tiles
 int g_ngroup = -1;
 
-template <typename TI, typename TO, int ACT, bool CS>
+// ---- tile height.  A launch is ceil(tiles / CUs) ROUNDS of tiles; with 256-row tiles the encoder's N = 768 products at ~55 k token rows
+// are 645 tiles = 2.52 rounds, i.e. THREE rounds of tile time for 2.52 rounds of work (16 % of the launch is idle CUs), N = 3072 is 10.08
+// rounds -> eleven.  The number of rounds is an integer either way, but the tile's height need not be 256: with 224-row tiles (wave row 1
+// owns three 32-row blocks instead of four; its fourth block's MFMAs are branched around, everything else -- barriers, DMA, LDS image --
+// is the 256-row schedule) the same N = 768 product is 738 tiles = 2.88 rounds of 7/8-size tiles: three rounds x 0.875.  pick_tmr takes
+// the height in {256, 224, 192} with the smallest rounds x (K-tiles x height / 256 + fixed per-tile cost in K-tile units), 256 on ties.
+// The result is the same numbers bit for bit (a tile boundary does not enter any sum).  MOREC_GEMM8P_TMR=0 / tuning key "gemm8p_tmr" 0: off.
+int g_tmr_mode = -1;      // -1: read MOREC_GEMM8P_TMR on first use; 0: always 256; 1: automatic; 224 / 192: forced where an instantiation exists
+static int pick_tmr(int M, int tiles_n, int nk, int n_cu) {
+    if (g_tmr_mode < 0) {
+        const char* e = getenv("MOREC_GEMM8P_TMR");
+        g_tmr_mode = e ? atoi(e) : 1;
+    }
+    if (g_tmr_mode == 0) return TM;
+    if (g_tmr_mode == 224 || g_tmr_mode == 192) return g_tmr_mode;
+    const double fixed = 4.0;      // prologue + first barrier + epilogue of a tile, in K-tile times (profiles/r03_gemm8p_stamps.txt: ~8.4 k of 2.25 k cycles)
+    int best = TM;
+    double best_cost = 0.0;
+    for (int t : {256, 224, 192}) {
+        const long tiles = (long)((M + t - 1) / t) * tiles_n;
+        if (tiles <= n_cu && t != TM) continue;                                        // a single round: nothing to balance
+        const double cost = (double)((tiles + n_cu - 1) / n_cu) * ((double)nk * t / 256.0 + fixed);
+        if (t == TM || cost < best_cost * 0.985) { if (t == TM || cost < best_cost) { best = t; best_cost = cost; } }
+    }
+    return best;
+}
+
+template <typename TI, typename TO, int ACT, bool CS, int TMR = 256>
 int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
-    a.tiles_m = (d->M + TM - 1) / TM;
+    constexpr bool PART = TMR != TM;
+    const int tmr = TMR;
+    a.tmr = TMR;
+    a.tiles_m = (d->M + tmr - 1) / tmr;
     a.tiles_n = (d->N + TN - 1) / TN;
     static const int n_cu_dev = [] {      // thread-safe one-time set-up (function-local static)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TI, TO, ACT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TI, TO, ACT, CS, TMR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_TOTAL);
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -572,8 +630,8 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
     // error against an exact product) but rounds 0.02 % of the outputs the other way, and a 12-layer bf16 encoder at random init
     // turns that into +-1e-2 on the step-0 loss (tests/test_bench_mode_parity_gpu.py); the default keeps the summation order of
     // the two-buffer kernels (bit-identical outputs) for 0.35 % of the step time.
-    if (a.tail_split && nwg > n_cu && nwg % n_cu && 2 * (nwg % n_cu) <= n_cu && d->K >= 24 * KE && !(a.debug & 128)) tail_workspace(s, n_cu, a);
-    hipLaunchKernelGGL((gemm8p_kernel<TI, TO, ACT, CS>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
+    if (!PART && a.tail_split && nwg > n_cu && nwg % n_cu && 2 * (nwg % n_cu) <= n_cu && d->K >= 24 * KE && !(a.debug & 128)) tail_workspace(s, n_cu, a);
+    hipLaunchKernelGGL((gemm8p_kernel<TI, TO, ACT, CS, TMR>), dim3(nwg < n_cu ? nwg : n_cu), dim3(THREADS), LDS_TOTAL, s, a);
     MOREC_CHECK_LAUNCH();
     if constexpr (CS) return colsum_f32_launch(a.colsum, a.colsum_dst, a.tiles_m * 2, d->N, s);
     return MOREC_OK;
@@ -592,6 +650,7 @@ extern "C" int morec_tuning_set(const char* key, int value) {
     if (!strcmp(key, "ce8p")) { g_ce8p_mode = value; return MOREC_OK; }
     if (!strcmp(key, "gemm_skinny")) { g_skinny_mode = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_ngroup")) { g_ngroup = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm8p_tmr")) { g_tmr_mode = (value == 0 || value == 1 || value == 224 || value == 192) ? value : 1; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_reserve_cus")) { g_reserve_cus = value < 0 ? 0 : value > 128 ? 128 : value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_bias")) { g_tail_bias = value < 0 ? 0 : value > 16 ? 16 : value; return MOREC_OK; }
     // device buffer (16 x 8 bytes per workgroup) that receives s_memtime stamps of wave 0: address in two halves
@@ -615,6 +674,22 @@ int gemm8p_mode() {
 
 template <typename TI>
 static int dispatch8p(const morec_gemm_desc* d, GemmArgs& a, int mode, hipStream_t s) {
+    // tile height (see pick_tmr): the PART instantiations exist for the three kernels of the encoder step -- plain, FFN-up + GELU (+ act'),
+    // x act' + column sums -- with 16-bit outputs
+    a.tmr = TM;
+    if (d->out_dtype == h16<TI>::dtype && ((mode == 0 && !a.colsum) || (mode == 1 && !a.colsum) || (mode == 5 && a.colsum))) {
+        const int t = pick_tmr(d->M, (d->N + TN - 1) / TN, (d->K + KE - 1) / KE, gemm8p_cu_count());
+        if (t == 224) {
+            if (mode == 0) return launch8p<TI, TI, 0, false, 224>(d, a, s);
+            if (mode == 1) return launch8p<TI, TI, 1, false, 224>(d, a, s);
+            return launch8p<TI, TI, 5, true, 224>(d, a, s);
+        }
+        if (t == 192) {
+            if (mode == 0) return launch8p<TI, TI, 0, false, 192>(d, a, s);
+            if (mode == 1) return launch8p<TI, TI, 1, false, 192>(d, a, s);
+            return launch8p<TI, TI, 5, true, 192>(d, a, s);
+        }
+    }
     if (d->out_dtype == MOREC_F32) {
         if (mode != 0 || a.colsum) return G8_NOT_TAKEN;
         return launch8p<TI, float, 0, false>(d, a, s);

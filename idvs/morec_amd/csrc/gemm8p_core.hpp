@@ -59,13 +59,19 @@ __device__ __forceinline__ uint4 lds16(const char* p) { return *reinterpret_cast
 
 // ZERO: the first K-tile of an output tile starts its accumulators from the MFMA's inline-constant 0 operand instead of 128
 // v_mov per lane ahead of the loop.
-template <typename T16, int M0, int NQ, bool ZERO>
+// NBW = 32-row blocks this WAVE owns (4: the full 128-row wave tile; 3 / 2: wave row 1 of a 224- / 192-row tile, gemm8p.hip "tile
+// height").  Compile time: a run-time branch around MFMAs makes the accumulators loop-carried through phi nodes and hipcc spills ~150 of
+// them (measured: 576-704 bytes of scratch per lane, launches 7x slower); the caller branches ONCE, outside the main loop, between two
+// instantiations.  Barriers, DMA and the fragment reads are those of the full tile; the accumulators of absent blocks are never read.
+template <typename T16, int M0, int NQ, bool ZERO, int NBW = 4>
 __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4 (&fa)[2][4], const uint4 (&fb)[4]) {
+    if constexpr (M0 >= NBW) return;
+    constexpr int NMI = (M0 + 1 < NBW) ? 2 : 1;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {  // operand-swapped: the lane ends up owning ONE m and runs of 4 consecutive n
+        for (int mi = 0; mi < NMI; ++mi) {  // operand-swapped: the lane ends up owning ONE m and runs of 4 consecutive n
             f32x16_t cin = acc[M0 + mi][NQ];
             if constexpr (ZERO) {
                 if (ks == 0) {
@@ -91,7 +97,7 @@ __device__ __forceinline__ void vm_wait_tail() {
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
 // last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
 // BAUX: cache policy of the B-panel loads (see dma2)
-template <typename T16, int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0>
+template <typename T16, int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0, int NBW = 4>
 __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
     const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
     const uint32_t m2 = last2 ? 0xffffffffu : 0u;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
-    mfma_quadrant<T16, 0, 0, ZERO>(acc, fa, fb0);
+    mfma_quadrant<T16, 0, 0, ZERO, NBW>(acc, fa, fb0);
     bar();
     // ---- phase 1: B-second fragments; refill A-second of t+1
 #pragma unroll
@@ -125,7 +131,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
-    mfma_quadrant<T16, 0, 1, ZERO>(acc, fa, fb1);
+    mfma_quadrant<T16, 0, 1, ZERO, NBW>(acc, fa, fb1);
     bar();
     // ---- phase 2: A-second fragments; refill A-first of t+2 (this buffer)
 #pragma unroll
@@ -136,14 +142,14 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
-    mfma_quadrant<T16, 2, 1, ZERO>(acc, fa, fb1);
+    mfma_quadrant<T16, 2, 1, ZERO, NBW>(acc, fa, fb1);
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
-    mfma_quadrant<T16, 2, 0, ZERO>(acc, fa, fb0);
+    mfma_quadrant<T16, 2, 0, ZERO, NBW>(acc, fa, fb0);
     bar();
 }
 
@@ -202,7 +208,7 @@ __device__ __forceinline__ void issue_prologue(const Ctx& c, char* smem, int nk)
     do {                                                                                \
         if (st && threadIdx.x == 0) st[(i)] = __builtin_readcyclecounter();              \
     } while (0)
-template <typename T16, int SLACK, int BAUX = 0>
+template <typename T16, int SLACK, int BAUX = 0, int NBW = 4>
 __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char* smem, f32x16_t (&acc)[4][2], unsigned long long* st) {
     G8_MSTAMP(8);
     vm_wait<8 + SLACK>();    // A-first, B-first of K-tile 0 (this wave's pieces)
@@ -213,7 +219,7 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     int cb = 0;
     int t = 0;
     if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<T16, 2, SLACK, true, BAUX>(smem, c, cb, 0, acc, nk == 3);
+        ktile<T16, 2, SLACK, true, BAUX, NBW>(smem, c, cb, 0, acc, nk == 3);
         cb ^= BUF_BYTES;
         t = 1;
     } else {
@@ -226,13 +232,13 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
-        ktile<T16, 2, 0, false, BAUX>(smem, c, cb, t * KB, acc, t + 3 == nk);
+        ktile<T16, 2, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc, t + 3 == nk);
         cb ^= BUF_BYTES;
         if (t == 1) G8_MSTAMP(12);
     }
     G8_MSTAMP(13);
-    ktile<T16, 1, 0, false, BAUX>(smem, c, cb, t * KB, acc);
-    ktile<T16, 0, 0, false, BAUX>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
+    ktile<T16, 1, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc);
+    ktile<T16, 0, 0, false, BAUX, NBW>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
     G8_MSTAMP(14);
     if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
     G8_MSTAMP(15);

@@ -27,6 +27,7 @@ struct GemmArgs {
     int tail_bias;   // gemm8p tail split: the consumer takes (nk + tail_bias) / 2 of the nk K-tiles
     int* tail_cnt;   // gemm8p tail split: one arrival counter per tail tile (zero between launches)
     int ngroup;      // gemm8p: N-tiles per column group of the tile order (0 / >= tiles_n: plain row-major order)
+    int tmr;         // gemm8p: rows of an output tile (256, or 224 / 192: the PART instantiations -- see gemm8p.hip "tile height")
 };
 
 // gemm8p.hip: runs the launch on the eight-phase kernel when the problem is eligible (returns MOREC_OK / an error) or

@@ -195,3 +195,45 @@ def test_gemm8p_tail_split_absolute():
     finally:
         L.morec_tuning_set(b"gemm8p_tail_split", 0)
     _check(o, exact, 2.0 ** -8, 1e-4 * sigma, "tail split")
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(M_TEXT, 768, 768, "plain"), (M_TEXT, 2304, 768, "bias"), (M_TEXT2, 768, 3072, "plain"),
+                                        (M_TEXT, 3072, 768, "gelu_deriv"), (M_TEXT, 3072, 768, "dactmul_cs"), (1000, 768, 768, "plain"),
+                                        (M_TEXT2 + 193, 768, 2304, "plain")])
+def test_gemm8p_tile_height_is_bit_identical(M, N, K, kind):
+    """Tile height (gemm8p.hip, pick_tmr): 224- / 192-row tiles (wave row 1 owns three / two 32-row blocks) change the number of rounds a
+    launch takes, never a number -- outputs, second outputs and fused column sums equal the 256-row launch bit for bit; the automatic
+    choice is one of the three."""
+    L = _lib.lib()
+    a, b, g = _operands(M, N, K, M + N + K)
+    bias = torch.randn(N, device=DEV, generator=g) if kind in ("bias", "gelu_deriv") else None
+    din = torch.randn(M, N, device=DEV, generator=g).to(BF) if kind == "dactmul_cs" else None
+
+    def run():
+        out = torch.full((M, N), 7.0, device=DEV, dtype=BF)
+        aux = torch.full((M, N), 7.0, device=DEV, dtype=BF) if kind == "gelu_deriv" else None
+        cs = torch.full((N,), 0.25, device=DEV) if kind == "dactmul_cs" else None
+        kw = {}
+        if kind == "gelu_deriv":
+            kw = dict(act=ACT_GELU, aux_out=aux, aux_deriv=True)
+        if kind == "dactmul_cs":
+            kw = dict(dact=DACT_MUL, dact_in=din, colsum_out=cs)
+        ops.gemm_nt(a, b, out=out, bias=bias, **kw)
+        return out, aux, cs
+
+    res = {}
+    try:
+        for mode in (0, 224, 192, 1):
+            assert L.morec_tuning_set(b"gemm8p_tmr", mode) == 0
+            res[mode] = run()
+    finally:
+        L.morec_tuning_set(b"gemm8p_tmr", 1)
+    for mode in (224, 192, 1):
+        assert torch.equal(res[mode][0], res[0][0]), f"tile height {mode}: output differs from the 256-row launch"
+        if res[0][1] is not None:
+            assert torch.equal(res[mode][1], res[0][1]), f"tile height {mode}: second output differs"
+        if res[0][2] is not None:      # column sums: the partial rows are cut at other row boundaries, the fold order follows -- rounding only
+            assert float((res[mode][2] - res[0][2]).abs().max()) <= 2e-5 * math.sqrt(M) * SCALE * SCALE * math.sqrt(K) * 4
+    acc = a.double() @ b.double().t() + (bias.double() if bias is not None else 0.0)
+    if kind in ("plain", "bias"):
+        _check(res[224][0], acc, 2.0 ** -8, 1e-4 * SCALE * SCALE * math.sqrt(K), f"tile height 224 {M}x{N}x{K}")
