@@ -217,12 +217,16 @@ def test_freeze_boundary_inside_qkv_group_is_refused():
         TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
 
 
-def test_several_news_attributes_are_refused_by_the_fused_step():
+def test_fused_step_checks_the_width_of_the_token_rows():
+    """Round 5: the fused step takes several text attributes (one encoder pass each, mean of the passes: tests/test_model_gpu.py g19);
+    what it refuses is a token row whose width is not the sum of the configured attributes' [ids | mask] blocks."""
     from idvs.morec_amd.train_step import TrainStep
-    model, *_ = _setup("fp32")
-    model.args.news_attributes = ["title", "abstract"]
-    with pytest.raises(ValueError, match="news_attributes"):
-        TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+    tdev = lambda a: torch.from_numpy(a).to(DEV)
+    model, ids, items, lm, pop, _ = _setup("fp32")
+    ts = TrainStep(model, lr=1e-4, fine_tune_lr=5e-5, l2_weight=0.0, fine_tune_l2_weight=0.0)
+    assert [n for n, _, _ in ts.text_attrs] == ["title"]
+    with pytest.raises(ValueError, match="token rows of width"):
+        ts.forward_backward(tdev(ids).view(-1), tdev(items)[:, :-2].contiguous(), tdev(lm))
 
 
 def test_sync_shadow_after_in_place_parameter_writes():
