@@ -379,23 +379,29 @@ __global__ __launch_bounds__(256) void scatter_add_rows_det_kernel(const T* __re
     }
     if (dup) return;
     float* dst = dtable + (size_t)id * D;
-    for (int c = lane * 4; c < D; c += 256) {
+    for (int c0 = 0; c0 < D; c0 += 256) {           // wave-uniform trip count: every lane takes part in the ballots below
+        const int c = c0 + lane * 4;
+        const bool mine = c < D;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int r0 = row; r0 < R; r0 += 64) {      // 64 candidate rows at a time: the lanes test, the wave walks the hits in order
+        for (int r0 = row; r0 < R; r0 += 64) {      // 64 candidate rows at a time: ALL lanes test, the wave walks the hits in order
             const int r = r0 + lane;
             unsigned long long hit = __ballot(r < R && idx[r] == id);
             while (hit) {
                 const int b = __builtin_ctzll(hit);
                 hit &= hit - 1;
-                float v[4];
-                io<T>::load4(d + (size_t)(r0 + b) * D + c, v);
+                if (mine) {
+                    float v[4];
+                    io<T>::load4(d + (size_t)(r0 + b) * D + c, v);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += v[k];
+                    for (int k = 0; k < 4; ++k) acc[k] += v[k];
+                }
             }
         }
-        float4 o = *reinterpret_cast<const float4*>(dst + c);
-        o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
-        *reinterpret_cast<float4*>(dst + c) = o;
+        if (mine) {
+            float4 o = *reinterpret_cast<const float4*>(dst + c);
+            o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+            *reinterpret_cast<float4*>(dst + c) = o;
+        }
     }
 }
 

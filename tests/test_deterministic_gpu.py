@@ -85,3 +85,55 @@ def test_two_runs_are_bit_identical(tower, dtype):
     dp = max(float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) for x, y in zip(a[1][::3], c[1][::3]))
     print(f"{tower} {dtype}: deterministic x 2 bit-identical over {steps} steps; vs default kernels: max |d loss| {dl:.2e}, parameter distance {dp:.2e}")
     assert dl < (2e-3 if dtype == "fp32" else 3e-2) and dp < (2e-3 if dtype == "fp32" else 3e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_deterministic_kernels_against_fp64(dt):
+    """The single-writer / fold-in-order variants themselves against fp64 references, at row widths that leave lanes idle (D = 64: a
+    quarter of the wave holds columns) and with heavy index collisions; each call twice: same bits."""
+    from idvs.morec_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    ops.set_deterministic(True)
+    try:
+        for D, R, V in ((64, 500, 40), (128, 2688, 300), (512, 2688, 3000), (520, 77, 9)):
+            idx = torch.randint(0, V, (R,), generator=g).to(torch.int32)
+            idx[::7] = 5                              # a hot id
+            idx[::11] = 0                             # padding id: skipped
+            d = (torch.randn(R, D, generator=g)).to(dt).to(DEV)
+            ref = torch.zeros(V, D, dtype=torch.float64, device=DEV)
+            ref.index_add_(0, idx.long().to(DEV), d.double())
+            ref[0] = 0
+            outs = []
+            for _ in range(2):
+                tab = torch.zeros(V, D, device=DEV)
+                ops.scatter_add_rows_(d, idx.to(DEV), tab, 0)
+                outs.append(tab)
+            assert torch.equal(outs[0], outs[1])
+            assert float((outs[0].double() - ref).abs().max()) < 1e-4 * float(ref.abs().max()), (D, R)
+        # embedding backward: word rows (runs of equal ids in sorted order), position rows, the type row
+        n_seq, T, H, V = 300, 30, 768, 200
+        ids = torch.randint(0, V, (n_seq * T,), generator=g).to(torch.int32)
+        ids[::5] = 101
+        dz = torch.randn(n_seq * T, H, generator=g).to(dt).to(DEV)
+        order = torch.argsort(ids, stable=True).to(torch.int32).to(DEV)
+        ref = torch.zeros(V, H, dtype=torch.float64, device=DEV)
+        ref.index_add_(0, ids.long().to(DEV), dz.double())
+        ref[0] = 0
+        outs = []
+        for _ in range(2):
+            dw, dp, dty = torch.zeros(V, H, device=DEV), torch.zeros(T + 2, H, device=DEV), torch.zeros(H, device=DEV)
+            ops.bert_embed_bwd_(ids.to(DEV), dz, dw, dp, dty, 0, T, order)
+            outs.append((dw, dp, dty))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+        assert float((outs[0][0].double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+        assert float((outs[0][1][:T].double() - dz.double().view(n_seq, T, H).sum(0)).abs().max()) < 1e-3
+        assert float((outs[0][2].double() - dz.double().sum(0)).abs().max()) < 2e-3
+        # column sums over many row blocks
+        x = torch.randn(70000, 520, generator=g).to(dt).to(DEV)
+        cs = [torch.full((520,), 0.5, device=DEV) for _ in range(2)]
+        for c in cs:
+            ops.colsum_(x, c)
+        assert torch.equal(cs[0], cs[1])
+        assert float((cs[0].double() - 0.5 - x.double().sum(0)).abs().max()) < 2e-2
+    finally:
+        ops.set_deterministic(False)
