@@ -84,7 +84,9 @@ def test_two_runs_are_bit_identical(tower, dtype):
     dl = max(abs(u - v) for u, v in zip(a[0], c[0]))
     dp = max(float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) for x, y in zip(a[1][::3], c[1][::3]))
     print(f"{tower} {dtype}: deterministic x 2 bit-identical over {steps} steps; vs default kernels: max |d loss| {dl:.2e}, parameter distance {dp:.2e}")
-    assert dl < (2e-3 if dtype == "fp32" else 3e-2) and dp < (2e-3 if dtype == "fp32" else 3e-2)
+    # (measured: text fp16 2.2e-4 / 5.5e-4, text fp32 2.4e-6 / 7.2e-5, id bf16 8.5e-5 / 5.4e-4; a scatter that dropped every source row past
+    # the first 32 candidates -- lanes without columns were missing from a ballot -- showed up here as 1e-2 on the id tower)
+    assert dl < (2e-4 if dtype == "fp32" else 3e-3) and dp < (1e-3 if dtype == "fp32" else 4e-3)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16])
