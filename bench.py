@@ -7,8 +7,9 @@ One "step" = one pass of the hot path over one batch of synthetic MIND-shaped in
 H2D of (ids, token rows, log_mask) -> BERT-base item encoder fwd -> SASRec -> fused in-batch debiased CE
 -> full backward -> gradient all-reduce (N > 1; negatives pooled over ranks by all-gather) -> fused AdamW.
 Workload: BASELINE.json configs[2] = SASRec + BERT-base, B = 128 user sequences per GPU, S = 20 (raw
-history 23), 30-token titles, D = 512, 2 heads, 2 blocks; bf16 MFMA operands / fp32 accumulate / fp32 master
-weights (the reference runs fp16 autocast, T/run.py:242).  Prints ONE JSON line on rank 0.
+history 23), 30-token titles, D = 512, 2 heads, 2 blocks; fp16 MFMA operands / fp32 accumulate / fp32 master
+weights with the GradScaler protocol on the device (the reference runs fp16 autocast + GradScaler, T/run.py:210,242-247).
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
