@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): kernel trace + PMC passes of the bench command and of four GEMM shapes; everything lands in
 # gpurun_out/ (copy what is to be judged into profiles/).   bash scripts/capture_profiles.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 # Single-stream runs for the per-kernel numbers (with the weight-gradient stream on, dW launches overlap the dX chain and the traced
@@ -15,6 +15,10 @@ python $R/scripts/prof_summary.py /tmp/prof/kt_results.db $NS "$TAG: MOREC_WGRAD
 rm -f /tmp/prof/ko_results.db
 MOREC_WGRAD_STREAM=1 timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ko -- $BENCH > /dev/null 2>&1
 python $R/scripts/prof_summary.py /tmp/prof/ko_results.db $NS "$TAG: default step (weight-gradient stream ON: kernels of the two streams overlap, their durations add up to more than the step)" > $O/${TAG}_bench_kernel_stats_overlap.csv
+# the fp16_res32 mode (fp32 residual stream): single-stream kernel trace
+rm -f /tmp/prof/kr_results.db
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o kr -- $BENCH --dtype fp16_res32 > /dev/null 2>&1
+python $R/scripts/prof_summary.py /tmp/prof/kr_results.db $NS "$TAG fp16_res32: MOREC_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -- bench.py --dtype fp16_res32 --steps 4 --warmup 2 --no-cpu-baseline --no-secondary ($NS steps traced; single stream)" > $O/${TAG}_res32_kernel_stats.csv
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof -o pf -- $BENCH > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof -o pw -- $BENCH > /dev/null 2>&1
 python $R/scripts/pmc_traffic.py /tmp/prof/pf_results.db /tmp/prof/pw_results.db $O/${TAG}_prof_bench_line.json $O/${TAG}_gemm_pmc.json
@@ -58,3 +62,18 @@ python $R/scripts/prof_summary.py /tmp/prof/cek_results.db 1 "$TAG scoring at th
 python $R/scripts/ce_pooled_bench.py 20 0 512
 python $R/scripts/ce_pooled_bench.py 20 1 512 8
 } > $O/${TAG}_scoring_pmc.txt 2>&1
+
+# round 5: tile height of gemm8p per shape (256-row tiles vs automatic vs forced 224 / 192) and the 64 x 64 attention tile against the VALU fallback
+{
+echo "# python scripts/tmr_bench.py  -- per launch: <gemm8p_tmr mode>:<time>/<TFLOP/s>; modes 0 = 256-row tiles, 1 = automatic (pick_tmr), 224 / 192 forced; 20 launches each, same process"
+python $R/scripts/tmr_bench.py
+} > $O/${TAG}_tile_height.txt 2>&1
+{
+echo "# python scripts/attn64_bench.py (T = 50, 2688 titles, 12 heads x 64, fp16, dropout 0.1): attention_mfma64.hip, then MOREC_ATTN_MFMA64=0 (exact-fp32 VALU kernels)"
+python $R/scripts/attn64_bench.py
+MOREC_ATTN_MFMA64=0 python $R/scripts/attn64_bench.py
+} > $O/${TAG}_attn64.txt 2>&1
+# ID tower kernel trace (two streams, as it runs)
+rm -f /tmp/prof/ki_results.db
+MOREC_WGRAD_STREAM=1 timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ki -- python $R/bench.py --tower id --batch 128 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+python $R/scripts/prof_summary.py /tmp/prof/ki_results.db 34 "$TAG id tower: rocprofv3 --kernel-trace --stats -- bench.py --tower id --batch 128 --steps 20 --warmup 5 (34 steps traced, two streams)" > $O/${TAG}_id_tower_kernel_stats.csv

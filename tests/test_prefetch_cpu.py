@@ -69,3 +69,71 @@ def test_batches_from_worker_processes_arrive_in_order():
     for idx, (a, b, c, pack) in zip(batches, got):
         assert a.tolist() == idx and b.tolist() == [2.0 * v for v in idx] and c.shape == (len(idx), 3)
         assert pack[0].dtype == torch.int32 and pack[0].tolist() == idx and pack[1] is None
+
+
+def _maker(n_users=37, n_items=50, S=6, T=5, attrs=(("title", 0, 10),), seed=0):
+    from idvs.morec_amd.run import BatchMaker
+    rng = np.random.default_rng(seed)
+    users_train = {u: [int(v) for v in rng.integers(1, n_items + 1, int(rng.integers(2, S + 2)))] for u in range(n_users)}
+    width = sum(w for _, _, w in attrs)
+    content = np.zeros((n_items + 1, width), dtype=np.int64)
+    for _, a0, aw in attrs:
+        h = aw // 2
+        lens = rng.integers(1, h + 1, n_items)
+        valid = np.arange(h)[None, :] < lens[:, None]
+        content[1:, a0:a0 + h] = np.where(valid, rng.integers(1, 99, (n_items, h)), 0)
+        content[1:, a0 + h:a0 + aw] = valid
+    return BatchMaker(list(users_train), users_train, content, S, True, text_attrs=list(attrs), pin=False), users_train, content
+
+
+def test_batch_maker_pickles_and_builds_one_packing_per_attribute():
+    """``run.BatchMaker`` (round 5): the host side of a batch as a picklable object over numpy tables (DataLoader workers under fork,
+    forkserver or spawn); with several text attributes (``--news_attributes title,abstract``) one unpadded-layout packing per attribute."""
+    import pickle
+    from idvs.morec_amd import engine
+    mk, users_train, content = _maker(attrs=(("title", 0, 10), ("abstract", 10, 16)))
+    mk2 = pickle.loads(pickle.dumps(mk))
+    for m in (mk, mk2):
+        ids, items, lm, pack = m([0, 5, 9])
+        assert ids.shape == (3, 7) and items.shape == (3, 7, 26) and lm.shape == (3, 6)
+        assert isinstance(pack, tuple) and len(pack) == 2 and all(len(p) == 4 for p in pack)
+        rows = items.view(-1, 26)
+        for (name, a0, aw), p in zip(m.text_attrs, pack):
+            h = aw // 2
+            want = engine.token_packing_host(rows[:, a0 + h:a0 + aw], rows[:, a0:a0 + h], pin=False)
+            assert all(torch.equal(x, y) for x, y in zip(p, want))
+            lens = (rows[:, a0 + h:a0 + aw] != 0).sum(1).clamp(min=1)
+            assert int(p[0][-1]) == int(lens.sum()) and p[1].numel() == int(lens.sum())
+    single, *_ = _maker()
+    pack1 = single([1, 2])[3]
+    assert len(pack1) == 4 and pack1[0].dtype == torch.int32          # one attribute: the packing tuple itself, as before
+
+
+def test_persistent_loader_follows_the_epoch_sampler():
+    """One DataLoader for the whole run (``persistent_workers``): a sample key is (epoch, b) and the WORKER derives the epoch's index
+    batches (``epoch_batches``: torch's DistributedSampler + batching), so batches match the in-process collate for every epoch, in order,
+    without anything being sent to the workers between epochs."""
+    from idvs.morec_amd.data_utils import epoch_batches
+    from idvs.morec_amd.run import _EpochBatchSet, _EpochSampler, _with_next
+    mk, users_train, content = _maker()
+    sampler = _EpochSampler()
+    loader = torch.utils.data.DataLoader(_EpochBatchSet(mk, len(users_train), 8, 2, 1), batch_size=None, sampler=sampler, num_workers=2,
+                                         prefetch_factor=2, persistent_workers=True, multiprocessing_context="fork")
+    for ep in (1, 2, 5):
+        batches = epoch_batches(len(users_train), 8, 2, 1, ep)
+        sampler.set_epoch(ep, len(batches))
+        got = list(loader)
+        assert len(got) == len(batches)
+        for idx, (ids, items, lm, pack) in zip(batches, got):
+            w_ids, w_items, w_lm, w_pack = mk(idx)
+            assert torch.equal(ids, w_ids) and torch.equal(items, w_items) and torch.equal(lm, w_lm)
+            assert all(torch.equal(x, y) for x, y in zip(pack, w_pack))
+    # an epoch cut short (--max_steps) leaves the loader usable
+    sampler.set_epoch(7, 3)
+    it = iter(loader)
+    next(it)
+    del it
+    sampler.set_epoch(8, 2)
+    assert len(list(loader)) == 2
+    pairs = list(_with_next(iter([10, 11, 12])))
+    assert pairs == [(10, 11), (11, 12), (12, None)] and list(_with_next(iter([]))) == []
