@@ -9,7 +9,10 @@ times.  Asserted here, at north_star's tolerance:
   relative (measured 3.1e-4; absolute 3.4e-3 on a loss of 10.90 -- a 12-layer encoder at random init, whose [CLS] rows are nearly
   identical across items, so rounding errors do not average out over the 2 560 rows; bf16: 1.3e-3 ... 1.5e-2 absolute), gradient norms
   within 1.5e-2 (measured 7.9e-3), the 20-step loss curve within 1e-2 relative (a scale that fits from the start: no skipped step);
-* HR@10 / nDCG@10 of the modal eval golden g17 in the fp16, bf16 and fp32x3 modes (``T/data_utils/metrics.py:60-107``);
+* the same in the ``fp16_res32`` mode (16-bit GEMM operands, fp32 residual stream and LayerNorm / softmax in fp32 -- the data flow
+  autocast itself produces): g6 within the error the reference's OWN CPU autocast run has against its fp32 run (golden g20:
+  tiny 7.9e-3, base 5.0e-3), and at the bench configuration step-0 loss within 1e-3 ABSOLUTE of the fp32 mode (measured 2.9e-4);
+* HR@10 / nDCG@10 of the modal eval golden g17 in the fp16, fp16_res32, bf16 and fp32x3 modes (``T/data_utils/metrics.py:60-107``);
 * the loss scaler: an overflowing step is skipped whole (parameters, moments, step count untouched), the scale backs off until a step applies."""
 import logging
 import os
@@ -273,7 +276,7 @@ def test_deferred_update_equals_the_inline_one():
     assert res[True][0][-1] < res[True][0][0] - 0.5            # eight steps move the loss by far more than either bound
 
 
-@pytest.mark.parametrize("mode", ["fp16", "bf16", "fp32x3"])
+@pytest.mark.parametrize("mode", ["fp16", "fp16_res32", "bf16", "fp32x3"])
 def test_g17_modal_eval_golden_in_the_fast_modes(golden_dir, mode):
     """HR@10 / nDCG@10 through the BERT tower on the device in the modes that are timed (golden g17, captured from the reference's
     ``get_item_embeddings(use_modal=True)`` + ``eval_model``): users whose target score is separated from every competitor by more
@@ -310,7 +313,7 @@ def test_g17_modal_eval_golden_in_the_fast_modes(golden_dir, mode):
     flips = int((hit.cpu().numpy() != g["hit_per_user"]).sum())
     print(f"g17 {mode}: item vectors max abs err {err:.2e} (scale {scale:.2e}); {int(safe.sum())}/{U} users decided beyond the mode's noise "
           f"({noise:.2e}); hit flips {flips}; HR@10 {hit10:.4f} vs reference {float(g['hit10']):.4f}")
-    assert err < {"fp16": 4e-3, "bf16": 3e-2, "fp32x3": 5e-5}[mode] * max(scale, 1.0)
+    assert err < {"fp16": 4e-3, "fp16_res32": 4e-3, "bf16": 3e-2, "fp32x3": 5e-5}[mode] * max(scale, 1.0)
     assert np.array_equal(hit.cpu().numpy()[safe], g["hit_per_user"][safe])
     if mode != "bf16":
         assert abs(hit10 - float(g["hit10"])) < 1e-3          # north_star: HR@10 within 1e-3
