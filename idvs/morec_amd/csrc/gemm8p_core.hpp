@@ -94,11 +94,31 @@ __device__ __forceinline__ void vm_wait_tail() {
     vm_wait<(REM >= 2 ? 8 + SLACK : (REM == 1 ? W1 : W0))>();
 }
 
+#ifdef G8_EXP_SHADOW
+// EXPERIMENT (not in the product build): G8_EXP_SHADOW units of 4 GELU + derivative evaluations on dummy registers in every read / DMA
+// segment -- what VALU work in the partner wave's MFMA shadow costs the main loop.
+#define G8_GS_PARAM , float (&gs)[4]
+#define G8_GS_ARG , gs
+#define G8_SHADOW()                                                   \
+    do {                                                              \
+        pin();                                                        \
+        _Pragma("unroll") for (int u_ = 0; u_ < G8_EXP_SHADOW; ++u_) { \
+            float d_[4];                                              \
+            gelu4_with_deriv(gs, d_);                                 \
+            _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) gs[r_] = gs[r_] * 0.5f + d_[r_]; \
+        }                                                             \
+        pin();                                                        \
+    } while (0)
+#else
+#define G8_GS_PARAM
+#define G8_GS_ARG
+#define G8_SHADOW() do {} while (0)
+#endif
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
 // last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
 // BAUX: cache policy of the B-panel loads (see dma2)
 template <typename T16, int REM, int SLACK = 0, bool ZERO = false, int BAUX = 0, int NBW = 4>
-__device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 = false) {
+__device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, f32x16_t (&acc)[4][2], bool last2 G8_GS_PARAM) {
     const uint32_t m1 = REM == 1 ? 0xffffffffu : 0u;           // K-tile t + 1 is the last one exactly when REM == 1
     const uint32_t m2 = last2 ? 0xffffffffu : 0u;
     static_assert(SLACK == 0 || REM == 2, "slack only on a steady K-tile");
@@ -119,6 +139,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
     if constexpr (REM >= 1) dma2z<BAUX>(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
+    G8_SHADOW();
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
@@ -128,6 +149,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb1[ks] = lds16(smem + adb[ks] + 32 * KB);
     if constexpr (REM >= 1) dma2z(c.ra, c.a2[0], c.a2[1], c.pz, m1, kb + KB, oth + c.dA2);
+    G8_SHADOW();
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
@@ -139,6 +161,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + (64 + mi * 32) * KB);
     if constexpr (REM >= 2) dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m2, kb + 2 * KB, cur + c.dA1);
+    G8_SHADOW();
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
@@ -146,6 +169,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
+    G8_SHADOW();
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();
@@ -216,10 +240,15 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     bar();                   // ... everybody's
     if (wr == 1) bar();      // waves 4-7 run one barrier behind waves 0-3 from here on
     G8_MSTAMP(10);
+#ifdef G8_EXP_SHADOW
+    float gs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gs[r] = (float)(c.loff[r] & 255) * 0.01f;
+#endif
     int cb = 0;
     int t = 0;
     if (nk >= 3) {     // first K-tile: accumulators start from zero; the previous epilogue's stores drain under it
-        ktile<T16, 2, SLACK, true, BAUX, NBW>(smem, c, cb, 0, acc, nk == 3);
+        ktile<T16, 2, SLACK, true, BAUX, NBW>(smem, c, cb, 0, acc, nk == 3 G8_GS_ARG);
         cb ^= BUF_BYTES;
         t = 1;
     } else {
@@ -232,13 +261,16 @@ __device__ __forceinline__ void mainloop8p_s(const Ctx& c, int wr, int nk, char*
     }
     G8_MSTAMP(11);
     for (; t < nk - 2; ++t) {
-        ktile<T16, 2, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc, t + 3 == nk);
+        ktile<T16, 2, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc, t + 3 == nk G8_GS_ARG);
         cb ^= BUF_BYTES;
         if (t == 1) G8_MSTAMP(12);
     }
     G8_MSTAMP(13);
-    ktile<T16, 1, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc);
-    ktile<T16, 0, 0, false, BAUX, NBW>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc);
+    ktile<T16, 1, 0, false, BAUX, NBW>(smem, c, cb, t * KB, acc, false G8_GS_ARG);
+    ktile<T16, 0, 0, false, BAUX, NBW>(smem, c, cb ^ BUF_BYTES, (t + 1) * KB, acc, false G8_GS_ARG);
+#ifdef G8_EXP_SHADOW
+    asm volatile("" ::"v"(gs[0]), "v"(gs[1]), "v"(gs[2]), "v"(gs[3]));
+#endif
     G8_MSTAMP(14);
     if (wr == 0) bar();      // waves 0-3 catch the trailing barrier of waves 4-7
     G8_MSTAMP(15);
