@@ -139,8 +139,7 @@ __device__ __forceinline__ void softmax_regs(f32x4_t (&s)[NB][NB], const AttnMAr
                 s[qb][kb][r] = (j < a.T) ? v : -INFINITY;
                 m = fmaxf(m, s[qb][kb][r]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
@@ -150,8 +149,7 @@ __device__ __forceinline__ void softmax_regs(f32x4_t (&s)[NB][NB], const AttnMAr
                 s[qb][kb][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
         const float inv = (i < a.T) ? 1.0f / sum : 0.f;
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
@@ -419,8 +417,7 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma64_kernel(AttnMArgs a) {
                 if (a.drop.thresh) dp[qb][kb][r] *= msk[qb][kb][r];     // dP = dP_dropped o mask / (1 - p)
                 delta += s[qb][kb][r] * dp[qb][kb][r];
             }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
+        delta = rows4_sum(delta);
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll

@@ -199,6 +199,32 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Butterfly steps over lane ^ 16 and lane ^ 32 in the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane rows
+// (the upper 32 lanes) of one register with the even rows (the lower 32 lanes) of another, so with both registers holding v the pair
+// afterwards holds {v[lane & ~16], v[lane | 16]} ({v[lane & 31], v[lane | 32]}) and one add / max finishes the step -- instead of a
+// ds_bpermute round trip through the LDS crossbar (~120 cycles, fully exposed in the one-wave-per-SIMD attention kernels, six per query
+// block).  Inline asm: given the same value twice, the builtin form folds its two results into one (hipcc 7.2); the s_nop covers the
+// VALU-write -> permlane-read wait states the compiler cannot see into.
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// sum / max over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (every lane receives the result)
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    permlane16_swap(a, b);
+    a += b;
+    b = a;
+    permlane32_swap(a, b);
+    return a + b;
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    float a = v, b = v;
+    permlane16_swap(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    permlane32_swap(a, b);
+    return fmaxf(a, b);
+}
+
 // erf GELU (HF "gelu" / nn.GELU: 0.5 x (1 + erf(x / sqrt 2))) and its derivative.
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at the fp32 rounding level of the result): one v_rcp, one
 // v_exp and five FMAs instead of OCML erff's ~50-instruction expansion -- at 248 M activations per FFN layer the

@@ -145,6 +145,10 @@ __device__ __forceinline__ LaneGeom window_geom(const SwinMArgs& a, int g) {
     return G;
 }
 
+// Accumulator element r of key block tj holds key 16 tj + 4 (lane >> 4) + r: with NT = 49, elements r = 1..3 of block 3 are padded keys in EVERY
+// lane (probability exactly 0, whatever the scores) -- the softmax, its backward and the bias gradient skip them at compile time.
+__device__ __forceinline__ constexpr bool dead_key(int tj, int r) { return 16 * tj + r >= NT; }
+
 // scores (S^T accumulators, layout [tj][ti][r]) -> probabilities, in place.  bias4(tj, ti) supplies the 4 consecutive keys'
 // bias (+ -inf on padded keys).
 template <typename BiasF>
@@ -159,6 +163,7 @@ __device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, Bi
             const f32x4_t b = bias4(tj, ti);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (dead_key(tj, r)) continue;
                 s[tj][ti][r] = fmaf(s[tj][ti][r], scale, b[r]);
                 m = fmaxf(m, s[tj][ti][r]);
             }
@@ -171,30 +176,30 @@ __device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, Bi
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (dead_key(tj, r)) continue;
                     s[tj][ti][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][ti][r]);
                     m = fmaxf(m, s[tj][ti][r]);
                 }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (dead_key(tj, r)) continue;
                 const float e = __expf(s[tj][ti][r] - m);
                 s[tj][ti][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
         // padded query rows (token >= NT) get probability 0 everywhere: their q / dO fragments are unguarded re-reads of token
         // 0's rows (see the load note in the kernels), and a zero P row keeps them out of dS, dK, dV and dbias
         const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[tj][ti][r] *= inv;
+            for (int r = 0; r < 4; ++r) s[tj][ti][r] = dead_key(tj, r) ? 0.f : s[tj][ti][r] * inv;
     }
 }
 
@@ -314,6 +319,7 @@ __device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, 
             const f32x4_t b = bias4(tj, ti);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (dead_key(tj, r)) continue;
                 s[tj][t][r] = fmaf(s[tj][t][r], scale, b[r]);
                 m = fmaxf(m, s[tj][t][r]);
             }
@@ -325,28 +331,28 @@ __device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, 
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (dead_key(tj, r)) continue;
                     s[tj][t][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][t][r]);
                     m = fmaxf(m, s[tj][t][r]);
                 }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows4_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (dead_key(tj, r)) continue;
                 const float e = __expf(s[tj][t][r] - m);
                 s[tj][t][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows4_sum(sum);
         const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;     // padded query rows: probability 0
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[tj][t][r] *= inv;
+            for (int r = 0; r < 4; ++r) s[tj][t][r] = dead_key(tj, r) ? 0.f : s[tj][t][r] * inv;
     }
 }
 
@@ -478,13 +484,14 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) delta = fmaf(s[tj][0][r], dp[tj][0][r], delta);
-            delta += __shfl_xor(delta, 16, 64);
-            delta += __shfl_xor(delta, 32, 64);
+                for (int r = 0; r < 4; ++r)
+                    if (!dead_key(tj, r)) delta = fmaf(s[tj][0][r], dp[tj][0][r], delta);
+            delta = rows4_sum(delta);
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (dead_key(tj, r)) { dp[tj][0][r] = 0.f; continue; }
                     const float ds = s[tj][0][r] * (dp[tj][0][r] - delta);
                     dp[tj][0][r] = ds;
                     dbacc[tj][TB][r] += ds;
