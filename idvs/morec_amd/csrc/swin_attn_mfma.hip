@@ -27,6 +27,9 @@ constexpr int TILE = 64 * TROW;       // 4 KiB
 constexpr int PROW = 136;             // bytes per row of the [64 x 64] bf16 P / dS tile (17 x 8: odd multiple of 8 B)
 constexpr int PTILE = 64 * PROW;
 constexpr int BP = 68;                // floats per row of the shared [NT x 64] bias / dbias tiles
+#ifndef SWIN_BWD_NTI
+#define SWIN_BWD_NTI 2                // query blocks the one-wave-per-SIMD backward runs through the softmax together (1 | 2 | 4)
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
@@ -149,57 +152,73 @@ __device__ __forceinline__ LaneGeom window_geom(const SwinMArgs& a, int g) {
 // lane (probability exactly 0, whatever the scores) -- the softmax, its backward and the bias gradient skip them at compile time.
 __device__ __forceinline__ constexpr bool dead_key(int tj, int r) { return 16 * tj + r >= NT; }
 
-// scores (S^T accumulators, layout [tj][ti][r]) -> probabilities, in place.  bias4(tj, ti) supplies the 4 consecutive keys'
-// bias (+ -inf on padded keys).
-template <typename BiasF>
-__device__ __forceinline__ void softmax_rows(f32x4_t (&s)[4][4], float scale, BiasF bias4, const LaneGeom& G, const MaskBits& mb) {
+// Scores (S^T accumulators s[tj][t][r], t = query blocks TB .. TB + NTI - 1) -> probabilities, in place.  bias4(tj, ti) supplies the 4
+// consecutive keys' bias (+ -inf on padded keys).  Written in STAGES over all NTI blocks -- scale + bias; the region mask behind ONE wave-uniform
+// branch; max; exp + sum; normalise -- so that the NTI dependency chains (MFMA result -> max -> lane exchange -> exp -> sum -> lane exchange ->
+// scale) sit in the same basic blocks and the scheduler overlaps them: with the branch inside a per-block loop every query block was its own
+// scheduling region and, at one wave per SIMD, paid each of those latencies in full.
+template <int TB, int NTI, typename BiasF>
+__device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, BiasF bias4, const LaneGeom& G, const MaskBits& mb) {
     const bool masked = G.edge_r || G.edge_c;
-    const uint32_t er = G.edge_r ? 0xffffu : 0u, ec = G.edge_c ? 0xffffu : 0u;
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-        float m = -INFINITY;
+    for (int t = 0; t < NTI; ++t)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
-            const f32x4_t b = bias4(tj, ti);
+            const f32x4_t b = bias4(tj, TB + t);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (dead_key(tj, r)) continue;
-                s[tj][ti][r] = fmaf(s[tj][ti][r], scale, b[r]);
-                m = fmaxf(m, s[tj][ti][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                if (!dead_key(tj, r)) s[tj][t][r] = fmaf(s[tj][t][r], scale, b[r]);
         }
-        if (masked) {   // wave-uniform: only windows on the last window row / column of a shifted block hold several regions
+    if (masked) {   // wave-uniform: only windows on the last window row / column of a shifted block hold several regions
+        const uint32_t er = G.edge_r ? 0xffffu : 0u, ec = G.edge_c ? 0xffffu : 0u;
+#pragma unroll
+        for (int t = 0; t < NTI; ++t) {
+            const int ti = TB + t;
             // bit (4 tj + r) set <=> key j lies in another region than query i
             const uint32_t bits = ((((mb.ai >> ti) & 1u) ? ~mb.aj : mb.aj) & er) | ((((mb.bi >> ti) & 1u) ? ~mb.bj : mb.bj) & ec);
-            m = -INFINITY;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (dead_key(tj, r)) continue;
-                    s[tj][ti][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][ti][r]);
-                    m = fmaxf(m, s[tj][ti][r]);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (!dead_key(tj, r)) s[tj][t][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][t][r]);
         }
-        m = rows4_max(m);
-        float sum = 0.f;
+    }
+    float m[NTI], sum[NTI];
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) {
+        m[t] = -INFINITY;
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!dead_key(tj, r)) m[t] = fmaxf(m[t], s[tj][t][r]);
+    }
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) m[t] = rows4_max(m[t]);
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) {
+        sum[t] = 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (dead_key(tj, r)) continue;
-                const float e = __expf(s[tj][ti][r] - m);
-                s[tj][ti][r] = e;
-                sum += e;
+                const float e = __expf(s[tj][t][r] - m[t]);
+                s[tj][t][r] = e;
+                sum[t] += e;
             }
-        sum = rows4_sum(sum);
+    }
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) sum[t] = rows4_sum(sum[t]);
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) {
         // padded query rows (token >= NT) get probability 0 everywhere: their q / dO fragments are unguarded re-reads of token
         // 0's rows (see the load note in the kernels), and a zero P row keeps them out of dS, dK, dV and dbias
-        const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;
+        const float inv = (16 * (TB + t) + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum[t] : 0.f;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[tj][ti][r] = dead_key(tj, r) ? 0.f : s[tj][ti][r] * inv;
+            for (int r = 0; r < 4; ++r) s[tj][t][r] = dead_key(tj, r) ? 0.f : s[tj][t][r] * inv;
     }
 }
 
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) s[tj][ti] = mfma<T16>(kf[tj], qf[ti], f32x4_t{0.f, 0.f, 0.f, 0.f});
-        softmax_rows(s, a.scale, [&](int tj, int ti) { return f32x4_t{bias[tj][ti][0], bias[tj][ti][1], bias[tj][ti][2], bias[tj][ti][3]}; }, G, mb);
+        softmax_part<0, 4>(s, a.scale, [&](int tj, int ti) { return f32x4_t{bias[tj][ti][0], bias[tj][ti][1], bias[tj][ti][2], bias[tj][ti][3]}; }, G, mb);
         wave_lds_fence();
         f32x4_t o[2][4];
 #pragma unroll
@@ -304,58 +323,9 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
     }
 }
 
-// Backward softmax for NTI of the four query blocks (ti = TB .. TB + NTI - 1): with all four blocks at once the live set (P 64 +
-// dP 64 + dbias 64 + operand fragments) spilled 42 registers.  s: [tj][t] accumulators of S^T for those blocks.
-template <int TB, int NTI, typename BiasF>
-__device__ __forceinline__ void softmax_part(f32x4_t (&s)[4][NTI], float scale, BiasF bias4, const LaneGeom& G, const MaskBits& mb) {
-    const bool masked = G.edge_r || G.edge_c;
-    const uint32_t er = G.edge_r ? 0xffffu : 0u, ec = G.edge_c ? 0xffffu : 0u;
-#pragma unroll
-    for (int t = 0; t < NTI; ++t) {
-        const int ti = TB + t;
-        float m = -INFINITY;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-            const f32x4_t b = bias4(tj, ti);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (dead_key(tj, r)) continue;
-                s[tj][t][r] = fmaf(s[tj][t][r], scale, b[r]);
-                m = fmaxf(m, s[tj][t][r]);
-            }
-        }
-        if (masked) {   // wave-uniform (see softmax_rows)
-            const uint32_t bits = ((((mb.ai >> ti) & 1u) ? ~mb.aj : mb.aj) & er) | ((((mb.bi >> ti) & 1u) ? ~mb.bj : mb.bj) & ec);
-            m = -INFINITY;
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (dead_key(tj, r)) continue;
-                    s[tj][t][r] = fmaf((float)((bits >> (4 * tj + r)) & 1u), -100.0f, s[tj][t][r]);
-                    m = fmaxf(m, s[tj][t][r]);
-                }
-        }
-        m = rows4_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (dead_key(tj, r)) continue;
-                const float e = __expf(s[tj][t][r] - m);
-                s[tj][t][r] = e;
-                sum += e;
-            }
-        sum = rows4_sum(sum);
-        const float inv = (16 * ti + (int)(threadIdx.x & 15) < NT) ? 1.0f / sum : 0.f;     // padded query rows: probability 0
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[tj][t][r] = dead_key(tj, r) ? 0.f : s[tj][t][r] * inv;
-    }
-}
-
+// The backward runs the softmax for NTI of the four query blocks at a time: with all four at once and two waves per SIMD the live set (P 64 +
+// dP 64 + dbias 64 + operand fragments) spilled 42 registers, so that form takes one block at a time; the one-wave-per-SIMD form (WIDE, 512
+// registers) takes two, whose dependency chains overlap.
 template <typename T16, int NTI>
 __device__ __forceinline__ uint4 pack_part(const f32x4_t (&p)[4][NTI], int t, int sk) {
     uint4 f;
@@ -466,51 +436,74 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
         uint4 dsf[4][2];
         // one 16-query block at a time (see softmax_part); dO rows of the block come back from the tile just written
         wave_lds_fence();
-        auto block = [&](auto TBc) {
-            constexpr int TB = decltype(TBc)::value;
-            f32x4_t s[4][1], dp[4][1];
-            const uint4 ob = *reinterpret_cast<const uint4*>(sX + (c + 16 * TB) * TROW + 16 * g4);
+        auto block = [&](auto TBc, auto NTIc) {
+            constexpr int TB = decltype(TBc)::value, NTI = decltype(NTIc)::value;
+            f32x4_t s[4][NTI], dp[4][NTI];
+            uint4 ob[NTI];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
-                s[tj][0] = mfma<T16>(fr.k[tj], fr.q[TB], f32x4_t{0.f, 0.f, 0.f, 0.f});
-                dp[tj][0] = mfma<T16>(fr.v[tj], ob, f32x4_t{0.f, 0.f, 0.f, 0.f});
-            }
+            for (int t = 0; t < NTI; ++t) ob[t] = *reinterpret_cast<const uint4*>(sX + (c + 16 * (TB + t)) * TROW + 16 * g4);
+#pragma unroll
+            for (int t = 0; t < NTI; ++t)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    s[tj][t] = mfma<T16>(fr.k[tj], fr.q[TB + t], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                    dp[tj][t] = mfma<T16>(fr.v[tj], ob[t], f32x4_t{0.f, 0.f, 0.f, 0.f});
+                }
             // padded query rows (i >= NT) read the last real bias row; softmax_part zeroes their probabilities
-            softmax_part<TB, 1>(s, a.scale, [&](int tj, int ti) {
+            softmax_part<TB, NTI>(s, a.scale, [&](int tj, int ti) {
                 return *reinterpret_cast<const f32x4_t*>(sBias + min(16 * ti + c, NT - 1) * BP + 16 * tj + 4 * g4);
             }, G, mb);
             // dS = P o (dP - rowsum(P o dP)); dbias += dS.  dS is exactly 0 on padded keys and padded queries (P = 0 on both).
-            float delta = 0.f;
+            float delta[NTI];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int t = 0; t < NTI; ++t) {
+                delta[t] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (!dead_key(tj, r)) delta = fmaf(s[tj][0][r], dp[tj][0][r], delta);
-            delta = rows4_sum(delta);
+                for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+                    for (int r = 0; r < 4; ++r)
+                        if (!dead_key(tj, r)) delta[t] = fmaf(s[tj][t][r], dp[tj][t][r], delta[t]);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (dead_key(tj, r)) { dp[tj][0][r] = 0.f; continue; }
-                    const float ds = s[tj][0][r] * (dp[tj][0][r] - delta);
-                    dp[tj][0][r] = ds;
-                    dbacc[tj][TB][r] += ds;
-                }
+            for (int t = 0; t < NTI; ++t) delta[t] = rows4_sum(delta[t]);
+#pragma unroll
+            for (int t = 0; t < NTI; ++t)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (dead_key(tj, r)) { dp[tj][t][r] = 0.f; continue; }
+                        const float ds = s[tj][t][r] * (dp[tj][t][r] - delta[t]);
+                        dp[tj][t][r] = ds;
+                        dbacc[tj][TB + t][r] += ds;
+                    }
             // P to the row-major LDS tile [i][j] (for dV); dS fragments stay in registers (for dQ) and follow P into the tile (for dK)
-            char* prow = sP + (16 * TB + c) * PROW;
 #pragma unroll
-            for (int sk = 0; sk < 2; ++sk) {
-                dsf[TB][sk] = pack_part<T16, 1>(dp, 0, sk);
-                const uint4 pfr = pack_part<T16, 1>(s, 0, sk);
-                *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
-                *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
+            for (int t = 0; t < NTI; ++t) {
+                char* prow = sP + (16 * (TB + t) + c) * PROW;
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    dsf[TB + t][sk] = pack_part<T16, NTI>(dp, t, sk);
+                    const uint4 pfr = pack_part<T16, NTI>(s, t, sk);
+                    *reinterpret_cast<uint2*>(prow + (32 * sk + 4 * g4) * 2) = make_uint2(pfr.x, pfr.y);          // keys 16 (2 sk) + 4 g + r
+                    *reinterpret_cast<uint2*>(prow + (32 * sk + 16 + 4 * g4) * 2) = make_uint2(pfr.z, pfr.w);     // keys 16 (2 sk + 1) + 4 g + r
+                }
             }
             if (!WIDE) __builtin_amdgcn_sched_barrier(0);      // the next block starts when this one's registers are free
         };
-        block(std::integral_constant<int, 0>{});
-        block(std::integral_constant<int, 1>{});
-        block(std::integral_constant<int, 2>{});
-        block(std::integral_constant<int, 3>{});
+        if constexpr (WIDE) {
+            block(std::integral_constant<int, 0>{}, std::integral_constant<int, SWIN_BWD_NTI>{});
+            if constexpr (SWIN_BWD_NTI < 4) block(std::integral_constant<int, SWIN_BWD_NTI>{}, std::integral_constant<int, SWIN_BWD_NTI>{});
+            if constexpr (SWIN_BWD_NTI < 2) {
+                block(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+                block(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+            }
+        } else {
+            block(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            block(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            block(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+        }
         wave_lds_fence();
         // dQ^T[d][i] = scale * sum_j K[j][d] dS[i][j]
         {
