@@ -173,9 +173,11 @@ _WS_RETIRED = []
 def _scratch(cache, device, need, floor):
     ws = cache.get(device)
     if ws is None or ws.numel() < need:
+        grown = 0
         if ws is not None:
             _WS_RETIRED.append(ws)
-        ws = torch.empty(max(need, floor), device=device, dtype=torch.float32)
+            grown = ws.numel() + ws.numel() // 2      # geometric growth: everything ever retired stays below twice the live buffer
+        ws = torch.empty(max(need, floor, grown), device=device, dtype=torch.float32)
         cache[device] = ws
     return ws
 
