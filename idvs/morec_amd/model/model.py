@@ -22,6 +22,10 @@ class Model(nn.Module):
         self.compute_dtype = resolve_dtype(args)
         self.fp32_gemm = resolve_fp32_gemm(args)                      # "exact" | "bf16x3": how fp32 GEMMs run (ops.FP32_GEMM)
         self.res32 = resolve_res32(args) and not hasattr(args, "CV_model_load")      # fp32 residual stream (autocast data flow): text / ID towers
+        if resolve_res32(args) and not self.res32:
+            import sys
+            print(f"morec: compute_dtype={getattr(args, 'compute_dtype', None)!r}: the vision tower has no fp32-residual-stream kernels (pre-LN Swin blocks keep "
+                  f"their 16-bit stream); running it as {str(self.compute_dtype).replace('torch.', '')!r}", file=sys.stderr)
         self.pop_prob_list = torch.FloatTensor(pop_prob_list)        # plain attribute, as in T/model/model.py:14
         self._log_pop = None                                          # log(pop) table, built once per device
         # pooled negatives across ranks; off = the reference's rank-local negatives
