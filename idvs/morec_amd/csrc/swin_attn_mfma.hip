@@ -667,7 +667,12 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     a.n_img = d->n_img; a.H = d->H; a.W = d->W; a.shift = d->shift; a.heads = d->heads; a.scale = d->scale;
     a.n_win_total = d->n_img * (d->H / WS) * (d->W / WS);
     const long tiles = (long)a.n_win_total * d->heads;
-    a.wpw = (int)std::max<long>(1, std::min<long>(32, tiles / 8192));
+    // Windows per wavefront.  Every BACKWARD workgroup ends with the reduction of its four wavefronts' dbias registers through LDS + 2 401 atomics: at the
+    // 1 ... 4 windows per wavefront the deep stages get from tiles / 8192 that was a third of its time -- at least 8 there (Swin-T stage 3, 704 images:
+    // 182 -> 148 us; Swin-B's stage 2, 352 images: 183 -> 145 us; profiles/r05_swin_attn_pmc.txt).  The forward has no such tail and loses 8-17 % to the
+    // smaller grid, so it keeps the plain rule.  MOREC_SWIN_WPW_MIN overrides the backward's floor.
+    static const int wpw_min_bwd = [] { const char* e = getenv("MOREC_SWIN_WPW_MIN"); return e ? std::max(1, atoi(e)) : 8; }();
+    a.wpw = (int)std::max<long>(backward ? wpw_min_bwd : 1, std::min<long>(32, tiles / 8192));
     a.gx = (a.n_win_total + 4 * a.wpw - 1) / (4 * a.wpw);
     if (csum_rows_needed) *csum_rows_needed = a.gx * 4;
     a.csum = (backward && csum && csum_rows >= (long)a.gx * 4) ? csum : nullptr;

@@ -31,7 +31,7 @@ for s in range(4):
         tf = timeit(lambda: ops.swin_attn_fwd(desc, qkv, bias_t))
         ctx = ops.swin_attn_fwd(desc, qkv, bias_t)
         dctx = torch.randn_like(ctx)
-        dbias = torch.zeros_like(bias_t)
+        dbias = None if os.environ.get("SAB_NODBIAS") else torch.zeros_like(bias_t)      # SAB_NODBIAS=1: what the dbias tail of the backward costs
         tb = timeit(lambda: ops.swin_attn_bwd(desc, qkv, bias_t, ctx, dctx, dbias))
         bf, bb = M * 4 * C * 2, M * 7 * C * 2
         print(f"stage {s} C={C:4d} M={M:8d} shift={shift}: fwd {tf:7.1f} us {bf / tf / 1e6:5.2f} TB/s | bwd {tb:7.1f} us {bb / tb / 1e6:5.2f} TB/s", flush=True)
