@@ -64,6 +64,7 @@ _SIGS = {
     "morec_strerror": (C.c_char_p, [C.c_int]),
     "morec_version": (C.c_int, []),
     "morec_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "morec_det_scratch_reserve": (C.c_int, [C.c_size_t, C.c_void_p]),
     "morec_stream_wait_stream": (C.c_int, [_P, _P]),
     "morec_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P]),
     "morec_gemm_nt_colsum": (C.c_int, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -154,7 +155,15 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
         _lib = h
+        # ONE parser for the deterministic switch: the Python decision (env_flag) is pushed into the library at load, so a value the
+        # two sides would read differently ("true", "yes": C's atoi gives 0) cannot leave the engines and the kernels in different modes
+        h.morec_tuning_set(b"deterministic", int(env_flag("MOREC_DETERMINISTIC")))
     return _lib
+
+
+def env_flag(name: str) -> bool:
+    """Boolean environment switch: unset / "" / "0" / "false" / "no" / "off" = off, anything else = on."""
+    return os.environ.get(name, "0").strip().lower() not in ("", "0", "false", "no", "off")
 
 
 def check(rc: int, what: str):

@@ -40,23 +40,42 @@ bool morec_deterministic() {
 }
 void morec_set_deterministic(int on) { g_deterministic = on ? 1 : 0; }
 
-float* morec_det_scratch(hipStream_t s, size_t n) {
-    struct Slot { hipStream_t s; int dev; float* p; size_t n; };
+// Library-owned partial-sum scratch of the deterministic mode, one buffer per (device, stream) -- launches on a stream are ordered, so they
+// share it.  nullptr = "not available": the callers return an error (never a silent fall-back to the atomic kernels).  Growth frees and
+// reallocates, which a stream that is being CAPTURED must not do (a graph would keep the freed address): under capture a request the
+// buffer cannot hold is refused -- run the shapes once eagerly (TrainStep does: its warm-up steps precede capture) or call
+// morec_det_scratch_reserve.  Sixteen (device, stream) pairs; beyond that the least recently used buffer is dropped behind a device sync.
+static float* det_scratch_impl(hipStream_t s, size_t n, bool may_grow) {
+    struct Slot { hipStream_t s; int dev; float* p; size_t n; unsigned long long used; };
     static Slot slots[16];
     static int n_slots = 0;
+    static unsigned long long tick = 0;
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool capturing = cap != hipStreamCaptureStatusNone;
     Slot* sl = nullptr;
     for (int i = 0; i < n_slots; ++i)
         if (slots[i].s == s && slots[i].dev == dev) sl = &slots[i];
     if (!sl) {
-        if (n_slots == 16) return nullptr;
-        sl = &slots[n_slots++];
-        *sl = Slot{s, dev, nullptr, 0};
+        if (capturing || !may_grow) return nullptr;
+        if (n_slots < 16) {
+            sl = &slots[n_slots++];
+        } else {      // evict the least recently used pair of THIS device (its stream may be gone: wait for the device, not for the stream)
+            for (int i = 0; i < n_slots; ++i)
+                if (slots[i].dev == dev && (!sl || slots[i].used < sl->used)) sl = &slots[i];
+            if (!sl) return nullptr;
+            (void)hipDeviceSynchronize();
+            if (sl->p) (void)hipFree(sl->p);
+        }
+        *sl = Slot{s, dev, nullptr, 0, 0};
     }
+    sl->used = ++tick;
     if (sl->n < n) {
+        if (capturing || !may_grow) return nullptr;
         if (sl->p) {      // launches that still read the old buffer are on this stream
             (void)hipStreamSynchronize(s);
             (void)hipFree(sl->p);
@@ -68,6 +87,11 @@ float* morec_det_scratch(hipStream_t s, size_t n) {
         sl->n = want;
     }
     return sl->p;
+}
+float* morec_det_scratch(hipStream_t s, size_t n) { return det_scratch_impl(s, n, true); }
+// Pre-size the deterministic mode's scratch of `stream` to `n_floats` (outside graph capture): see include/morec_hip.h.
+extern "C" int morec_det_scratch_reserve(size_t n_floats, void* stream) {
+    return det_scratch_impl(reinterpret_cast<hipStream_t>(stream), n_floats, true) ? MOREC_OK : (int)hipErrorOutOfMemory;
 }
 
 __global__ __launch_bounds__(256) void det_fold_add_kernel(const float* __restrict__ part, float* __restrict__ dst, int n_parts, size_t n, size_t stride) {

@@ -302,16 +302,22 @@ extern "C" int morec_bert_embed_bwd(const int32_t* ids, const void* dz, float* d
     dim3 g3((((M + rpw - 1) / rpw) + 3) / 4);
     const bool sorted = order != nullptr && H <= 1024;
     const int T_ = T;      // (the lambda below names its storage type T)
+    const bool det = morec_deterministic();
+    // deterministic mode has no atomic fall-backs: it needs the token-id order (one writer wave per table row) and a row width the
+    // vector kernel takes; anything else is refused instead of silently summing in arrival order
+    if (det && (order == nullptr || !vec)) return MOREC_E_UNSUPPORTED;
+    int rc_pos = 1;
     if (!by_dtype(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            if (order != nullptr && morec_deterministic())
+            if (det)
                 hipLaunchKernelGGL((word_scatter_runs_kernel<T>), g1, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H);
             else if (sorted) hipLaunchKernelGGL((word_scatter_sorted_kernel<T, 4>), g3, dim3(256), 0, s, ids, order, (const T*)dz, dword, pad_id, M, H, rpw);
             else hipLaunchKernelGGL((word_scatter_kernel<T>), g1, dim3(256), 0, s, ids, (const T*)dz, dword, pad_id, M, H);
-            if (vec) pos_type_grad_launch<T>((const T*)dz, dpos, dtype0, M / T_, T_, H, s);
+            if (vec) rc_pos = pos_type_grad_launch<T>((const T*)dz, dpos, dtype0, M / T_, T_, H, s);
             else hipLaunchKernelGGL((pos_type_grad_scalar_kernel<T>), g2, dim3(256), 0, s, (const T*)dz, dpos, dtype0, M / T_, T_, H, spb);
         }))
         return MOREC_E_DTYPE;
+    if (rc_pos < 0) return (int)hipErrorOutOfMemory;      // deterministic scratch unavailable (e.g. it would have to grow under graph capture)
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

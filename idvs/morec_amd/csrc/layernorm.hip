@@ -486,15 +486,19 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const T* __restrict__ dz,
 extern "C" int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dtype, void* stream) {
     if (!dz || !dpos || M <= 0 || N <= 0 || period <= 0 || M % period) return MOREC_E_ARG;
     const int spb = 64;
-    dim3 grid(period, (M / period + spb - 1) / spb);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // 16-byte column vectors, several rows in flight (pos_grad.hpp); the scalar kernel keeps the row widths that do not fit
+    int rc_pos = 1;
     if (!by_dtype(dtype, [&](auto* t) {
             using T = MOREC_TAG_T(t);
-            if (!pos_type_grad_launch<T>((const T*)dz, dpos, nullptr, M / period, period, N, s))
-                hipLaunchKernelGGL((pos_grad_kernel<T>), grid, dim3(256), 0, s, (const T*)dz, dpos, M, N, period, spb);
+            rc_pos = pos_type_grad_launch<T>((const T*)dz, dpos, nullptr, M / period, period, N, s);
+            if (rc_pos == 0) {      // row width outside the vector layout: the scalar kernel; deterministic mode = ONE block per position (single writer)
+                const int spb_ = morec_deterministic() ? M / period : spb;
+                hipLaunchKernelGGL((pos_grad_kernel<T>), dim3(period, (M / period + spb_ - 1) / spb_), dim3(256), 0, s, (const T*)dz, dpos, M, N, period, spb_);
+            }
         }))
         return MOREC_E_DTYPE;
+    if (rc_pos < 0) return (int)hipErrorOutOfMemory;      // deterministic scratch unavailable (it may not grow under graph capture)
     MOREC_CHECK_LAUNCH();
     return MOREC_OK;
 }

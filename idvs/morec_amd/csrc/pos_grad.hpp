@@ -69,11 +69,12 @@ __global__ __launch_bounds__(256) void pos_type_grad_kernel(const T* __restrict_
 #undef PT_POSITION
 }
 
-// false: the row width does not fit the one-vector-per-thread layout (the callers keep a scalar kernel for that)
+// 0: the row width does not fit the one-vector-per-thread layout (the callers keep a scalar kernel for that); 1: launched; -1: the
+// deterministic mode's scratch is not available (callers return an error: never a silent fall-back to the atomic kernel)
 template <typename T>
-inline bool pos_type_grad_launch(const T* dz, float* dpos, float* dtype0, int nseq, int Tlen, int H, hipStream_t s) {
+inline int pos_type_grad_launch(const T* dz, float* dpos, float* dtype0, int nseq, int Tlen, int H, hipStream_t s) {
     constexpr int EV = vio<T>::EV;
-    if (H % EV || H / EV > 256) return false;
+    if (H % EV || H / EV > 256) return 0;
     const int grp = 256 / (H / EV);
     const int seq_blocks = (nseq + 4 * grp - 1) / (4 * grp);
     int t_chunks = 512 / seq_blocks;
@@ -83,15 +84,14 @@ inline bool pos_type_grad_launch(const T* dz, float* dpos, float* dtype0, int ns
     if (morec_deterministic()) {      // per-block partial rows [seq_blocks][Tlen][H] (+ [seq_blocks * ty_blocks][H] for the type row), folded in block order
         const size_t n_pos = (size_t)seq_blocks * Tlen * H, n_ty = dtype0 ? (size_t)seq_blocks * ty_blocks * H : 0;
         float* part = morec_det_scratch(s, n_pos + n_ty);
-        if (part) {
-            hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, ty_blocks), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
-                               part, dtype0 ? part + n_pos : nullptr, nseq, Tlen, H, tpb, 1);
-            (void)morec_det_fold_add(part, dpos, seq_blocks, (size_t)Tlen * H, (size_t)Tlen * H, s);
-            if (dtype0) (void)morec_det_fold_add(part + n_pos, dtype0, seq_blocks * ty_blocks, (size_t)H, (size_t)H, s);
-            return true;
-        }
+        if (!part) return -1;
+        hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, ty_blocks), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
+                           part, dtype0 ? part + n_pos : nullptr, nseq, Tlen, H, tpb, 1);
+        (void)morec_det_fold_add(part, dpos, seq_blocks, (size_t)Tlen * H, (size_t)Tlen * H, s);
+        if (dtype0) (void)morec_det_fold_add(part + n_pos, dtype0, seq_blocks * ty_blocks, (size_t)H, (size_t)H, s);
+        return 1;
     }
     hipLaunchKernelGGL((pos_type_grad_kernel<T>), dim3(seq_blocks, ty_blocks), dim3(256), (size_t)grp * H * sizeof(float), s, dz,
                        dpos, dtype0, nseq, Tlen, H, tpb);
-    return true;
+    return 1;
 }

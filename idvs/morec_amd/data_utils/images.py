@@ -211,6 +211,7 @@ class DeviceImageFeed:
         t = slot[key]
         if t is None or t.numel() < need or t.dtype != dtype:
             t = slot[key] = torch.empty(need + need // 8, device=self.dev, dtype=dtype)
+            slot["fresh"] = True      # a block the step stream's allocator may just have recycled: see submit()
         return t[:need].view(*shape)
 
     def submit(self, flat, meta, tabs=None):
@@ -228,8 +229,12 @@ class DeviceImageFeed:
         src = None if tabs is None else self._buf(slot, "src", (int(flat.numel()),), torch.uint8)
         if slot["free"] is not None:      # the step that read this set last must be done with it
             self.stream.wait_event(slot["free"])
-        else:
-            self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # (first use: the allocations above)
+        if slot["free"] is None or slot.pop("fresh", False):
+            # first use, or a buffer that has just been (re)allocated from the STEP stream's pool (a later batch outgrew it): the block may
+            # be one that kernels still queued on the step stream are reading -- stream-ordered reuse only holds on that stream -- so the
+            # feed waits for everything the step stream has queued so far, not only for the set's last reader
+            self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        slot.pop("fresh", None)
         with torch.cuda.stream(self.stream):
             if tabs is None:
                 imgs.copy_(flat, non_blocking=True)

@@ -23,7 +23,9 @@ def save_model(now_epoch, model, model_dir, optimizer, rng_state, cuda_rng_state
                 "optimizer": (optimizer.optimizer_state_dict() if hasattr(optimizer, "optimizer_state_dict") else optimizer.state_dict())
                 if optimizer is not None else None,
                 "rng_state": rng_state, "cuda_rng_state": cuda_rng_state,
-                "scaler_state": scaler.state_dict() if scaler is not None else {}}, ckpt_path)
+                # torch.cuda.amp.GradScaler (state_dict) or train_step.TrainStep (scaler_state_dict: its device-side loss-scale block)
+                "scaler_state": ({} if scaler is None else scaler.scaler_state_dict() if hasattr(scaler, "scaler_state_dict")
+                                 else scaler.state_dict())}, ckpt_path)
     if Log_file is not None:
         Log_file.info(f"Model saved to {ckpt_path}")
     return ckpt_path

@@ -661,7 +661,7 @@ def bert_backward(p: dict, prep, saved, d_item: torch.Tensor, grads: dict, prefi
                                 grads[bm + "embeddings.LayerNorm.weight"], grads[bm + "embeddings.LayerNorm.bias"],
                                 p_out=drop.p_hidden, seed_out=drop.site(0), sub16=False)
     if order is None:      # integer bookkeeping: rows in token-id order for the run-length scatter (the collate can supply it: token_packing_host)
-        order = torch.argsort(ids32).to(torch.int32)
+        order = torch.argsort(ids32, stable=ops.DETERMINISTIC).to(torch.int32)      # (stable: the fixed summation order of word_scatter_runs_kernel)
     ops.bert_embed_bwd_(ids32, dz_e, grads[bm + "embeddings.word_embeddings.weight"],
                         grads[bm + "embeddings.position_embeddings.weight"],
                         grads[bm + "embeddings.token_type_embeddings.weight"][0], pad_id, T, order)

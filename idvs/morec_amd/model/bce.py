@@ -7,7 +7,7 @@ from torch import nn
 from torch.nn.init import xavier_normal_
 
 from .. import ops
-from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, resolve_dtype, resolve_fp32_gemm
+from .encoders import Bert_Encoder, IdEmbedding, User_Encoder, resolve_dtype, resolve_fp32_gemm, resolve_res32
 
 
 class BceLossFn(torch.autograd.Function):
@@ -42,7 +42,7 @@ class BceModel(nn.Module):
         self.fp32_gemm = resolve_fp32_gemm(args)          # "exact" | "bf16x3": how fp32 GEMMs run for this model (ops.FP32_GEMM)
         self.user_encoder = User_Encoder(item_num=item_num, max_seq_len=args.max_seq_len, item_dim=args.embedding_dim,
                                          num_attention_heads=args.num_attention_heads, dropout=args.drop_rate,
-                                         n_layers=args.transformer_block, compute_dtype=self.compute_dtype)
+                                         n_layers=args.transformer_block, compute_dtype=self.compute_dtype, res32=resolve_res32(args))
         if self.use_modal:
             self.bert_encoder = Bert_Encoder(args=args, bert_model=bert_model)
         else:

@@ -19,7 +19,7 @@ FLT_MIN_MASK = -3.4028234663852886e38  # torch.finfo(torch.float32).min: HF eage
 # fp32 atomics (LayerNorm / bias column sums, the embedding-table scatters) fold per-block partials in a fixed order instead, and the
 # engines keep the split-K of the exact-fp32 weight-gradient GEMMs at one -- two runs of the same step give the same bits.  The
 # reference sets torch's deterministic flags (``T/run.py:313-314``).  Covers the text / ID towers; see DESIGN.md §3.
-DETERMINISTIC = os.environ.get("MOREC_DETERMINISTIC", "0") not in ("", "0")
+DETERMINISTIC = _lib.env_flag("MOREC_DETERMINISTIC")      # the library is told the same at load (_lib.lib)
 
 
 def set_deterministic(on: bool = True):

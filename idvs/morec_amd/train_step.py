@@ -728,13 +728,20 @@ class TrainStep:
             return {}
         h = self.sp.host()
         return {"scale": float(h.loss_scale), "growth_factor": self.sp.growth_factor, "backoff_factor": self.sp.backoff_factor,
-                "growth_interval": self.sp.growth_interval, "_growth_tracker": int(h.growth_tracker)}
+                "growth_interval": self.sp.growth_interval, "_growth_tracker": int(h.growth_tracker), "dynamic": bool(self.sp.dynamic)}
 
     def load_scaler_state_dict(self, sd):
         """Counterpart of ``scaler_state_dict`` (``GradScaler.load_state_dict``): the loss scale and the count of clean steps since its
         last change go back into the device block, so a resumed fp16 run does not restart at 65536 and skip its first steps.  An empty
         dict (a checkpoint of the reference, which never saves its scaler) leaves the block as it is."""
         if self.sp is None or not sd:
+            return
+        if not self.sp.dynamic or not sd.get("dynamic", True):
+            # a scale saved by a static block (bf16 / fp32 step: 1.0) says nothing about fp16 overflow, and a static block has no use for a
+            # dynamic run's scale: keep this run's own
+            import warnings
+            warnings.warn("load_scaler_state_dict: the checkpoint's loss scale comes from a different loss-scaling mode "
+                          f"(saved dynamic={sd.get('dynamic', True)}, this step dynamic={self.sp.dynamic}); ignored")
             return
         self.flush()
         scale = float(sd["scale"])
@@ -746,10 +753,6 @@ class TrainStep:
         self.sp.growth_factor = float(sd.get("growth_factor", self.sp.growth_factor))
         self.sp.backoff_factor = float(sd.get("backoff_factor", self.sp.backoff_factor))
         self.sp.growth_interval = int(sd.get("growth_interval", self.sp.growth_interval))
-
-    def state_dict(self):
-        """``GradScaler.state_dict()`` spelling of ``scaler_state_dict`` (what ``data_utils.utils.save_model(scaler=...)`` calls)."""
-        return self.scaler_state_dict()
 
     def global_loss(self, loss):
         """With pooled negatives ``step`` returns THIS rank's share ``loss_sum_local / n_valid_global`` (the shares add up to

@@ -35,7 +35,11 @@
  *   2. with "gemm8p_tail_split" = 1 only: one device scratch allocation per stream (the only memory the library ever allocates);
  *   3. morec_comm handles (below): created and destroyed by the caller;
  *   4. the dropout seed source (morec_dropout_seed_source): one device pointer, NULL by default;
- *   5. the ring of 256 events behind morec_stream_wait_stream (created on first use, never destroyed).
+ *   5. the ring of 256 events behind morec_stream_wait_stream (created on first use, never destroyed);
+ *   6. deterministic mode only (morec_tuning_set("deterministic", 1) / MOREC_DETERMINISTIC=1; the reference sets torch's
+ *      deterministic flags, T/run.py:313-314): one partial-sum scratch per (device, stream), grown on demand OUTSIDE graph capture
+ *      (morec_det_scratch_reserve).  In this mode no kernel falls back to atomics: a call that cannot run its fixed-order form
+ *      (scratch unavailable, no token order, row width outside the vector layout) returns an error instead.
  */
 #ifndef MOREC_HIP_H
 #define MOREC_HIP_H
@@ -75,9 +79,14 @@ int morec_version(void);
  *                        N <= 768, K <= 192, GELU(product + bias); M >= 8192) -- morec_mlp_dact_recompute_supported() then answers 0;
  *   "ce8p"               scoring kernels: 0 = automatic, 1 = always the 128 x 128 kernels, 2 = the 256 x 256 eight-phase kernels
  *                        wherever the shape rules allow (bf16, D > 64, D % 8 == Nc % 8 == (B S) % 8 == 0);
+ *   "deterministic"      1 = fixed summation order everywhere (state item 6), 0 = off; overrides MOREC_DETERMINISTIC;
  *   "gemm8p_debug", "gemm8p_stamps_lo/hi"  ablation bits / device address of a cycle-stamp buffer (diagnostics).
  * Returns MOREC_E_UNSUPPORTED for an unknown key.  No reference counterpart (the reference has no kernels). */
 int morec_tuning_set(const char* key, int value);
+/* Deterministic mode: make the partial-sum scratch of `stream` hold at least n_floats (call outside graph capture; under capture the
+ * scratch cannot grow and a launch that needs more returns hipErrorOutOfMemory).  The largest user of the encoder step is the LayerNorm
+ * backward: blocks x 3 x N floats.  No reference counterpart (torch.use_deterministic_algorithms, T/run.py:313-314, has no workspace API). */
+int morec_det_scratch_reserve(size_t n_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  C[M,N] (+)= alpha * A[M,K] . B[N,K]^T  (both operands K-contiguous, "NT")

@@ -76,6 +76,41 @@ def test_g17_modal_eval_golden(golden_dir):
         assert abs(hit10 - float(g["hit10"])) < 1e-6
 
 
+def test_encode_all_items_second_pass_allocates_nothing():
+    """``get_item_embeddings`` (``T/data_utils/metrics.py:60-74``) over a catalogue of ragged titles in 16-bit: the chunks are encoded
+    largest first, so (a) the second pass of a process asks the device allocator for NOTHING (the driver of round 5 recorded 2.9 s for a
+    pass whose kernels take 0.28 s: hipMalloc per chunk on a cold allocator) and (b) an item's vector is the same whatever chunk
+    size -- i.e. whatever neighbours and encoding order -- it is computed with (to 16-bit rounding)."""
+    from idvs.morec_amd.data_utils import get_item_embeddings
+    from idvs.morec_amd.model import BertShape, HipBertModel, Model
+    T, item_num, D = 30, 1500, 64
+    shape = BertShape.named("micro")
+    args = types.SimpleNamespace(max_seq_len=8, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                 num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
+                                 bert_model_load="bert_micro", word_embedding_dim=shape.hidden_size, compute_dtype="fp16", num_workers=0)
+    torch.manual_seed(5)
+    m = Model(args, item_num, True, HipBertModel(shape), np.full(item_num + 1, 1.0 / item_num)).to(DEV)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3, T + 1, size=item_num + 1)
+    lens[0] = 0
+    lens[1000:1256] = T          # one chunk far heavier than the first ones
+    ids = rng.integers(5, shape.vocab_size, size=(item_num + 1, T))
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.int64)
+    content = np.concatenate([ids * mask, mask], 1)
+    emb = get_item_embeddings(m, content, 256, args, True, DEV)
+    torch.cuda.synchronize()
+    n0 = torch.cuda.memory_stats(DEV)["num_device_alloc"]
+    emb2 = get_item_embeddings(m, content, 256, args, True, DEV)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats(DEV)["num_device_alloc"] == n0, "the second encode pass went to hipMalloc"
+    assert torch.equal(emb, emb2)
+    emb3 = get_item_embeddings(m, content, 100, args, True, DEV)      # other chunks, other order
+    # (row 0: the all-[PAD] item, masked everywhere; another chunk size may select another GEMM kernel, i.e. another fp32 summation order:
+    # equal to 16-bit rounding, and any misplaced row would be off by O(1))
+    assert float((emb[1:] - emb3[1:]).abs().max()) < 1e-2 * float(emb[1:].abs().max())
+    assert emb.shape == (item_num + 1, D) and emb.dtype == torch.float32 and bool(torch.isfinite(emb[1:]).all())
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_run_driver_id_tower_learns(fused):
     """A few dozen steps of the driver on synthetic data: the loss must fall (both optimisation paths)."""
