@@ -87,6 +87,8 @@ _SIGS = {
                                       C.c_uint64, C.c_float, C.c_uint64, _P, _P, C.c_int, _P]),
     "morec_layernorm_fwd_res32": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_float, _P, _P, _P, _P, _P, C.c_int, C.c_int,
                                             C.c_int, C.c_float, C.c_uint64, C.c_float, C.c_uint64, _P]),
+    "morec_layernorm_fwd_res32_pre": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int,
+                                                C.c_float, C.c_uint64, _P]),
     "morec_layernorm_bwd_res32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.c_uint64, C.c_float, C.c_uint64, _P]),
     "morec_pos_grad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -34,18 +34,25 @@ __device__ __forceinline__ void store_f32x8(float* p, const float (&o)[8]) {
     *reinterpret_cast<float4*>(p + 4) = make_float4(o[4], o[5], o[6], o[7]);
 }
 
+// The residual stream in PRE-LayerNorm form: `res` holds the previous LayerNorm's input z, and the stream value is LN(z) = (z - mean[row]) *
+// rstd[row] * gamma + beta, recomputed here (a few FMAs per element under a memory-bound kernel) instead of having been written by that
+// LayerNorm and read back: 4 of the 16 bytes per element the forward moves.  mean == nullptr: `res` is the stream itself.
+struct ResLN { const float* mean; const float* rstd; const float* gamma; const float* beta; };
+
 template <typename T16, int VPL, int LPR, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_res32_kernel(const T16* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ res,
                                                            const float* __restrict__ pos, int pos_period, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ z_out,
                                                            float* __restrict__ y32, T16* __restrict__ y16, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out, int M, int N, DropRng din, DropRng dout) {
+                                                           float* __restrict__ rstd_out, int M, int N, DropRng din, DropRng dout, const ResLN rl) {
     din = drop_resolve(din);
     dout = drop_resolve(dout);
     constexpr int GRP = 64 / LPR;
     const int lane = threadIdx.x & (LPR - 1);
     const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GRP + ((threadIdx.x & 63) / LPR);
     if (row >= M) return;
+    float rl_mu = 0.f, rl_rs = 0.f;
+    if (rl.mean) { rl_mu = rl.mean[row]; rl_rs = rl.rstd[row]; }
     const size_t base = (size_t)row * N;
     // every row-sized load first, from clamped (unguarded) addresses: one memory round trip per row (see layernorm.hip)
     uint4 rx[VPL];
@@ -84,6 +91,13 @@ __global__ __launch_bounds__(256) void ln_fwd_res32_kernel(const T16* __restrict
                 for (int k = 0; k < EV; ++k) v[i][k] = kp[k] ? v[i][k] : 0.f;
             }
             if (res) {
+                if (rl.mean) {      // the residual is handed over as the PREVIOUS LayerNorm's input: its output, recomputed (morec_layernorm_fwd_res32_pre)
+                    float pg[EV], pb[EV];
+                    load_f32v<EV>(rl.gamma + c, pg);
+                    load_f32v<EV>(rl.beta + c, pb);
+#pragma unroll
+                    for (int k = 0; k < EV; ++k) rr[i][k] = (rr[i][k] - rl_mu) * rl_rs * pg[k] + pb[k];
+                }
 #pragma unroll
                 for (int k = 0; k < EV; ++k) v[i][k] += rr[i][k];
             }
@@ -335,11 +349,12 @@ int bwd_launch(const void* dy16, const float* dy32, const float* z, const float*
 
 template <typename T16>
 int fwd_dispatch(const void* x, const float* bias, const float* res, const float* pos, int pos_period, const float* gamma, const float* beta, float eps,
-                 float* z_out, float* y32, void* y16, float* mean, float* rstd, int M, int N, DropRng din, DropRng dout, hipStream_t s) {
+                 float* z_out, float* y32, void* y16, float* mean, float* rstd, int M, int N, DropRng din, DropRng dout, hipStream_t s,
+                 const ResLN rl = ResLN{nullptr, nullptr, nullptr, nullptr}) {
     const int vpl = (N + 64 * EV - 1) / (64 * EV);
 #define LNF(V, L, F)                                                                                                                             \
     hipLaunchKernelGGL((ln_fwd_res32_kernel<T16, V, L, F>), dim3((M + 4 * (64 / L) - 1) / (4 * (64 / L))), dim3(256), 0, s, (const T16*)x, bias, res, pos, \
-                       pos_period, gamma, beta, eps, z_out, y32, (T16*)y16, mean, rstd, M, N, din, dout)
+                       pos_period, gamma, beta, eps, z_out, y32, (T16*)y16, mean, rstd, M, N, din, dout, rl)
     if (N <= 16 * EV) LNF(1, 16, false);
     else if (N <= 32 * EV) LNF(1, 32, false);
     else if (N == 96 * EV) LNF(3, 32, true);      // H = 768: 32 lanes x 3 vectors, two rows per wave, no bounds checks
@@ -384,6 +399,21 @@ extern "C" int morec_layernorm_fwd_res32(const void* x16, const float* bias, con
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype16 == MOREC_BF16) return fwd_dispatch<bf16>(x16, bias, res32, pos, pos_period, gamma, beta, eps, z32, y32, y16, mean, rstd, M, N, din, dout, s);
     if (dtype16 == MOREC_F16) return fwd_dispatch<f16>(x16, bias, res32, pos, pos_period, gamma, beta, eps, z32, y32, y16, mean, rstd, M, N, din, dout, s);
+    return MOREC_E_DTYPE;
+}
+
+extern "C" int morec_layernorm_fwd_res32_pre(const void* x16, const float* bias, const float* res_z32, const float* res_mean, const float* res_rstd,
+                                             const float* res_gamma, const float* res_beta, const float* gamma, const float* beta, float eps, float* z32,
+                                             void* y16, float* mean, float* rstd, int M, int N, int dtype16, float p_in, uint64_t seed_in, void* stream) {
+    if (!x16 || !res_z32 || !res_mean || !res_rstd || !res_gamma || !res_beta || !gamma || !beta || !y16 || M <= 0 || N <= 0) return MOREC_E_ARG;
+    if (p_in < 0.f || p_in >= 1.f) return MOREC_E_ARG;
+    if (N % EV) return MOREC_E_ALIGN;
+    if (!aligned16(x16) || !aligned16(res_z32) || (z32 && !aligned16(z32)) || !aligned16(y16) || !aligned16(res_gamma) || !aligned16(res_beta)) return MOREC_E_ALIGN;
+    const DropRng din = make_drop(p_in, seed_in), dout = make_drop(0.f, 0);
+    const ResLN rl{res_mean, res_rstd, res_gamma, res_beta};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype16 == MOREC_BF16) return fwd_dispatch<bf16>(x16, bias, res_z32, nullptr, 0, gamma, beta, eps, z32, nullptr, y16, mean, rstd, M, N, din, dout, s, rl);
+    if (dtype16 == MOREC_F16) return fwd_dispatch<f16>(x16, bias, res_z32, nullptr, 0, gamma, beta, eps, z32, nullptr, y16, mean, rstd, M, N, din, dout, s, rl);
     return MOREC_E_DTYPE;
 }
 

@@ -179,6 +179,12 @@ def linear_wgrad_(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dyt=None,
 # ---------------------------------------------------------------------------------------------------------
 # one transformer layer
 # ---------------------------------------------------------------------------------------------------------
+# res32 modes: the fp32 residual stream between the LayerNorms of the encoder layers is handed on as ``ops.PreLN`` (the previous LayerNorm's
+# saved input + statistics) and recomputed by its one reader instead of being written and read back: the forward LayerNorm moves 12 instead
+# of 16 bytes per element.  MOREC_RES32_LAZY=0 keeps the written stream (A/B, tests).
+RES32_LAZY = os.environ.get("MOREC_RES32_LAZY", "1") != "0"
+
+
 def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tensor, n_seq: int, need_grad: bool,
                   drop: DropCfg = NO_DROP, site0: int = 0, cu=None):
     """w keys: qkv (PreparedLinear [3H,H]), bqkv, o, bo, ln1_g, ln1_b, f1, b1, f2, b2, ln2_g, ln2_b.
@@ -196,7 +202,9 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     a = ops.gemm_nt(ctx, w["o"].w)
     if cfg.res32:
-        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0r, p_in=ph, seed_in=s1)
+        # (the stream between the LayerNorms of the encoder layers travels as ops.PreLN: never written, recomputed by its one reader)
+        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0r, p_in=ph, seed_in=s1,
+                                                            lazy_out=RES32_LAZY)
     else:
         x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0, z_inplace=True,
                                                  p_in=ph, seed_in=s1)
@@ -204,7 +212,8 @@ def layer_forward(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.Tens
     g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
     if cfg.res32:
-        x2, x2r, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2)
+        x2, x2r, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2,
+                                                            lazy_out=RES32_LAZY)
     else:
         x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
                                                  p_in=ph, seed_in=s2)
@@ -268,10 +277,14 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     qkv = ops.gemm_nt(x0, w["qkv"].w, bias=w["bqkv"])
     ctx = ops.attn_fwd(desc, qkv, key_keep)
     ctx_c = gather_cls(ctx, n_seq, T, cu)
-    x0_c = gather_cls(x0r if cfg.res32 else x0, n_seq, T, cu)      # the residual rows (res32: from the fp32 stream)
+    if cfg.res32 and isinstance(x0r, ops.PreLN):      # the residual rows of a stream that exists as the previous LayerNorm's input only
+        x0_c = x0r.rows(idx=cu[:-1]) if cu is not None else x0r.rows(stride=T, n=n_seq)
+    else:
+        x0_c = gather_cls(x0r if cfg.res32 else x0, n_seq, T, cu)      # the residual rows (res32: from the fp32 stream)
     a = ops.gemm_nt(ctx_c, w["o"].w)
     if cfg.res32:
-        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, p_in=ph, seed_in=s1)
+        x1, x1r, z1, mean1, rstd1 = ops.layernorm_fwd_res32(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, p_in=ph, seed_in=s1,
+                                                            lazy_out=RES32_LAZY)
     else:
         x1, z1, mean1, rstd1 = ops.layernorm_fwd(a, w["ln1_g"], w["ln1_b"], cfg.eps, bias=w["bo"], res=x0_c, z_inplace=True,
                                                  p_in=ph, seed_in=s1)
@@ -279,7 +292,8 @@ def layer_forward_cls(cfg: LayerCfg, w: dict, x0: torch.Tensor, key_keep: torch.
     g = ops.gemm_nt(x1, w["f1"].w, bias=w["b1"], act=cfg.act, aux_out=u, aux_deriv=need_grad)      # u = act'(pre-activation)
     f = ops.gemm_nt(g, w["f2"].w)
     if cfg.res32:      # (the [CLS] vectors feed the projection head's GEMM: only the 16-bit copy is consumed)
-        x2, _, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2)
+        x2, _, z2, mean2, rstd2 = ops.layernorm_fwd_res32(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1r, p_in=ph, seed_in=s2,
+                                                          lazy_out=RES32_LAZY)
     else:
         x2, z2, mean2, rstd2 = ops.layernorm_fwd(f, w["ln2_g"], w["ln2_b"], cfg.eps, bias=w["b2"], res=x1, z_inplace=True,
                                                  p_in=ph, seed_in=s2)

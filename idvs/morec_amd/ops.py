@@ -333,21 +333,54 @@ def layernorm_fwd(x, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_per
     return y, (z if need_z else x), mean, rstd
 
 
-def layernorm_fwd_res32(x16, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0):
+class PreLN:
+    """The fp32 residual stream in PRE-LayerNorm form: the stream value is ``LN(z) = (z - mean[m]) * rstd[m] * gamma + beta`` of tensors a
+    LayerNorm call has saved anyway; the consumer (the next ``layernorm_fwd_res32``) recomputes it in registers, so the stream itself is never
+    written or read back (``morec_layernorm_fwd_res32_pre``)."""
+    __slots__ = ("z", "mean", "rstd", "gamma", "beta")
+
+    def __init__(self, z, mean, rstd, gamma, beta):
+        self.z, self.mean, self.rstd, self.gamma, self.beta = z, mean, rstd, gamma, beta
+
+    def rows(self, idx=None, stride=None, n=None):
+        """The same stream restricted to rows ``idx`` (int tensor) or ``0, stride, 2 stride, ...`` (``n`` rows)."""
+        if idx is not None:
+            i = idx.long()
+            return PreLN(self.z.index_select(0, i), self.mean.index_select(0, i), self.rstd.index_select(0, i), self.gamma, self.beta)
+        N = self.z.shape[1]
+        return PreLN(self.z.view(n, stride, N)[:, 0].contiguous(), self.mean.view(n, stride)[:, 0].contiguous(),
+                     self.rstd.view(n, stride)[:, 0].contiguous(), self.gamma, self.beta)
+
+    def materialize(self):
+        return ((self.z - self.mean[:, None]) * self.rstd[:, None]) * self.gamma[None, :] + self.beta[None, :]
+
+
+def layernorm_fwd_res32(x16, gamma, beta, eps, *, bias=None, res=None, pos=None, pos_period=0, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0,
+                        lazy_out=False):
     """LayerNorm of the autocast data flow (``morec_layernorm_fwd_res32``; ``*_res32`` compute modes): ``x16`` is the 16-bit output of the
-    sub-layer's GEMM, ``res`` the fp32 residual stream.  Returns (y16, y32, z32, mean, rstd): the next GEMM's operand, the fp32 residual
-    stream, and what the backward needs."""
+    sub-layer's GEMM, ``res`` the fp32 residual stream (a tensor, or a ``PreLN``).  Returns (y16, y32, z32, mean, rstd): the next GEMM's
+    operand, the fp32 residual stream, and what the backward needs.  ``lazy_out``: the stream is NOT written; ``y32`` is a ``PreLN`` over
+    (z32, mean, rstd, gamma, beta) for the next call to recompute (needs ``p_out == 0``)."""
     _dev(x16)
     M, N = x16.shape
     z = torch.empty((M, N), device=x16.device, dtype=torch.float32)
-    y32 = torch.empty((M, N), device=x16.device, dtype=torch.float32)
     y16 = torch.empty_like(x16)
     mean = torch.empty(M, device=x16.device, dtype=torch.float32)
     rstd = torch.empty(M, device=x16.device, dtype=torch.float32)
+    if lazy_out and p_out > 0:
+        raise ValueError("layernorm_fwd_res32(lazy_out=True) cannot carry an output dropout")
+    if isinstance(res, PreLN):
+        if not lazy_out or pos is not None or p_out > 0:
+            raise ValueError("a PreLN residual needs lazy_out=True, no pos, no output dropout")
+        check(_lib.lib().morec_layernorm_fwd_res32_pre(_p(x16), _p(bias), _p(res.z), _p(res.mean), _p(res.rstd), _p(res.gamma), _p(res.beta),
+                                                       _p(gamma), _p(beta), eps, _p(z), _p(y16), _p(mean), _p(rstd), M, N, code(x16.dtype),
+                                                       p_in, seed_in, _stream()), "morec_layernorm_fwd_res32_pre")
+        return y16, PreLN(z, mean, rstd, gamma, beta), z, mean, rstd
+    y32 = None if lazy_out else torch.empty((M, N), device=x16.device, dtype=torch.float32)
     check(_lib.lib().morec_layernorm_fwd_res32(_p(x16), _p(bias), _p(res), _p(pos), pos_period, _p(gamma), _p(beta), eps, _p(z), _p(y32), _p(y16),
                                                _p(mean), _p(rstd), M, N, code(x16.dtype), p_in, seed_in, p_out, seed_out, _stream()),
           "morec_layernorm_fwd_res32")
-    return y16, y32, z, mean, rstd
+    return y16, (PreLN(z, mean, rstd, gamma, beta) if lazy_out else y32), z, mean, rstd
 
 
 def layernorm_bwd_res32(dy16, dy32, z, mean, rstd, gamma, dgamma, dbeta, dtype16, p_in=0.0, seed_in=0, p_out=0.0, seed_out=0, dbias=None, sub16=True):

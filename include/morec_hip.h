@@ -226,6 +226,13 @@ int morec_layernorm_bwd(const void* dy_a, const void* dy_b, const void* z, const
 int morec_layernorm_fwd_res32(const void* x16, const float* bias, const float* res32, const float* pos, int pos_period, const float* gamma,
                               const float* beta, float eps, float* z32, float* y32, void* y16, float* mean, float* rstd, int M, int N,
                               int dtype16, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);
+/* The same forward with the residual stream handed over in PRE-LayerNorm form: res_z32 is the z32 the PREVIOUS LayerNorm saved, and the stream
+ * value is (res_z32 - res_mean[m]) * res_rstd[m] * res_gamma + res_beta, recomputed in registers -- the previous call then passes y32 = NULL and
+ * never writes the stream (12 instead of 16 bytes per element and call; same numbers as reading y32 back up to fp32 contraction).  No pos, no
+ * output dropout (the LayerNorms inside an encoder layer have neither: HF BertSelfOutput / BertOutput, T/model/modules.py:17,63). */
+int morec_layernorm_fwd_res32_pre(const void* x16, const float* bias, const float* res_z32, const float* res_mean, const float* res_rstd,
+                                  const float* res_gamma, const float* res_beta, const float* gamma, const float* beta, float eps, float* z32,
+                                  void* y16, float* mean, float* rstd, int M, int N, int dtype16, float p_in, uint64_t seed_in, void* stream);
 int morec_layernorm_bwd_res32(const void* dy16, const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
                               float* dz32, void* dzd16, float* dgamma, float* dbeta, float* dbias, int M, int N, int dtype16, float p_in,
                               uint64_t seed_in, float p_out, uint64_t seed_out, void* stream);

@@ -101,3 +101,42 @@ def test_position_rows_and_dropout_streams():
     dz32, dzd16 = ops.layernorm_bwd(dy16, None, z32, mean, rstd, gamma, None, None, p_in=p, seed_in=seed2, dbias=dbias)
     assert float((dzd16.float() - (dz32 * keep2 * inv).to(dt).float()).abs().max()) == 0.0
     assert float((dbias - dzd16.float().sum(0)).abs().max()) < 2e-4 * max(1.0, float(dzd16.float().sum(0).abs().max()))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(300, 768), (257, 512), (100, 64), (64, 1024)])
+def test_residual_in_pre_layernorm_form_equals_the_written_stream(M, N, dt):
+    """``morec_layernorm_fwd_res32_pre``: a chain of two LayerNorms where the stream between them is never written (``ops.PreLN``: the first
+    call's z32 / mean / rstd / gamma / beta, recomputed by the second) gives what the chain over the written fp32 stream gives, with a
+    dropout on the second sub-layer's output; row subsets (the [CLS]-only last layer) too."""
+    from idvs.morec_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + 7 * N)
+    xa = (torch.randn(M, N, generator=g) * 0.7).to(dt).to(DEV)
+    xb = (torch.randn(M, N, generator=g) * 0.7).to(dt).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ba, bb = ((torch.randn(N, generator=g) * 0.1).to(DEV) for _ in range(2))
+    ga, gb = ((1.0 + 0.2 * torch.randn(N, generator=g)).to(DEV) for _ in range(2))
+    be_a, be_b = ((0.1 * torch.randn(N, generator=g)).to(DEV) for _ in range(2))
+    eps, p, seed = 1e-12, 0.1, 0xabcdef
+    # written stream
+    y16a, y32a, z32a, ma, ra = ops.layernorm_fwd_res32(xa, ga, be_a, eps, bias=ba, res=res)
+    y16b, y32b, z32b, mb, rb = ops.layernorm_fwd_res32(xb, gb, be_b, eps, bias=bb, res=y32a, p_in=p, seed_in=seed)
+    # the same chain, stream in pre-LayerNorm form
+    l16a, lazy_a, lz32a, lma, lra = ops.layernorm_fwd_res32(xa, ga, be_a, eps, bias=ba, res=res, lazy_out=True)
+    assert isinstance(lazy_a, ops.PreLN) and torch.equal(l16a, y16a) and torch.equal(lz32a, z32a) and torch.equal(lma, ma) and torch.equal(lra, ra)
+    assert float((lazy_a.materialize() - y32a).abs().max()) < 2e-6 * max(1.0, float(y32a.abs().max()))
+    l16b, lazy_b, lz32b, lmb, lrb = ops.layernorm_fwd_res32(xb, gb, be_b, eps, bias=bb, res=lazy_a, p_in=p, seed_in=seed, lazy_out=True)
+    assert isinstance(lazy_b, ops.PreLN)
+    tol = 2e-6 * max(1.0, float(z32b.abs().max()))
+    assert float((lz32b - z32b).abs().max()) < tol                      # (fp32 contraction of the recomputed stream value at most)
+    assert float((lmb - mb).abs().max()) < tol and float((lrb / rb - 1).abs().max()) < 1e-5
+    assert float((l16b.float() - y16b.float()).abs().max()) <= float(y16b.float().abs().max()) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
+    assert float((l16b != y16b).float().mean()) < 2e-3                  # a last-bit difference may cross a 16-bit rounding boundary
+    # row subset: every third row of the stream
+    idx = torch.arange(0, M, 3, device=DEV, dtype=torch.int32)
+    sub = lazy_a.rows(idx=idx)
+    s16, _, sz, _, _ = ops.layernorm_fwd_res32(xb[idx.long()].contiguous(), gb, be_b, eps, bias=bb, res=sub, lazy_out=True)
+    e16, _, ez, _, _ = ops.layernorm_fwd_res32(xb[idx.long()].contiguous(), gb, be_b, eps, bias=bb, res=y32a[idx.long()].contiguous())
+    assert float((sz - ez).abs().max()) < tol
+    with pytest.raises(ValueError):
+        ops.layernorm_fwd_res32(xb, gb, be_b, eps, bias=bb, res=lazy_a)      # a PreLN residual cannot feed a call that has to write the stream
