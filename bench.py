@@ -124,6 +124,61 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
+class PowerSampler:
+    """Socket power and shader clock of GPU 0 from the amdgpu hwmon files (readable by an ordinary user), sampled every `period` s on a side
+    thread while the `sustained` pass runs: the evidence behind DESIGN.md's "power-limited" reading of the GEMM roofline (a 16-bit MFMA
+    main loop draws the part's whole budget below its 2.4 GHz data-sheet clock, which is the clock the 2.5 PFLOP/s peak assumes)."""
+
+    def __init__(self, period=0.02):
+        import glob
+        self.period, self.rows, self._stop, self._thr = period, [], False, None
+        self.files = {}
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = {k: os.path.join(d, n) for k, names in (("power", ("power1_average", "power1_input")), ("cap", ("power1_cap",)),
+                                                         ("sclk", ("freq1_input",))) for n in names if os.path.exists(os.path.join(d, n))}
+            if "power" in f:
+                self.files = f
+                break
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return float(fh.read().strip())
+        except Exception:  # noqa: BLE001
+            return None
+
+    def __enter__(self):
+        if self.files:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    self.rows.append((self._read(self.files["power"]), self._read(self.files["sclk"]) if "sclk" in self.files else None))
+                    time.sleep(self.period)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+
+    def summary(self):
+        pw = [r[0] for r in self.rows if r[0] is not None]
+        ck = [r[1] for r in self.rows if r[1] is not None]
+        if not pw:
+            return None
+        cap = self._read(self.files["cap"]) if "cap" in self.files else None
+        out = {"avg_w": round(sum(pw) / len(pw) / 1e6, 1), "max_w": round(max(pw) / 1e6, 1), "cap_w": (round(cap / 1e6, 1) if cap else None),
+               "samples": len(pw), "source": os.path.dirname(self.files["power"])}
+        if ck:
+            out["sclk_mhz_avg"] = round(sum(ck) / len(ck) / 1e6, 1)
+            out["sclk_mhz_min"] = round(min(ck) / 1e6, 1)
+        return out
+
+
 def main():
     a = parse()
     if a.cpu_baseline_only:
@@ -561,16 +616,18 @@ def main():
     if not a.no_secondary and world == 1:
         use_graph["v"] = graph_was
         n_sus, t1 = 0, time.perf_counter()
-        while True:
-            for i in range(a.warmup, n_batches):
-                run_step(i)
-            n_sus += a.steps
-            torch.cuda.synchronize()
-            if time.perf_counter() - t1 >= 3.0:
-                break
-        dts = time.perf_counter() - t1
+        with PowerSampler() as psamp:
+            while True:
+                for i in range(a.warmup, n_batches):
+                    run_step(i)
+                n_sus += a.steps
+                torch.cuda.synchronize()
+                if time.perf_counter() - t1 >= 3.0:
+                    break
+            dts = time.perf_counter() - t1
         sustained = {"ms_per_step": round(dts / n_sus * 1e3, 3), "user_seq_per_s": round(a.batch * n_sus / dts, 2), "steps": n_sus,
-                     "seconds": round(dts, 2), "note": "the K batches of the headline region cycled back to back for >= 3 s"}
+                     "seconds": round(dts, 2), "note": "the K batches of the headline region cycled back to back for >= 3 s",
+                     "power": psamp.summary()}
         log(f"sustained: {sustained['ms_per_step']} ms/step over {n_sus} steps")
     use_graph["v"] = False
     # secondary measurement (never `value`): the same steps with distinct-item dedup on, and the duplicate rate of the batches
@@ -719,6 +776,11 @@ def main():
             "measured": f"HIP events around every GEMM launch in an instrumented pass of {n_inst} steps AFTER the headline region (which carries no events); "
                         "single stream in that pass (the headline region overlaps the weight-gradient GEMMs with the dX chain on a second stream: "
                         + ("on" if wgrad_was else "off") + ")"}
+    if sustained is not None and sustained.get("power") and sustained["power"].get("sclk_mhz_avg"):
+        ck = sustained["power"]["sclk_mhz_avg"]
+        roof["at_sustained_clock"] = {"sclk_mhz": ck, "peak": round(peak * ck / 2400.0, 1), "frac": round(tf / (peak * ck / 2400.0), 4),
+                                      "note": "the 2.5 PFLOP/s peak is 256 CUs x 4096 FLOP/clk at 2.4 GHz; under this step's load the part holds its power cap at the "
+                                              "shader clock sampled during `sustained` (hwmon freq1_input), which scales what the matrix cores can issue"}
     ce_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ce_log)
     ce_gbs = sum(b for b, _, _ in ce_log) / (ce_ms * 1e-3) / 1e9 if ce_ms > 0 else 0.0
     # Scoring is MFMA-bound, not HBM-bound: 2 Nr Nc D FLOP per product (1 forward, 3 backward: recompute, dP, dE) over

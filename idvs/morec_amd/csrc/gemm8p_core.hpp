@@ -67,7 +67,9 @@ template <typename T16, int M0, int NQ, bool ZERO, int NBW = 4>
 __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4 (&fa)[2][4], const uint4 (&fb)[4]) {
     if constexpr (M0 >= NBW) return;
     constexpr int NMI = (M0 + 1 < NBW) ? 2 : 1;
+#ifndef G8_NO_SETPRIO      // (experiment builds only: scripts/shadow_build.sh)
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -81,7 +83,9 @@ __device__ __forceinline__ void mfma_quadrant(f32x16_t (&acc)[4][2], const uint4
             }
             acc[M0 + mi][NQ] = h16<T16>::mma32(__builtin_bit_cast(bf16x8_t, fb[ks]), __builtin_bit_cast(bf16x8_t, fa[mi][ks]), cin);
         }
+#ifndef G8_NO_SETPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // vmcnt left in flight after a phase's issue: 8 in the steady state (the refills of the last four phases); the last two
@@ -99,8 +103,13 @@ __device__ __forceinline__ void vm_wait_tail() {
 // segment -- what VALU work in the partner wave's MFMA shadow costs the main loop.
 #define G8_GS_PARAM , float (&gs)[4]
 #define G8_GS_ARG , gs
-#define G8_SHADOW()                                                   \
+#ifndef G8_EXP_SHADOW_MASK
+#define G8_EXP_SHADOW_MASK 15      // bit p: the units run in phase p of every K-tile
+#endif
+#define G8_SHADOW() G8_SHADOW_P(0)
+#define G8_SHADOW_P(ph_)                                              \
     do {                                                              \
+        if (!((G8_EXP_SHADOW_MASK >> (ph_)) & 1)) break;              \
         pin();                                                        \
         _Pragma("unroll") for (int u_ = 0; u_ < G8_EXP_SHADOW; ++u_) { \
             float d_[4];                                              \
@@ -113,6 +122,7 @@ __device__ __forceinline__ void vm_wait_tail() {
 #define G8_GS_PARAM
 #define G8_GS_ARG
 #define G8_SHADOW() do {} while (0)
+#define G8_SHADOW_P(ph_) do {} while (0)
 #endif
 // One K-tile out of the buffer at byte offset `cb` (0 or BUF_BYTES); kb = byte offset of this K-tile within a row.
 // last2 (REM == 2 only): K-tile t + 2, refilled in phases 2 / 3, is the last one of K.
@@ -139,7 +149,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + mi * (32 * KB));
     if constexpr (REM >= 1) dma2z<BAUX>(c.rb, c.b2[0], c.b2[1], c.pz, m1, kb + KB, oth + OP_BYTES + c.dB2);
-    G8_SHADOW();
+    G8_SHADOW_P(0);
     pin();
     vm_wait_tail<REM, 8, 2, SLACK>();
     bar();
@@ -149,7 +159,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb1[ks] = lds16(smem + adb[ks] + 32 * KB);
     if constexpr (REM >= 1) dma2z(c.ra, c.a2[0], c.a2[1], c.pz, m1, kb + KB, oth + c.dA2);
-    G8_SHADOW();
+    G8_SHADOW_P(1);
     pin();
     vm_wait_tail<REM, 8, 0, SLACK>();
     bar();
@@ -161,7 +171,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fa[mi][ks] = lds16(smem + ada[ks] + (64 + mi * 32) * KB);
     if constexpr (REM >= 2) dma2z(c.ra, c.a1[0], c.a1[1], c.pz, m2, kb + 2 * KB, cur + c.dA1);
-    G8_SHADOW();
+    G8_SHADOW_P(2);
     pin();
     vm_wait_tail<REM, 6, 0, SLACK>();
     bar();
@@ -169,7 +179,7 @@ __device__ __forceinline__ void ktile(char* smem, const Ctx& c, int cb, int kb, 
     bar();
     // ---- phase 3: nothing to read (B-first is still in registers); refill B-first of t+2
     if constexpr (REM >= 2) dma2z<BAUX>(c.rb, c.b1[0], c.b1[1], c.pz, m2, kb + 2 * KB, cur + OP_BYTES + c.dB1);
-    G8_SHADOW();
+    G8_SHADOW_P(3);
     pin();
     vm_wait_tail<REM, 4, 0, SLACK>();
     bar();

@@ -127,3 +127,17 @@ def test_swin_tiny_full_size_scalars():
 def test_swin_base_full_size_scalars():
     """BASELINE.json configs[4]: Swin-B (embed 128, depths 2/2/18/2, heads 4/8/16/32) -- oracle vs the reference's g15 scalars."""
     _full_size_scalars("g15_swin_base_scalars.npz", "g15", SwinCfg(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)))
+
+
+def test_g21_autocast_floor_is_pinned_to_the_vision_goldens(golden_dir):
+    """g21 (tests/golden/make_autocast_floor_vision.py): the reference vision Model's loss on the g13 / g15 inputs in fp32 and under
+    ``torch.autocast('cpu', fp16 | bf16)``.  Its fp32 entries must BE the goldens' losses (same inputs, same weights), and the autocast gaps
+    are what the GPU tests measure the HIP 16-bit modes against."""
+    import json
+    with open(os.path.join(golden_dir, "g21_autocast_floor_vision.json")) as fh:
+        fl = json.load(fh)
+    for name, fname in (("swin_tiny", "g13_swin_tiny_scalars.npz"), ("swin_base", "g15_swin_base_scalars.npz")):
+        G = np.load(os.path.join(golden_dir, fname))
+        assert abs(fl[name]["fp32"] - float(G["loss"])) < 1e-6
+        for t in ("autocast_fp16", "autocast_bf16"):
+            assert fl[name][t] is not None and 1e-4 < abs(fl[name][t] - fl[name]["fp32"]) < 0.1

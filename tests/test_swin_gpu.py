@@ -294,7 +294,18 @@ def _full_size_swin_golden(golden_dir, dt, name, fname, tag):
         worst = max(worst, abs(got - ref) / (ref + 1e-9)) if ref > 1e-6 else worst
         kg = 1.0 if dt == "bf16" else 0.25      # fp16 gradient norms: measured worst 2.4e-2 (g13) / 2.7e-3 (g15); a quarter of the bf16 bound
         assert abs(got - ref) <= (5e-3 if not half else 1.5e-1 * kg) * ref + (1e-6 if not half else 1e-3), (n, got, ref)
-    print(f"{tag} {name} {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}")
+    floor = ""
+    if half:
+        # yardstick g21 (tests/golden/make_autocast_floor_vision.py): the reference's OWN loss under torch.autocast(fp16 / bf16) on these inputs --
+        # how far 16-bit GEMM operands move the reference itself from its fp32 loss.  The HIP 16-bit modes must sit inside 1.5 x that gap.
+        import json
+        with open(os.path.join(golden_dir, "g21_autocast_floor_vision.json")) as fh:
+            fl = json.load(fh)[name]
+        ref_gap = abs(fl["autocast_" + dt] - fl["fp32"])
+        floor = f", the reference's own autocast gap {ref_gap:.2e}"
+        assert abs(fl["fp32"] - float(G["loss"])) < 1e-5
+        assert e_l <= 1.5 * ref_gap + 1e-4, (e_l, ref_gap)
+    print(f"{tag} {name} {dt}: item-vector relerr {e_v:.2e}, |loss - ref| {e_l:.2e}, worst grad-norm relerr {worst:.2e}{floor}")
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16", "fp32x3"])      # fp32x3: the fp32 bounds (GEMMs as three bf16 MFMA passes over operand splits); fp16: 1/8 of the bf16 bounds
