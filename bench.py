@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="one rank: replay the step as a captured hipGraph (TrainStep.step_graphed; one graph per input "
                     "shape, the unpadded token layout padded to buckets of 512 rows) instead of launching its ~700 kernels from the host.  Opt-in: on "
                     "this stack a replayed graph keeps the 5-8 us dependency gap between consecutive kernels, so it buys little (DESIGN.md)")
+    ap.add_argument("--no-sweep", action="store_true", help="N > 1: skip the reduced default sweep (torch.distributed x reserved CUs x overlap)")
     ap.add_argument("--sweep", action="store_true", help="N > 1: after the headline region, time the data-parallel knobs -- collectives through "
                     "torch.distributed vs the library's own RCCL communicators, 0 / 8 / 16 CUs reserved for the ring kernel, reduction overlapped "
                     "with the backward or after it -- and print each configuration's bucket trace under `sweep` (schema: INTEGRATION.md)")
@@ -544,12 +545,18 @@ def main():
     # {torch.distributed | the library's own RCCL communicators} x {CUs kept out of the GEMM grid during the backward: 0, 8, 16} x
     # {bucketed reduction overlapped with the backward | one sweep after it}.  Every configuration: 2 untimed + K timed steps between
     # barriers (max over ranks), then one traced step.  Schema: INTEGRATION.md "bench.py --sweep".
+    # Without --sweep (the driver's scaling runs) a REDUCED sweep still runs at N > 1: torch.distributed only -- no second communicator is
+    # created, nothing that could hang a run that has never been on > 1 GPU -- x {overlap, reserve 16 | overlap, reserve 0 | after the
+    # backward}, so that the first real multi-GPU line already says what the reserved CUs and the bucket overlap are worth (--no-sweep: off).
     sweep = None
-    if world > 1 and a.sweep:
+    if world > 1 and (a.sweep or not a.no_sweep):
         sweep = []
+        full = bool(a.sweep)
         base = (ts.comm, ts.comm_grad, ts._grad_stream, ts.reserve_cus, ts.overlap_reduce)
         own = None
-        if a.backend == "nccl" and not a.share_device:
+        if not full:
+            pass
+        elif a.backend == "nccl" and not a.share_device:
             try:
                 from idvs.morec_amd.comm import MorecComm
                 own = (MorecComm(), MorecComm(), torch.cuda.Stream(device=dev))
@@ -564,12 +571,12 @@ def main():
                 sweep.append({"comm": "rccl", "skipped": f"{type(e).__name__}: {e}"})
         else:
             sweep.append({"comm": "rccl", "skipped": "needs backend nccl with one GPU per rank (RCCL refuses two ranks on one device)"})
-        K = max(2, min(a.steps, 6))
+        K = max(2, min(a.steps, 6 if full else 4))
         for comm_name in ("torch.distributed", "rccl"):
             if comm_name == "rccl" and own is None:
                 continue
             for overlap in (True, False):
-                for reserve in ((0, 8, 16) if (overlap and a.backend == "nccl") else (0,)):
+                for reserve in (((0, 8, 16) if full else (0, 16)) if (overlap and a.backend == "nccl") else (0,)):
                     ts.comm, ts.comm_grad, ts._grad_stream = (own if comm_name == "rccl" else (None, None, None))
                     ts.overlap_reduce, ts.reserve_cus = overlap, reserve
                     rec = {"comm": comm_name, "overlap_reduce": overlap, "reserve_cus": reserve}
