@@ -20,6 +20,7 @@ struct SwinAttnArgs {
     const void* dctx;     // backward: gradient of ctx
     void* dqkv;           // backward: [rows, 3C]
     float* dbias_t;       // backward: [heads][j][i] accumulators (atomicAdd)
+    float* dbias_part;    // deterministic mode: [heads][gridDim.x][NT * NT] per-block partials instead (folded in block order by the launcher)
     int n_img, H, W, shift, heads;
     float scale;
     int n_win_total, wpb; // windows in the launch, windows per block
@@ -264,7 +265,11 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(SwinAttnArgs a) {
             store_row32<T>(dqkv + (size_t)myrow * pitch + 2 * C + head * DH, dv);
         }
     }
-    if (lane < NT && a.dbias_t) {
+    if (lane < NT && a.dbias_part) {
+        float* part = a.dbias_part + ((size_t)head * gridDim.x + blockIdx.x) * (NT * NT);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) part[j * NT + lane] = dbacc[j];
+    } else if (lane < NT && a.dbias_t) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) atomicAdd(a.dbias_t + (size_t)head * NT * NT + j * NT + lane, dbacc[j]);
     }
@@ -286,14 +291,25 @@ __global__ void swin_bias_expand_kernel(const float* __restrict__ table, float* 
     bias_t[e] = table[rel_index(i, j, ws) * heads + h];
 }
 
-// dtable[rel_index(i, j)][h] += dbias_t[h][j][i]
+// dtable[rel_index(i, j)][h] += dbias_t[h][j][i]: ONE thread per table entry gathers its (i, j) pairs in a fixed order (the first version
+// scattered the 2 401 cells of a head onto the 169 entries with atomics: up to 49 adds per entry in arrival order)
 __global__ void swin_bias_reduce_kernel(const float* __restrict__ dbias_t, float* __restrict__ dtable, int ws, int heads) {
-    const int NT = ws * ws;
+    const int NT = ws * ws, R = 2 * ws - 1;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= heads * NT * NT) return;
-    const int h = e / (NT * NT), r = e - h * NT * NT;
-    const int j = r / NT, i = r - j * NT;
-    atomicAdd(dtable + rel_index(i, j, ws) * heads + h, dbias_t[e]);
+    if (e >= R * R * heads) return;
+    const int rel = e / heads, h = e - rel * heads;
+    const int dy = rel / R - (ws - 1), dx = rel % R - (ws - 1);      // yi - yj, xi - xj of every pair behind this entry
+    float acc = 0.f;
+    for (int yi = 0; yi < ws; ++yi) {
+        const int yj = yi - dy;
+        if (yj < 0 || yj >= ws) continue;
+        for (int xi = 0; xi < ws; ++xi) {
+            const int xj = xi - dx;
+            if (xj < 0 || xj >= ws) continue;
+            acc += dbias_t[((size_t)h * NT + (yj * ws + xj)) * NT + (yi * ws + xi)];
+        }
+    }
+    dtable[rel * heads + h] += acc;
 }
 
 // ---- patchify: out[(n, py, px), (c, i, j)] = pixels[n, c, py*ps + i, px*ps + j]; thread = one (row, c, i) run of ps pixels
@@ -511,10 +527,20 @@ extern "C" int morec_swin_attn_bwd(const morec_swin_attn_desc* d, const void* qk
     rc = morec_swin_attn_mfma_launch(d, qkv, bias_t, const_cast<void*>(ctx), dctx, dqkv, dbias_t, true, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     dim3 grid(gx, d->heads), block(64);
+    const int NT2 = d->window * d->window * d->window * d->window;
+    if (dbias_t && morec_deterministic()) {      // per-block partial tiles, folded in block order below
+        a.dbias_part = morec_det_scratch(s, (size_t)d->heads * gx * NT2);
+        if (!a.dbias_part) return (int)hipErrorOutOfMemory;
+    }
     if (d->dtype == MOREC_F32) hipLaunchKernelGGL((swin_attn_bwd_kernel<float, 7>), grid, block, 0, s, a);
     else if (d->dtype == MOREC_F16) hipLaunchKernelGGL((swin_attn_bwd_kernel<f16, 7>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((swin_attn_bwd_kernel<bf16, 7>), grid, block, 0, s, a);
     MOREC_CHECK_LAUNCH();
+    if (a.dbias_part)
+        for (int h = 0; h < d->heads; ++h) {
+            rc = morec_det_fold_add(a.dbias_part + (size_t)h * gx * NT2, dbias_t + (size_t)h * NT2, gx, (size_t)NT2, (size_t)NT2, s);
+            if (rc) return rc;
+        }
     return MOREC_OK;
 }
 
@@ -529,7 +555,7 @@ extern "C" int morec_swin_bias_expand(const float* table, float* bias_t, int win
 
 extern "C" int morec_swin_bias_reduce(const float* dbias_t, float* dtable, int window, int heads, void* stream) {
     if (!dbias_t || !dtable || window <= 0 || heads <= 0) return MOREC_E_ARG;
-    const int n = heads * window * window * window * window;
+    const int n = heads * (2 * window - 1) * (2 * window - 1);
     hipLaunchKernelGGL(swin_bias_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        dbias_t, dtable, window, heads);
     MOREC_CHECK_LAUNCH();

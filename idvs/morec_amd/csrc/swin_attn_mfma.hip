@@ -47,6 +47,7 @@ struct SwinMArgs {
     int gx;                // window groups (4 wavefronts x wpw windows each)
     unsigned qkv_bytes;    // size of qkv / dqkv in bytes (bwd: buffer-descriptor extent, < 4 GiB)
     float* csum;           // bwd, optional: [gx * 4 wavefronts][3 C] fp32 column sums of the wavefront's dq / dk / dv rows
+    float* dbias_part;     // bwd, deterministic mode: [heads][gx][NT * NT] per-workgroup dbias tiles (the launcher folds them in order) instead of atomics
 };
 
 // T16 = bf16 | f16: the storage type of q / k / v / ctx and their gradients (the operand bits go to the MFMA as they are; only the
@@ -646,9 +647,11 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
             }
         }
         __syncthreads();
+        float* part = a.dbias_part ? a.dbias_part + ((size_t)head * a.gx + wm.bx) * (NT * NT) : nullptr;
         for (int e = threadIdx.x; e < NT * NT; e += 256) {
             const int j = e / NT, i = e - j * NT;
-            atomicAdd(a.dbias_t + (size_t)head * NT * NT + e, red[j * BP + i]);
+            if (part) part[e] = red[j * BP + i];
+            else atomicAdd(a.dbias_t + (size_t)head * NT * NT + e, red[j * BP + i]);
         }
     }
 }
@@ -681,6 +684,10 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
     const unsigned long long qkv_bytes = (unsigned long long)d->n_img * d->H * d->W * 3 * d->heads * DH * 2;
     if (backward && qkv_bytes >= 0xffffffffull) return MOREC_E_UNSUPPORTED;     // 32-bit buffer offsets in the backward kernel
     a.qkv_bytes = (unsigned)qkv_bytes;
+    if (backward && dbias_t && morec_deterministic()) {
+        a.dbias_part = morec_det_scratch(s, (size_t)d->heads * a.gx * (NT * NT));
+        if (!a.dbias_part) return (int)hipErrorOutOfMemory;
+    }
     const size_t lds = (size_t)NT * BP * sizeof(float) + 4 * (2 * TILE + PTILE);
     static const int wide = [] { const char* e = getenv("MOREC_SWIN_BWD_WIDE"); return e ? atoi(e) : 1; }();
     by_h16(d->dtype, [&](auto* t) {
@@ -699,5 +706,10 @@ int morec_swin_attn_mfma_launch(const morec_swin_attn_desc* d, const void* qkv, 
         else hipLaunchKernelGGL((swin_attn_bwd_mfma_kernel<T, false>), grid, block, lds, s, a);
     });
     MOREC_CHECK_LAUNCH();
+    if (a.dbias_part)      // deterministic mode: the workgroups' tiles in window-group order, one fold per head
+        for (int h = 0; h < d->heads; ++h) {
+            const int rc = morec_det_fold_add(a.dbias_part + (size_t)h * a.gx * (NT * NT), dbias_t + (size_t)h * (NT * NT), a.gx, (size_t)(NT * NT), (size_t)(NT * NT), s);
+            if (rc) return rc;
+        }
     return MOREC_OK;
 }

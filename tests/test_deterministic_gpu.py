@@ -1,5 +1,5 @@
 """-m gpu: ``MOREC_DETERMINISTIC`` (``ops.set_deterministic``).  The reference sets torch's deterministic flags (``T/run.py:313-314``); the
-library's counterpart replaces every fp32 atomic of the text / ID step -- LayerNorm dgamma / dbeta / bias column sums, bias gradients,
+library's counterpart replaces every fp32 atomic of the text / ID / Swin step -- LayerNorm dgamma / dbeta / bias column sums, bias gradients,
 position / type rows, the word-table and id-table scatters, multi-block folds of partial rows -- by per-block partials folded in a fixed
 order (or a single writer per table row).  Checked: two runs of the same steps from the same initial state are BIT-identical (losses,
 every parameter, both AdamW moments), with dropout on and with the weight gradients on the second stream; and the mode changes the
@@ -47,6 +47,16 @@ def _run(tower, dtype, steps, det):
                                          num_words_title=T, num_words_abstract=50, num_words_body=50, news_attributes=["title"],
                                          bert_model_load="bert_tiny", word_embedding_dim=shape.hidden_size, compute_dtype=dtype)
             m = Model(args, item_num, True, HipBertModel(shape, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1), pop).to(DEV).train()
+        elif tower == "vision":
+            from idvs.morec_amd.model.swin import HipSwinForImageClassification
+            from idvs.morec_amd.swin_engine import SwinShape
+            shape = SwinShape.named("swin_micro")      # 56 x 56 images, two stages (plain + shifted windows, a patch merging), DropPath 0.1
+            gen = torch.Generator(device=DEV).manual_seed(11)
+            catalog = torch.randn((item_num + 1, 3, shape.image_size, shape.image_size), device=DEV, generator=gen)
+            catalog[0].zero_()
+            args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2,
+                                         CV_model_load="swin_micro", compute_dtype=dtype)
+            m = Model(args, item_num, True, HipSwinForImageClassification(shape, D), pop).to(DEV).train()
         else:
             args = types.SimpleNamespace(max_seq_len=S, embedding_dim=D, num_attention_heads=2, drop_rate=0.1, transformer_block=2, compute_dtype=dtype)
             m = Model(args, item_num, False, None, pop).to(DEV).train()
@@ -60,6 +70,8 @@ def _run(tower, dtype, steps, det):
                 rows = content[ids_all[i].reshape(-1)]
                 pack = tuple(t.to(DEV) for t in engine.token_packing_host(rows[:, T:], rows[:, :T]))
                 losses.append(ts.step(ids.view(-1), torch.from_numpy(rows).to(DEV), lm, token_packing=pack))
+            elif tower == "vision":
+                losses.append(ts.step(ids.view(-1), catalog[ids.view(-1)], lm))
             else:
                 losses.append(ts.step(ids.view(-1), ids.view(-1).clone(), lm))
         ts.flush()
@@ -70,7 +82,7 @@ def _run(tower, dtype, steps, det):
         ops.set_deterministic(False)
 
 
-@pytest.mark.parametrize("tower,dtype", [("text", "fp16"), ("text", "fp32"), ("id", "bf16")])
+@pytest.mark.parametrize("tower,dtype", [("text", "fp16"), ("text", "fp32"), ("id", "bf16"), ("vision", "fp16"), ("vision", "fp32")])
 def test_two_runs_are_bit_identical(tower, dtype):
     steps = 5
     a = _run(tower, dtype, steps, True)
@@ -86,6 +98,7 @@ def test_two_runs_are_bit_identical(tower, dtype):
     print(f"{tower} {dtype}: deterministic x 2 bit-identical over {steps} steps; vs default kernels: max |d loss| {dl:.2e}, parameter distance {dp:.2e}")
     # (measured: text fp16 2.2e-4 / 5.5e-4, text fp32 2.4e-6 / 7.2e-5, id bf16 8.5e-5 / 5.4e-4; a scatter that dropped every source row past
     # the first 32 candidates -- lanes without columns were missing from a ballot -- showed up here as 1e-2 on the id tower)
+    # (vision, round 6: the window-attention dbias tiles per workgroup + an ordered fold, the relative-position table as a gather)
     assert dl < (2e-4 if dtype == "fp32" else 3e-3) and dp < (1e-3 if dtype == "fp32" else 4e-3)
 
 
