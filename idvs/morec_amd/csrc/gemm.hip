@@ -53,6 +53,10 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
         const int rw = gemm_skinny_wide_try_launch(d, a, s);      // 288 < N <= 512, K <= 128 (stage-1 fc1 + GELU without a second output)
         if (rw != G8_NOT_TAKEN) return rw;
     }
+    {   // epilogue-heavy 16-bit products: 256 x 128 tiles, two workgroups per CU (gemm2w.hip)
+        const int r2 = gemm2w_try_launch(d, a, s);
+        if (r2 != G8_NOT_TAKEN) return r2;
+    }
     {   // bf16, large: the 256 x 256 eight-phase kernel (gemm8p.hip)
         const int r8 = gemm8p_try_launch(d, a, s);
         if (r8 != G8_NOT_TAKEN) return r8;

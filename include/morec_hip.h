@@ -71,6 +71,8 @@ const char* morec_strerror(int code);
 int morec_version(void);
 /* Process-wide kernel-selection knobs (measurement / A-B aid; see "State the library keeps" above).  Keys:
  *   "gemm8p"             0 = automatic, 1 = never use the 256 x 256 eight-phase GEMM, 2 = use it wherever it is eligible;
+ *   "gemm2w"             0 = automatic, 1 = never use the 256 x 128 two-workgroups-per-CU GEMM (gemm2w.hip: the epilogue-heavy products --
+ *                        GELU + act' outputs, x act' + column sums -- with >= 1024 tiles), 2 = every eligible 16-bit product; env MOREC_GEMM2W;
  *   "gemm8p_tail_split"  1 = split the last, partly filled round of tiles along K between two workgroups (K >= 1536);
  *   "gemm8p_tail_bias"   share of K the first part takes in that split;
  *   "gemm8p_ngroup"      tile order: -1 = automatic column groups (default), 0 = row-major, n = column groups of n N-tiles;
