@@ -811,6 +811,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             roof["scoring"]["pooled_8_ranks"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # Is the GEMM rate set by the schedule or by the part's power limit?  The same launch (FFN-up shape of the step, plain epilogue) on N(0, 0.5)
+    # operands and on zeros: identical instruction stream and cycle count, different switching activity (never part of `value`)
+    if not a.no_secondary and not vision and not id_tower and world == 1 and a.dtype16 in ("bf16", "fp16"):
+        try:
+            roof["operand_activity_probe"] = operand_activity_probe(ops, dev, torch.float16 if a.dtype16 == "fp16" else torch.bfloat16)
+        except Exception as e:  # noqa: BLE001
+            roof["operand_activity_probe"] = {"error": f"{type(e).__name__}: {e}"}
+
     eval_info = None
     if not a.no_secondary and not vision and not id_tower and world == 1 and a.dtype16 in ("bf16", "fp16"):
         keep = (list(gemm_log), list(ce_log), list(ce_shapes))
@@ -1021,6 +1029,38 @@ def eval_lines(model, ops, args, content, item_num, S, D, dev, gemm_log, timing_
         timing_on["v"] = False
     if was_training:
         model.train()
+    return out
+
+
+def operand_activity_probe(ops, dev, dt, M=54919, N=3072, K=768, iters=20):
+    """One GEMM launch of the step's FFN-up shape (plain epilogue) timed on random and on all-zero operands.  Same kernel, same cycles; a part
+    that runs at its power limit clocks the quiet operands higher (MI355X_MICROARCH.md "DVFS give-back").  The ratio says how far the random-
+    operand rate -- the one `roofline.achieved` is made of -- sits below what the same schedule does when power is not the limit."""
+    out = {}
+    c = torch.empty(M, N, device=dev, dtype=dt)
+    for name in ("random", "zero"):
+        if name == "random":
+            a_, b_ = (torch.randn(M, K, device=dev) * 0.5).to(dt), (torch.randn(N, K, device=dev) * 0.5).to(dt)
+        else:
+            a_, b_ = torch.zeros(M, K, device=dev, dtype=dt), torch.zeros(N, K, device=dev, dtype=dt)
+        for _ in range(5):
+            ops.gemm_nt(a_, b_, out=c)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.gemm_nt(a_, b_, out=c)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            best = us if best is None else min(best, us)
+        out[name + "_operands"] = {"us": round(best, 1), "tflops": round(2.0 * M * N * K / best / 1e6, 1)}
+    out["shape"] = {"M": M, "N": N, "K": K, "dtype": str(dt).replace("torch.", "")}
+    out["zero_over_random"] = round(out["zero_operands"]["tflops"] / out["random_operands"]["tflops"], 3)
+    out["note"] = ("same launch, same instruction stream: the gap is the clock the part sustains on each operand set, i.e. the random-operand rate is "
+                   "power-limited by that factor (profiles/r06_gemm_power_probe.txt has both tile kernels and K = 3072)")
     return out
 
 

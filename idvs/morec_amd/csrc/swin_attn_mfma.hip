@@ -69,13 +69,23 @@ __device__ __forceinline__ uint4 frag_tr(const char* tile, int row_bytes, int co
     return __builtin_bit_cast(uint4, v);
 }
 
-// The same read with the 16 head columns of block pair td spread as 4 groups of 4: lane c receives column 4 td + 8 (c >> 2) + (c & 3).
-// As the A operand of an MFMA this makes output row 4 g + r of block td the head column 8 g + 4 td + r, i.e. the two blocks td = 0, 1 of a
-// lane are 8 CONSECUTIVE head columns of its token row: one 16-byte store per (token, tensor) instead of two 8-byte ones (the 8-byte
-// pieces made these kernels store-issue bound: 2.4 - 3.3 TB/s, profiles/r03_swin_tiny_kernel_stats.csv).
+// ---- [64 x 32] 16-bit operand tiles (K, V, dO, Q): 64-byte rows, the four 16-byte chunks of row r stored at chunk ^ ((r >> 1) & 3).  With plain
+// rows the eight lanes of a ds_write_b128 service group (rows c = 0..7, one chunk) sit on TWO 4-bank groups (4-way conflict: 32 LDS cycles per
+// store instead of 13) and the 32 lanes of a transposing read (rows R and R + 4 share their banks) are 2-way; with the swizzle both are conflict-free
+// (round 6; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the backward was 47 %: profiles/r05_swin_attn_pmc.txt).
+// byte offset of (row c + 16 k, chunk g4) for the lane that owns it: tile_wr_off() + k * 1024
+__device__ __forceinline__ int tile_wr_off() {
+    const int lane = threadIdx.x & 63, c = lane & 15, g4 = lane >> 4;
+    return c * TROW + 16 * (g4 ^ ((c >> 1) & 3));
+}
+// The transposed fragment with the 16 head columns of block pair td spread as 4 groups of 4: lane c receives column 4 td + 8 (c & 3) + e of rows
+// {32 s + 4 g + e} (e = 0..3) and {32 s + 16 + 4 g + e}.  As the A operand of an MFMA this makes output row 4 g + r of block td the head column
+// 8 g + 4 td + r, i.e. the two blocks td = 0, 1 of a lane are 8 CONSECUTIVE head columns of its token row: one 16-byte store per (token, tensor)
+// instead of two 8-byte ones (the 8-byte pieces made these kernels store-issue bound: 2.4 - 3.3 TB/s, profiles/r03_swin_tiny_kernel_stats.csv).
 __device__ __forceinline__ uint4 frag_tr_spread(const char* tile, int row_bytes, int td, int s) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const char* p0 = tile + (32 * s + 4 * g + (c >> 2)) * row_bytes + (4 * td + 8 * (c & 3)) * 2;
+    // the lane reads 8 bytes of row R = 32 s + 4 g + (c >> 2), logical chunk c & 3; (R >> 1) & 3 = (2 g + (c >> 3)) & 3 for R and for R + 16
+    const char* p0 = tile + (32 * s + 4 * g + (c >> 2)) * row_bytes + 16 * ((c & 3) ^ ((2 * g + (c >> 3)) & 3)) + 8 * td;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * row_bytes));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(SwinMArgs a) {
             vf[k] = *reinterpret_cast<const uint4*>(base + 2 * C);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sV + (c + 16 * k) * TROW + 16 * g4) = vf[k];
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sV + tile_wr_off() + k * 1024) = vf[k];
         f32x4_t s[4][4];
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
@@ -431,8 +441,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            *reinterpret_cast<uint4*>(sK + (c + 16 * k) * TROW + 16 * g4) = fr.k[k];
-            *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = fr.o[k];
+            *reinterpret_cast<uint4*>(sK + tile_wr_off() + k * 1024) = fr.k[k];
+            *reinterpret_cast<uint4*>(sX + tile_wr_off() + k * 1024) = fr.o[k];
         }
         uint4 dsf[4][2];
         // one 16-query block at a time (see softmax_part); dO rows of the block come back from the tile just written
@@ -442,7 +452,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
             f32x4_t s[4][NTI], dp[4][NTI];
             uint4 ob[NTI];
 #pragma unroll
-            for (int t = 0; t < NTI; ++t) ob[t] = *reinterpret_cast<const uint4*>(sX + (c + 16 * (TB + t)) * TROW + 16 * g4);
+            for (int t = 0; t < NTI; ++t) ob[t] = *reinterpret_cast<const uint4*>(sX + tile_wr_off() + (TB + t) * 1024);
 #pragma unroll
             for (int t = 0; t < NTI; ++t)
 #pragma unroll
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void swin_attn_bwd_mfma_kernel(S
         wave_lds_fence();
         // dK^T[d][j] = scale * sum_i Q[i][d] dS[i][j]: Q (still in registers) and dS replace dO and P in their tiles
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + (c + 16 * k) * TROW + 16 * g4) = fr.q[k];
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint4*>(sX + tile_wr_off() + k * 1024) = fr.q[k];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             char* prow = sP + (16 * ti + c) * PROW;
