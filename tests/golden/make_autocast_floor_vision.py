@@ -53,6 +53,27 @@ def main():
                     rec[t] = None
                     rec[t + "_error"] = f"{type(e).__name__}: {e}"
         rec["rows"] = int(log_mask.sum())
+        # gradient norms: fp32 (= the golden's) against the reference under autocast(fp16) with a fixed loss scale of 1024 (what GradScaler does
+        # dynamically; tests/test_swin_gpu.py uses the same scale) -- the reference's own gradient-norm gap, parameter by parameter
+        def grad_norms(autocast_dt, scale):
+            m.zero_grad()
+            if autocast_dt is None:
+                loss = m(torch.from_numpy(ids).view(-1), px, torch.from_numpy(log_mask), "cpu")
+            else:
+                with torch.autocast(device_type="cpu", dtype=autocast_dt):
+                    loss = m(torch.from_numpy(ids).view(-1), px, torch.from_numpy(log_mask), "cpu")
+            (loss * scale).backward()
+            return {k: float(p_.grad.double().norm()) / scale for k, p_ in m.named_parameters() if p_.grad is not None}
+        g32 = grad_norms(None, 1.0)
+        try:
+            g16 = grad_norms(torch.float16, 1024.0)
+            rel = {k: abs(g16[k] - g32[k]) / (g32[k] + 1e-9) for k in g32 if g32[k] > 1e-6}
+            worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+            rec["autocast_fp16_grad_norm_relerr_worst"] = float(worst[0][1])
+            rec["autocast_fp16_grad_norm_relerr_top5"] = [[k, float(v)] for k, v in worst]
+            rec["autocast_fp16_grad_norm_relerr_median"] = float(np.median(list(rel.values())))
+        except Exception as e:  # noqa: BLE001
+            rec["autocast_fp16_grad_norm_error"] = f"{type(e).__name__}: {e}"
         out[name] = rec
         print(name, rec, flush=True)
     out["note"] = ("losses of the imported reference vision Model on the g13 / g15 inputs: fp32, and under torch.autocast('cpu', fp16 / bf16); torch "
