@@ -10,7 +10,7 @@ extern "C" int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void
 }
 
 extern "C" size_t morec_gemm_colsum_workspace_bytes(int M, int N) {
-    return (size_t)((M + 63) / 64) * (size_t)N * sizeof(float);      // one partial row per 64-row wave block at most
+    return (size_t)((M + 31) / 32) * (size_t)N * sizeof(float);      // one partial row per 32-row wave block at most (gemm_small.hip)
 }
 
 extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, const void* B, void* C, const float* bias,
@@ -60,6 +60,10 @@ extern "C" int morec_gemm_nt_colsum(const morec_gemm_desc* d, const void* A, con
     {   // bf16, large: the 256 x 256 eight-phase kernel (gemm8p.hip)
         const int r8 = gemm8p_try_launch(d, a, s);
         if (r8 != G8_NOT_TAKEN) return r8;
+    }
+    {   // latency-class 16-bit products (the SASRec layers): 64 x 64 tiles on a four-stage ring (gemm_small.hip)
+        const int rs = gemm_small_try_launch(d, a, s);
+        if (rs != G8_NOT_TAKEN) return rs;
     }
     if (d->in_dtype == MOREC_F32 && d->out_dtype == MOREC_F32) return launch_gemm<float, float>(d, a, s);
     if (d->in_dtype == MOREC_BF16 && d->out_dtype == MOREC_BF16) return launch_gemm<bf16, bf16>(d, a, s);

@@ -641,12 +641,14 @@ int launch8p(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s) {
 // 0: automatic (eligible large problems), 1: never, 2: every eligible problem regardless of size
 static int g_mode8p = -1, g_debug8p = 0, g_tail_bias = 2, g_tail_split = 0;
 extern int g_mode2w;      // gemm2w.hip
+extern int g_mode_small;  // gemm_small.hip
 static unsigned long long g_stamps = 0;
 extern "C" int morec_tuning_set(const char* key, int value) {
     if (!key) return MOREC_E_ARG;
     if (!strcmp(key, "deterministic")) { morec_set_deterministic(value); return MOREC_OK; }
     if (!strcmp(key, "gemm8p")) { g_mode8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm2w")) { g_mode2w = value; return MOREC_OK; }
+    if (!strcmp(key, "gemm_small")) { g_mode_small = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_debug")) { g_debug8p = value; return MOREC_OK; }
     if (!strcmp(key, "gemm8p_tail_split")) { g_tail_split = value != 0; return MOREC_OK; }
     if (!strcmp(key, "ce8p")) { g_ce8p_mode = value; return MOREC_OK; }

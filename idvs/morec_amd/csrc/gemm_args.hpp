@@ -35,6 +35,7 @@ struct GemmArgs {
 #define G8_NOT_TAKEN 0x7fff0001
 int gemm8p_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);
 int gemm2w_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm2w.hip: 256 x 128 tiles, two workgroups per CU (epilogue-heavy products)
+int gemm_small_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);       // gemm_small.hip: 64 x 64 tiles, four-stage ring (latency-class products)
 int gemm_skinny_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s);      // gemm_skinny.hip: N <= 128, K <= 384, plain product
 int gemm_skinny_wide_try_launch(const morec_gemm_desc* d, GemmArgs& a, hipStream_t s); // gemm_skinny_wide.hip: 288 < N <= 512, K <= 128, bias / GELU
 extern int g_skinny_mode;

@@ -27,8 +27,12 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < G::NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    gemm_mainloop_cfg<G, TI>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb, m0,
-                             n0, kbeg, kend, smem, acc);
+    if constexpr (G::NST > 2)
+        gemm_mainloop_ring<G, TI>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb, m0,
+                                  n0, kbeg, kend, smem, acc);
+    else
+        gemm_mainloop_cfg<G, TI>(reinterpret_cast<const TI*>(p.A), reinterpret_cast<const TI*>(p.B), p.M, p.N, p.lda, p.ldb, m0,
+                                 n0, kbeg, kend, smem, acc);
 
     TO* C = reinterpret_cast<TO*>(p.C);
     TO* aux = reinterpret_cast<TO*>(p.aux_out);

@@ -399,7 +399,9 @@ static int ln_bwd_launch(const void* dy_a, const void* dy_b, const void* z, cons
         slots = nb * n_cu;
         lds_seen = lds;
     }
-    const int rpb = std::max(64, (((M + slots - 1) / slots) + 15) & ~15);
+    // (floor of rows per block: 64 keeps the per-block column atomics rare on the encoders' 50 k rows; on the SASRec layers' 2 560 rows it
+    // left 40 blocks whose four waves walked 16 rows each, one memory round trip per row: 18 - 24 us per launch -- 16 rows there)
+    const int rpb = std::max(M <= 8192 ? 16 : 64, (((M + slots - 1) / slots) + 15) & ~15);
     dim3 grid((M + rpb - 1) / rpb), block(256);
     float* det = nullptr;
     if ((dgamma || dbias) && morec_deterministic()) {      // per-block partial rows instead of one atomic per column per block
