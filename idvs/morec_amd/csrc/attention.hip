@@ -397,6 +397,9 @@ int attn_spare_blocks(const morec_attn_desc* d) { return (d->cu_seqlens && d->to
 int morec_attn_mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx,
                            void* dqkv, bool backward, hipStream_t s, float* csum = nullptr);
 int colsum_f32_launch(const float* in, float* out, int rows, int N, hipStream_t s);
+// fp32 path on the matrix cores (attention_f32mfma.hip: T <= 32, head width a multiple of 16); MOREC_E_UNSUPPORTED = shape outside it
+int morec_attn_f32mfma_launch(const morec_attn_desc* d, const void* qkv, const float* key_keep, void* ctx_or_dctx, void* dqkv, bool backward,
+                              hipStream_t s);
 
 // A 16-bit problem outside the matrix-core path's shape rules (T <= 32, head width a multiple of 32) runs on the exact-fp32 VALU
 // kernels -- correct, several times slower.  Said ONCE per process on stderr (MOREC_QUIET=1 silences it) so that e.g. a run with
@@ -424,6 +427,8 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
+    rc = morec_attn_f32mfma_launch(d, qkv, key_keep, ctx, nullptr, false, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
     (void)block;
     return launch_valu<false>(d, a, grid, s);
@@ -439,6 +444,8 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     dim3 grid(d->n_seq * d->n_heads + attn_spare_blocks(d)), block(64);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = morec_attn_mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
+    if (rc != MOREC_E_UNSUPPORTED) return rc;
+    rc = morec_attn_f32mfma_launch(d, qkv, key_keep, const_cast<void*>(dctx), dqkv, true, s);
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
     (void)block;
