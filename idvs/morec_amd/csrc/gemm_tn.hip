@@ -169,7 +169,17 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         const size_t e = i * 4;
         const int n = (int)(e / K), k = (int)(e % K);
         float4 s = reinterpret_cast<const float4*>(slabs)[i];
-        for (int t = 1; t < nslab; ++t) {
+        // eight slabs' loads in flight per thread, added in slab order (the sum is the sequential one): with one load per trip a fold over 40 - 64 slabs of a
+        // small weight (few blocks) was a chain of memory round trips -- 35 - 48 us for the BERT-tiny weights, 23 us on average in the Swin-T step
+        int t = 1;
+        for (; t + 8 <= nslab; t += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(slabs + (size_t)(t + u) * N * K)[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; t < nslab; ++t) {
             const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)t * N * K)[i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
