@@ -349,7 +349,307 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a) {
     }
 }
 
-constexpr int T_MAX = Tile<8>::TP;     // 64
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 < T <= 256: longer texts / behaviour sequences than any launcher of the reference sets (T/parameters.py:42-44: 30 / 50 / 50 tokens,
+// max_seq_len 20) but that its command line accepts.  Correctness-first form of the same arithmetic on the 32 x 32 register-block helpers
+// above: one wavefront per (sequence, head) walks the T / 32 query tiles; a whole row STRIP of scores ([32 queries] x [T keys], fp32) sits in
+// LDS, so the softmax is the plain two-pass one over complete rows (the reference's absorb arithmetic, fully masked rows included) and
+// nothing is rescaled on line.  Backward: (A) row statistics m, 1 / sum, delta = rowsum(P o dP) of every query into LDS, (B) per query tile
+// the dS strip -> dQ, (C) per key tile the dS / P strips over all queries -> dK, dV; every score tile is recomputed in each phase (three
+// times the minimum: this path is a fallback, 5 - 20 x slower per token than the matrix-core kernels).
+// Dropout stream: element index ((tile * TPD + i) * TPD + j) with TPD = 32 * ceil(T / 32).
+constexpr int T_LONG_MAX = 256;
+constexpr int LDC = 64;                                   // head-width chunk of the long kernels
+constexpr int LP = LDC + 4, LPP = Tile<4>::PP, LCW = LDC / 8;
+
+// s[r][c] = sum_d X[qt*32 + i0 + r][d] * Y[kt*32 + j0 + c][d] over the whole head width (chunks restaged per call)
+template <typename T>
+__device__ __forceinline__ void long_dot(const T* __restrict__ xsrc, int xpitch, int xcol, const T* __restrict__ ysrc, int ypitch, int ycol,
+                                         size_t row0, int dh, int Tlen, int qt, int kt, float* sX, float* sY, float (&s)[4][4]) {
+    const int lane = threadIdx.x, i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[r][c] = 0.f;
+    for (int d0 = 0; d0 < dh; d0 += LDC) {
+        stage_chunk<T, LDC, 4>(xsrc, row0 + (size_t)qt * 32, xpitch, xcol, d0, dh, min(32, Tlen - qt * 32), sX);
+        stage_chunk<T, LDC, 4>(ysrc, row0 + (size_t)kt * 32, ypitch, ycol, d0, dh, min(32, Tlen - kt * 32), sY);
+        __syncthreads();
+        block_dot<LDC, 4>(sX, sY, i0, j0, s);
+        __syncthreads();
+    }
+}
+
+// reference arithmetic of one score: scaled + additive mask; keys >= T never enter (-inf)
+__device__ __forceinline__ float long_masked(float s, int i, int j, int Tlen, int causal, float scale, float mask_value, const float* __restrict__ keep_row) {
+    if (j >= Tlen) return -INFINITY;
+    const bool kept = (keep_row[j] != 0.f) && (!causal || j <= i);
+    return s * scale + (kept ? 0.f : mask_value);
+}
+
+// o[r][c] += sum_{k < klen} W[k][w0 + r] * V[k][c0 + c]
+__device__ __forceinline__ void long_pv_acc(const float* __restrict__ W, const float* __restrict__ V, int w0, int c0, int klen, float (&o)[4][LCW]) {
+    for (int k = 0; k < klen; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(W + k * LPP + w0);
+        const float wr[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int q = 0; q < LCW / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(V + k * LP + c0 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r][4 * q + 0] += wr[r] * v.x; o[r][4 * q + 1] += wr[r] * v.y;
+                o[r][4 * q + 2] += wr[r] * v.z; o[r][4 * q + 3] += wr[r] * v.w;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_fwd_long_kernel(AttnArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {
+        zero_dead_rows(a.ctx, a.cu, a.n_seq, a.total_rows, (size_t)a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
+    const int seq_ = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
+    const int TPD = ((a.T + 31) / 32) * 32;              // mask-stream pitch: from the descriptor's T, not the sequence's own length
+    if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
+    if (a.T <= 0) return;
+    const int NT = (a.T + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* sA = smem_f;
+    float* sB = sA + 32 * LP;
+    float* strip = sB + 32 * LP;                         // [key][query of this tile], pitch LPP
+    const int lane = threadIdx.x, i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    T* ctx = reinterpret_cast<T*>(a.ctx);
+    const float* keep_row = a.key_keep + row0;
+    for (int qt = 0; qt < NT; ++qt) {
+        for (int kt = 0; kt < NT; ++kt) {
+            float s[4][4];
+            long_dot<T>(qkv, pitch, head * a.dh, qkv, pitch, H + head * a.dh, row0, a.dh, a.T, qt, kt, sA, sB, s);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float col[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) col[r] = long_masked(s[r][c], qt * 32 + i0 + r, kt * 32 + j0 + c, a.T, a.causal, a.scale, a.mask_value, keep_row);
+                put_row<4>(strip + (kt * 32 + j0 + c) * LPP + i0, col);
+            }
+        }
+        __syncthreads();
+        {   // softmax of row q = lane & 31 over the keys j = h, h + 2, ... (h = lane >> 5), the two halves combined by one exchange
+            const int q = lane & 31, h = lane >> 5, i = qt * 32 + q;
+            float m = -INFINITY;
+            for (int j = h; j < a.T; j += 2) m = fmaxf(m, strip[j * LPP + q]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+            for (int j = h; j < a.T; j += 2) sum += expf(strip[j * LPP + q] - m);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = (i < a.T) ? 1.0f / sum : 0.f;
+            for (int j = h; j < NT * 32; j += 2) {
+                float p = (j < a.T) ? expf(strip[j * LPP + q] - m) * inv : 0.f;
+                if (a.drop.thresh) p = drop_keep(a.drop, ((uint64_t)blockIdx.x * TPD + (uint64_t)i) * TPD + (uint64_t)j) ? p * a.drop.inv_keep : 0.f;
+                strip[j * LPP + q] = p;
+            }
+        }
+        __syncthreads();
+        const int c0 = (lane & 7) * LCW;
+        for (int d0 = 0; d0 < a.dh; d0 += LDC) {
+            float o[4][LCW];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < LCW; ++c) o[r][c] = 0.f;
+            for (int kt = 0; kt < NT; ++kt) {
+                stage_chunk<T, LDC, 4>(qkv, row0 + (size_t)kt * 32, pitch, 2 * H + head * a.dh, d0, a.dh, min(32, a.T - kt * 32), sA);
+                __syncthreads();
+                long_pv_acc(strip + kt * 32 * LPP, sA, i0, c0, min(32, a.T - kt * 32), o);
+                __syncthreads();
+            }
+            store_rows<T, LCW, 4>(ctx, row0 + (size_t)qt * 32, H, head * a.dh + d0 + c0, i0, min(32, a.T - qt * 32), d0 + c0, a.dh, o);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_long_kernel(AttnArgs a) {
+    if ((int)blockIdx.x >= a.n_seq * a.n_heads) {
+        zero_dead_rows(a.dqkv, a.cu, a.n_seq, a.total_rows, (size_t)3 * a.n_heads * a.dh * sizeof(T), (int)blockIdx.x - a.n_seq * a.n_heads);
+        return;
+    }
+    a.drop = drop_resolve(a.drop);
+    const int seq_ = blockIdx.x / a.n_heads, head = blockIdx.x % a.n_heads;
+    const size_t row0 = a.cu ? (size_t)a.cu[seq_] : (size_t)seq_ * a.T;
+    const int TPD = ((a.T + 31) / 32) * 32;
+    if (a.cu) a.T = a.cu[seq_ + 1] - a.cu[seq_];
+    if (a.T <= 0) return;
+    const int NT = (a.T + 31) / 32, TPAD = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* sA = smem_f;                                  // Q / dO side tile
+    float* sB = sA + 32 * LP;                            // K / V side tile
+    float* U1 = sB + 32 * LP;                            // strip 1: [TPAD][LPP]
+    float* U2 = U1 + T_LONG_MAX * LPP;                   // strip 2
+    float* st_m = U2 + T_LONG_MAX * LPP;                 // row statistics of every query: max, 1 / sum, delta
+    float* st_i = st_m + T_LONG_MAX;
+    float* st_d = st_i + T_LONG_MAX;
+    const int lane = threadIdx.x, i0 = (lane >> 3) * 4, j0 = (lane & 7) * 4;
+    const int H = a.n_heads * a.dh, pitch = 3 * H;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv);
+    const T* dctx = reinterpret_cast<const T*>(a.ctx);
+    T* dqkv = reinterpret_cast<T*>(a.dqkv);
+    const float* keep_row = a.key_keep + row0;
+    const int colQ = head * a.dh, colK = H + head * a.dh, colV = 2 * H + head * a.dh;
+    auto keep_scale = [&](int i, int j) -> float {       // dropout factor of element (i, j): 0 or 1 / (1 - p)
+        if (!a.drop.thresh) return 1.f;
+        return drop_keep(a.drop, ((uint64_t)blockIdx.x * TPD + (uint64_t)i) * TPD + (uint64_t)j) ? a.drop.inv_keep : 0.f;
+    };
+    // ---- phase A: statistics.  U1 = masked scaled scores [key][q], U2 = dP o mask [key][q] of one query tile at a time
+    for (int qt = 0; qt < NT; ++qt) {
+        for (int kt = 0; kt < NT; ++kt) {
+            float s[4][4], dp[4][4];
+            long_dot<T>(qkv, pitch, colQ, qkv, pitch, colK, row0, a.dh, a.T, qt, kt, sA, sB, s);
+            long_dot<T>(dctx, H, colQ, qkv, pitch, colV, row0, a.dh, a.T, qt, kt, sA, sB, dp);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float col[4], dcol[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = qt * 32 + i0 + r, j = kt * 32 + j0 + c;
+                    col[r] = long_masked(s[r][c], i, j, a.T, a.causal, a.scale, a.mask_value, keep_row);
+                    dcol[r] = dp[r][c] * keep_scale(i, j);
+                }
+                put_row<4>(U1 + (kt * 32 + j0 + c) * LPP + i0, col);
+                put_row<4>(U2 + (kt * 32 + j0 + c) * LPP + i0, dcol);
+            }
+        }
+        __syncthreads();
+        {
+            const int q = lane & 31, h = lane >> 5, i = qt * 32 + q;
+            float m = -INFINITY;
+            for (int j = h; j < a.T; j += 2) m = fmaxf(m, U1[j * LPP + q]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+            for (int j = h; j < a.T; j += 2) sum += expf(U1[j * LPP + q] - m);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = (i < a.T) ? 1.0f / sum : 0.f;
+            float delta = 0.f;
+            for (int j = h; j < a.T; j += 2) delta += expf(U1[j * LPP + q] - m) * inv * U2[j * LPP + q];
+            delta += __shfl_xor(delta, 32, 64);
+            if (h == 0) { st_m[i] = m; st_i[i] = inv; st_d[i] = delta; }
+        }
+        __syncthreads();
+    }
+    const int c0 = (lane & 7) * LCW;
+    // P and dS of the lane's 4 x 4 block of tile (qt, kt) from the stored statistics
+    auto tile_p_ds = [&](int qt, int kt, float (&p)[4][4], float (&ds)[4][4]) {
+        float s[4][4], dp[4][4];
+        long_dot<T>(qkv, pitch, colQ, qkv, pitch, colK, row0, a.dh, a.T, qt, kt, sA, sB, s);
+        long_dot<T>(dctx, H, colQ, qkv, pitch, colV, row0, a.dh, a.T, qt, kt, sA, sB, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = qt * 32 + i0 + r;
+            const float m = st_m[i], inv = st_i[i], delta = st_d[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = kt * 32 + j0 + c;
+                const float v = long_masked(s[r][c], i, j, a.T, a.causal, a.scale, a.mask_value, keep_row);
+                const float pr = (j < a.T) ? expf(v - m) * inv : 0.f;
+                const float ks = keep_scale(i, j);
+                ds[r][c] = pr * (dp[r][c] * ks - delta) * a.scale;
+                p[r][c] = pr * ks;                       // dV uses the DROPPED probabilities
+            }
+        }
+    };
+    // ---- phase B: dQ.  U1 = dS^T [key][q] of the query tile
+    for (int qt = 0; qt < NT; ++qt) {
+        for (int kt = 0; kt < NT; ++kt) {
+            float p[4][4], ds[4][4];
+            tile_p_ds(qt, kt, p, ds);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float col[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) col[r] = ds[r][c];
+                put_row<4>(U1 + (kt * 32 + j0 + c) * LPP + i0, col);
+            }
+        }
+        __syncthreads();
+        for (int d0 = 0; d0 < a.dh; d0 += LDC) {
+            float o[4][LCW];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < LCW; ++c) o[r][c] = 0.f;
+            for (int kt = 0; kt < NT; ++kt) {
+                stage_chunk<T, LDC, 4>(qkv, row0 + (size_t)kt * 32, pitch, colK, d0, a.dh, min(32, a.T - kt * 32), sB);
+                __syncthreads();
+                long_pv_acc(U1 + kt * 32 * LPP, sB, i0, c0, min(32, a.T - kt * 32), o);
+                __syncthreads();
+            }
+            store_rows<T, LCW, 4>(dqkv, row0 + (size_t)qt * 32, pitch, colQ + d0 + c0, i0, min(32, a.T - qt * 32), d0 + c0, a.dh, o);
+        }
+        __syncthreads();
+    }
+    // ---- phase C: dK, dV.  U1 = dS [q][key of this tile], U2 = P (dropped) [q][key of this tile], all queries
+    for (int kt = 0; kt < NT; ++kt) {
+        for (int qt = 0; qt < NT; ++qt) {
+            float p[4][4], ds[4][4];
+            tile_p_ds(qt, kt, p, ds);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                put_row<4>(U1 + (qt * 32 + i0 + r) * LPP + j0, ds[r]);
+                put_row<4>(U2 + (qt * 32 + i0 + r) * LPP + j0, p[r]);
+            }
+        }
+        __syncthreads();
+        for (int d0 = 0; d0 < a.dh; d0 += LDC) {
+            float ok[4][LCW], ov[4][LCW];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < LCW; ++c) { ok[r][c] = 0.f; ov[r][c] = 0.f; }
+            for (int qt = 0; qt < NT; ++qt) {
+                const int qlen = min(32, a.T - qt * 32);
+                stage_chunk<T, LDC, 4>(qkv, row0 + (size_t)qt * 32, pitch, colQ, d0, a.dh, qlen, sA);
+                stage_chunk<T, LDC, 4>(dctx, row0 + (size_t)qt * 32, H, colQ, d0, a.dh, qlen, sB);
+                __syncthreads();
+                long_pv_acc(U1 + qt * 32 * LPP, sA, i0, c0, qlen, ok);      // dK[key i0 ..][cols] += sum_q dS[q][key] Q[q][cols]
+                long_pv_acc(U2 + qt * 32 * LPP, sB, i0, c0, qlen, ov);      // dV[key i0 ..][cols] += sum_q P[q][key] dO[q][cols]
+                __syncthreads();
+            }
+            store_rows<T, LCW, 4>(dqkv, row0 + (size_t)kt * 32, pitch, colK + d0 + c0, i0, min(32, a.T - kt * 32), d0 + c0, a.dh, ok);
+            store_rows<T, LCW, 4>(dqkv, row0 + (size_t)kt * 32, pitch, colV + d0 + c0, i0, min(32, a.T - kt * 32), d0 + c0, a.dh, ov);
+        }
+        __syncthreads();
+    }
+    (void)TPAD;
+}
+
+constexpr size_t attn_long_fwd_lds() { return (size_t)(2 * 32 * LP + T_LONG_MAX * LPP) * sizeof(float); }
+constexpr size_t attn_long_bwd_lds() { return (size_t)(2 * 32 * LP + 2 * T_LONG_MAX * LPP + 3 * T_LONG_MAX) * sizeof(float); }
+
+template <bool BWD>
+int launch_long(const morec_attn_desc* d, const AttnArgs& a, dim3 grid, hipStream_t s) {
+    if (!by_dtype(d->dtype, [&](auto* t) {
+            using T = MOREC_TAG_T(t);
+            if constexpr (!BWD) {
+                hipLaunchKernelGGL((attn_fwd_long_kernel<T>), grid, dim3(64), attn_long_fwd_lds(), s, a);
+            } else {
+                static const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_long_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_long_bwd_lds());
+                (void)rc;
+                hipLaunchKernelGGL((attn_bwd_long_kernel<T>), grid, dim3(64), attn_long_bwd_lds(), s, a);
+            }
+        }))
+        return MOREC_E_DTYPE;
+    MOREC_CHECK_LAUNCH();
+    return MOREC_OK;
+}
+
+constexpr int T_MAX = T_LONG_MAX;     // 256: the long kernels above; 64 for the tile kernels (launch_valu)
 
 // one launch of the VALU kernels (forward: d-chunks of 64; backward: of 32), tile edge by sequence length
 template <bool BWD>
@@ -383,7 +683,7 @@ int launch_valu(const morec_attn_desc* d, const AttnArgs& a, dim3 grid, hipStrea
 int check_desc(const morec_attn_desc* d) {
     if (!d) return MOREC_E_ARG;
     if (d->n_seq <= 0 || d->T <= 0 || d->n_heads <= 0 || d->dh <= 0) return MOREC_E_ARG;
-    if (d->T > T_MAX) return MOREC_E_UNSUPPORTED;      // 64: the larger of the two tile edges
+    if (d->T > T_MAX) return MOREC_E_UNSUPPORTED;      // 256: the strip kernels (64 < T <= 256); beyond, a row strip no longer fits LDS
     if (d->dh % 8) return MOREC_E_ALIGN;
     if (d->p_drop < 0.f || d->p_drop >= 1.f) return MOREC_E_ARG;
     if (d->total_rows < 0 || d->spare_rows_max < 0 || (d->spare_rows_max > 0 && (!d->cu_seqlens || d->total_rows <= 0))) return MOREC_E_ARG;
@@ -431,6 +731,7 @@ extern "C" int morec_attn_fwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
     (void)block;
+    if (d->T > Tile<8>::TP) return launch_long<false>(d, a, grid, s);
     return launch_valu<false>(d, a, grid, s);
 }
 
@@ -449,6 +750,7 @@ extern "C" int morec_attn_bwd(const morec_attn_desc* d, const void* qkv, const f
     if (rc != MOREC_E_UNSUPPORTED) return rc;
     warn_valu_fallback(d);
     (void)block;
+    if (d->T > Tile<8>::TP) return launch_long<true>(d, a, grid, s);
     return launch_valu<true>(d, a, grid, s);
 }
 

@@ -73,6 +73,8 @@ int morec_version(void);
  *   "gemm8p"             0 = automatic, 1 = never use the 256 x 256 eight-phase GEMM, 2 = use it wherever it is eligible;
  *   "gemm2w"             0 = automatic, 1 = never use the 256 x 128 two-workgroups-per-CU GEMM (gemm2w.hip: the epilogue-heavy products --
  *                        GELU + act' outputs, x act' + column sums -- with >= 1024 tiles), 2 = every eligible 16-bit product; env MOREC_GEMM2W;
+ *   "gemm_small"         0 = automatic, 1 = never use the 64 x 64 four-stage-ring GEMM (gemm_small.hip: the narrow long-K products of the SASRec
+ *                        layers, N-tiles of 128 x 128 < 128 and K >= 1024), 2 = every eligible 16-bit product; outputs bit-identical; env MOREC_GEMM_SMALL;
  *   "gemm8p_tail_split"  1 = split the last, partly filled round of tiles along K between two workgroups (K >= 1536);
  *   "gemm8p_tail_bias"   share of K the first part takes in that split;
  *   "gemm8p_ngroup"      tile order: -1 = automatic column groups (default), 0 = row-major, n = column groups of n N-tiles;
@@ -243,9 +245,11 @@ int morec_pos_grad(const void* dz, float* dpos, int M, int N, int period, int dt
 
 /* ------------------------------------------------------------------------------------------
  * Small-tile multi-head attention on packed projections qkv[M, 3*H] = [Q | K | V], M = n_seq*T,
- * H = n_heads*dh, T <= 64 (T <= 32 with head width % 32 == 0 and 16-bit storage: the matrix-core kernels; otherwise -- fp32, other
- * head widths, 32 < T <= 64: abstracts / bodies of 50 tokens, longer behaviour sequences -- the exact-fp32 VALU kernels; T > 64:
- * MOREC_E_UNSUPPORTED).  scores = (q.k) * scale + (key masked ? mask_value : 0), causal option,
+ * H = n_heads*dh, T <= 256.  16-bit storage, head width % 32 == 0: the matrix-core kernels for T <= 32 and for 32 < T <= 64 (abstracts /
+ * bodies of 50 tokens, T/parameters.py:43-44); fp32 storage, T <= 32, head width % 16 == 0: exact-fp32 MFMA (attention_f32mfma.hip: the
+ * parity and fp32x3 modes); other head widths and fp32 up to T = 64: the exact-fp32 VALU tile kernels; 64 < T <= 256 (longer than any
+ * launcher of the reference sets, accepted by its command line): the row-strip VALU kernels, every dtype; T > 256: MOREC_E_UNSUPPORTED.
+ * scores = (q.k) * scale + (key masked ? mask_value : 0), causal option,
  * softmax, ctx = P.V.   SASRec: T/model/encoders.py:24-27 + T/model/modules.py:27-31 (causal,
  * mask_value -1e9, scale 1/sqrt(d_k)).  BERT: HF BertSelfAttention eager (mask_value finfo.min).
  * key_keep: float [n_seq, T], nonzero = attend.  One wavefront per (sequence, head).
@@ -256,7 +260,7 @@ typedef struct {
     float scale, mask_value;
     int dtype;
     float p_drop;      /* dropout on the attention probabilities (0 = off) */
-    uint64_t seed;     /* element index = ((seq * n_heads + head) * TP + i) * TP + j, TP = 32 for T <= 32, 64 above */
+    uint64_t seed;     /* element index = ((seq * n_heads + head) * TP + i) * TP + j, TP = 32 for T <= 32, 64 for T <= 64, 32 * ceil(T / 32) above */
     const int32_t* cu_seqlens;   /* NULL: every sequence owns T rows.  Otherwise int32[n_seq + 1] (device): sequence s owns rows
                                     cu_seqlens[s] .. cu_seqlens[s+1]-1 (<= T of them) -- the unpadded ("varlen") token layout in
                                     which [PAD] positions are not materialised at all; key_keep is then indexed by packed row */

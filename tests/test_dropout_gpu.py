@@ -60,13 +60,13 @@ def test_layernorm_dropout(dt):
     assert rel(dzd, zs.grad * m_in) < tol
 
 
-@pytest.mark.parametrize("T", [30, 50])
+@pytest.mark.parametrize("T", [30, 50, 100])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention_dropout(dt, T):
     """T = 50: the 64 x 64 tile (abstracts / bodies, T/parameters.py:43-44) -- exact VALU kernels in fp32, attention_mfma64.hip in the 16-bit
     modes -- whose mask stream is indexed with a row pitch of 64."""
     n_seq, nh, dh, p, seed = 4, 3, 64, 0.2, 777
-    TP = 32 if T <= 32 else 64
+    TP = 32 if T <= 32 else (64 if T <= 64 else 32 * ((T + 31) // 32))      # (T > 64: the row-strip kernels, mask pitch 32 * ceil(T / 32))
     H = nh * dh
     g = torch.Generator().manual_seed(1)
     qkv = (0.7 * torch.randn(n_seq * T, 3 * H, generator=g)).to(DEV).to(dt)

@@ -316,7 +316,11 @@ def attn_ref(qkv, keep, n_heads, causal, scale, mask_value):
                                  # 32 < T <= 64 (abstracts / bodies of 50 tokens, T/parameters.py:43-44; longer behaviour sequences): the 64 x 64
                                  # tile -- exact VALU kernels in fp32, attention_mfma64.hip (two k-steps over keys / queries) in the 16-bit modes
                                  (3, 50, 12, 64, False, ops.FLT_MIN_MASK), (2, 48, 2, 256, True, -1e9), (4, 64, 4, 64, True, -1e9),
-                                 (5, 33, 2, 32, False, ops.FLT_MIN_MASK), (3, 40, 2, 128, True, -1e9), (130, 50, 12, 64, False, ops.FLT_MIN_MASK)])
+                                 (5, 33, 2, 32, False, ops.FLT_MIN_MASK), (3, 40, 2, 128, True, -1e9), (130, 50, 12, 64, False, ops.FLT_MIN_MASK),
+                                 # 64 < T <= 256 (longer than any launcher of the reference sets, accepted by its command line): the row-strip
+                                 # kernels of attention.hip in every dtype
+                                 (3, 100, 2, 64, True, -1e9), (2, 128, 12, 64, False, ops.FLT_MIN_MASK), (2, 200, 2, 256, True, -1e9),
+                                 (1, 256, 2, 32, False, ops.FLT_MIN_MASK), (4, 65, 2, 128, True, -1e9)])
 def test_attention(dt, cfg):
     n_seq, T, nh, dh, causal, mv = cfg
     H = nh * dh

@@ -299,15 +299,17 @@ def test_g19_two_text_attributes_golden(golden_dir, dtype):
         print(f"g19 {dtype} fused step (packed={packed}): loss {loss2.item():.6f}, worst grad-norm rel err {worst2:.2e}")
 
 
-@pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16"), (10, 30, "fp16_res32"), (40, 50, "fp16_res32")])
+@pytest.mark.parametrize("S,T,dt", [(10, 30, "fp32"), (40, 50, "fp32"), (40, 50, "fp16"), (10, 30, "fp16_res32"), (40, 50, "fp16_res32"),
+                                    (70, 80, "fp32"), (70, 80, "fp16")])
 def test_oracle_midsize_all_grads(S, T, dt):
     """Every parameter gradient of a mid-size modal model against the CPU oracle (autograd over the restatement).  (40, 50): behaviour
     sequences and texts longer than the 32-row attention tile -- abstracts / bodies of 50 tokens (T/parameters.py:43-44) -- run on the
-    64 x 64 form of the VALU attention kernels (16-bit modes included: they fall back to it)."""
+    64 x 64 form of the VALU attention kernels (16-bit modes included: they fall back to it).  (70, 80): beyond 64 positions -- longer than any
+    launcher of the reference sets, accepted by its command line (T/parameters.py:42-44, --max_seq_len) -- on the row-strip kernels of attention.hip."""
     import morec_oracle as orc
     D, item_num, B = 128, 300, 12
     shape = BertShape(vocab_size=2000, hidden_size=128, num_hidden_layers=3, num_attention_heads=4,
-                      intermediate_size=512, max_position_embeddings=64)
+                      intermediate_size=512, max_position_embeddings=max(64, T))
     # (seed: with 7 the (40, 50) data puts one SASRec FFN pre-activation within rounding of 0, where ReLU' of the GPU and of the CPU oracle
     # legitimately disagree -- w_1's gradient, and only it, was off by one element's worth: scripts/longseq_probe.py)
     rng = np.random.default_rng(7 if S == 10 else 11)
