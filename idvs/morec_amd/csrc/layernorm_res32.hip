@@ -325,7 +325,7 @@ int bwd_launch(const void* dy16, const float* dy32, const float* z, const float*
         slots = nb * n_cu;
         lds_seen = lds;
     }
-    const int rpb = std::max(64, (((M + slots - 1) / slots) + 15) & ~15);
+    const int rpb = std::max(M <= 8192 ? 16 : 64, (((M + slots - 1) / slots) + 15) & ~15);      // (small M: see layernorm.hip, ln_bwd launch)
     dim3 grid((M + rpb - 1) / rpb), block(256);
     float* det = nullptr;
     if ((dgamma || dbias) && morec_deterministic()) {
