@@ -130,16 +130,27 @@ class PowerSampler:
     thread while the `sustained` pass runs: the evidence behind DESIGN.md's "power-limited" reading of the GEMM roofline (a 16-bit MFMA
     main loop draws the part's whole budget below its 2.4 GHz data-sheet clock, which is the clock the 2.5 PFLOP/s peak assumes)."""
 
-    def __init__(self, period=0.02):
+    def __init__(self, period=0.02, pci_bdf=None):
+        """`pci_bdf` ("0000:bb:dd.f"): the PCI address of the GPU the step runs on.  A one-GPU lease on a multi-GPU host still sees every card's hwmon
+        files; without the match the first card with a power file would be sampled -- a neighbour's load (seen in round 6: 342 W / 948 W / 1352 W on
+        three boxes for the same step).  `matched` says whether the sampled card is the step's own; unmatched samples are reported, not interpreted."""
         import glob
         self.period, self.rows, self._stop, self._thr = period, [], False, None
-        self.files = {}
+        self.files, self.matched = {}, False
+        first = None
         for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
             f = {k: os.path.join(d, n) for k, names in (("power", ("power1_average", "power1_input")), ("cap", ("power1_cap",)),
                                                          ("sclk", ("freq1_input",))) for n in names if os.path.exists(os.path.join(d, n))}
-            if "power" in f:
-                self.files = f
+            if "power" not in f:
+                continue
+            if first is None:
+                first = f
+            bdf = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+            if pci_bdf and bdf.lower() == pci_bdf.lower():
+                self.files, self.matched = f, True
                 break
+        if not self.files and first is not None:
+            self.files = first
 
     @staticmethod
     def _read(path):
@@ -173,11 +184,21 @@ class PowerSampler:
             return None
         cap = self._read(self.files["cap"]) if "cap" in self.files else None
         out = {"avg_w": round(sum(pw) / len(pw) / 1e6, 1), "max_w": round(max(pw) / 1e6, 1), "cap_w": (round(cap / 1e6, 1) if cap else None),
-               "samples": len(pw), "source": os.path.dirname(self.files["power"])}
+               "samples": len(pw), "source": os.path.dirname(self.files["power"]), "device_matched": bool(self.matched)}
         if ck:
             out["sclk_mhz_avg"] = round(sum(ck) / len(ck) / 1e6, 1)
             out["sclk_mhz_min"] = round(min(ck) / 1e6, 1)
         return out
+
+
+def _pci_bdf(dev):
+    """PCI address of the torch device ("0000:bb:dd.0"), or None when the properties do not carry it."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev)
+        return f"{int(getattr(pr, 'pci_domain_id', 0)):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -650,7 +671,7 @@ def main():
     if not a.no_secondary and world == 1:
         use_graph["v"] = graph_was
         n_sus, t1 = 0, time.perf_counter()
-        with PowerSampler() as psamp:
+        with PowerSampler(pci_bdf=_pci_bdf(dev)) as psamp:
             while True:
                 for i in range(a.warmup, n_batches):
                     run_step(i)
@@ -810,7 +831,7 @@ def main():
             "measured": f"HIP events around every GEMM launch in an instrumented pass of {n_inst} steps AFTER the headline region (which carries no events); "
                         "single stream in that pass (the headline region overlaps the weight-gradient GEMMs with the dX chain on a second stream: "
                         + ("on" if wgrad_was else "off") + ")"}
-    if sustained is not None and sustained.get("power") and sustained["power"].get("sclk_mhz_avg"):
+    if sustained is not None and sustained.get("power") and sustained["power"].get("sclk_mhz_avg") and sustained["power"].get("device_matched"):
         ck = sustained["power"]["sclk_mhz_avg"]
         roof["at_sustained_clock"] = {"sclk_mhz": ck, "peak": round(peak * ck / 2400.0, 1), "frac": round(tf / (peak * ck / 2400.0), 4),
                                       "note": "the 2.5 PFLOP/s peak is 256 CUs x 4096 FLOP/clk at 2.4 GHz; under this step's load the part holds its power cap at the "

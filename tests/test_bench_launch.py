@@ -65,3 +65,20 @@ def test_two_rank_line_on_one_gpu_carries_the_reduce_trace():
     no_overlap = [c for c in timed if not c["overlap_reduce"]][0]["trace"]
     # without overlap nothing is issued from the backward pass: one closing sweep per arena, at the join
     assert len(no_overlap["buckets"]) <= 2 and all("issued_at_ms" in b for b in no_overlap["buckets"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_watchdog_prints_the_headline_alone():
+    """N > 1: when the explanatory passes behind the timed region do not finish in MOREC_BENCH_WATCHDOG_S (here: a limit they cannot meet), rank 0
+    prints the measured headline with `post_headline` saying so and every rank exits 0 -- a hang in a first real multi-GPU run must not take
+    the measured number with it."""
+    env = dict(_clean_env(), MOREC_BENCH_WATCHDOG_S="0.001")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-device", "--backend", "gloo", "--bert", "tiny", "--batch", "16", "--steps", "3",
+                        "--warmup", "2", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["value"] > 0 and "watchdog" in out["post_headline"]
+    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]
