@@ -81,7 +81,7 @@ __global__ __launch_bounds__(G::THREADS) void gemm_nt_kernel(GemmArgs p) {
     };
 
     // CS: column sums of the finished tile, taken from the LDS staging of the output (no extra accumulator registers per
-    // block): one partial row of p.colsum per 64-row wave block (wave epilogue) or per tile (block epilogue), each written
+    // block): one partial row of p.colsum per wave row block (wave epilogue: MI * 16 rows -- 64, or 32 on the 64 x 64 tiles of gemm_small.hip) or per tile (block epilogue), each written
     // by exactly one wave / workgroup -- the launcher folds the partial rows with one small column-sum launch.
     float csum0 = 0.f, csum1 = 0.f;
     // Fast path: the output tile goes through LDS (free after the main loop) so that every global store is a

@@ -119,7 +119,8 @@ int morec_gemm_nt(const morec_gemm_desc* d, const void* A, const void* B, void* 
 /* Same, and colsum_out[n] += sum_m C[m, n]: with a dact epilogue C is the pre-activation gradient of the layer below, so
  * this is that layer's bias gradient (autograd of nn.Linear: db = dY.sum(0)) without a second pass over C.  The sums are
  * taken from the output tile while it is staged in LDS (the values as rounded to the output dtype), one partial row per
- * 64-row block into `workspace` (morec_gemm_colsum_workspace_bytes(M, N) bytes, fp32), folded by a second small launch.
+ * row block of the kernel's epilogue (32 ... 256 rows) into `workspace` (morec_gemm_colsum_workspace_bytes(M, N) bytes, fp32: sized for the
+ * smallest block, 32 rows), folded by a second small launch.
  * colsum_out == NULL: plain morec_gemm_nt.  MOREC_E_UNSUPPORTED unless dact != NONE, accumulate == 0, split_k <= 1 and
  * the output rows are 16-byte addressable. */
 size_t morec_gemm_colsum_workspace_bytes(int M, int N);
