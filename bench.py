@@ -929,6 +929,8 @@ def main():
                                     (res32 + "_mode", ["--dtype", res32, "--batch", str(a.batch), "--steps", "20", "--warmup", "5"], 0),
                                     ("vision_swin_tiny", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2"], 11),
                                     ("vision_swin_base", ["--tower", "swin_base", "--batch", "32", "--steps", "4", "--warmup", "2"], 11),
+                                    # (BASELINE.json configs[4] names the bf16 MFMA path for Swin-B: the same child in the other 16-bit dtype)
+                                    ("vision_swin_base_" + other16, ["--tower", "swin_base", "--batch", "32", "--steps", "4", "--warmup", "2", "--dtype", other16], 11),
                                     ("vision_u8_pipeline", ["--tower", "swin_tiny", "--batch", "64", "--steps", "6", "--warmup", "2", "--vision-input", "u8"], 11),
                                     # (the two latency-class configurations: 1 - 2 ms per step, so 20 timed steps are 30 ms of wall clock and one host hiccup is 50 % -- 100 steps)
                                     ("id_tower", ["--tower", "id", "--batch", "128", "--steps", "100", "--warmup", "20"], 0),
